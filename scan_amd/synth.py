@@ -1,0 +1,168 @@
+"""Procedural (seeded, network-free) weights and synthetic inputs.
+
+There is no network for ImageNet weights or Cityscapes frames, so the bench and
+every parity test use these generators.  They are keyed by the reference's
+``state_dict`` names so the same tensors can be loaded into the
+reference modules (oracle/make_golden.py), the CPU restatement
+(oracle/scan_ref.py) and the HIP modules (scan_amd/modeling).
+
+Input synthesis follows SURVEY.md 8d: frames are U[0,255) minus
+INPUT.PIXEL_MEAN in BGR order, std 1 (reference fcos_core/config/defaults.py:57-61,
+fcos_core/data/transforms/transforms.py:80-90); source ground truth is 12 boxes
+per image with sqrt(area) log-uniform in [16, 512] px so that all five FCOS
+size-of-interest ranges (fcos_core/modeling/rpn/fcos/loss.py:41-47) are hit.
+"""
+import math
+import zlib
+
+import numpy as np
+import torch
+
+PIXEL_MEAN = (102.9801, 115.9465, 122.7717)
+
+VGG_CONV_IDX = (0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28)
+VGG_CHANNELS = ((3, 64), (64, 64), (64, 128), (128, 128), (128, 256), (256, 256), (256, 256),
+                (256, 512), (512, 512), (512, 512), (512, 512), (512, 512), (512, 512))
+
+
+def _rs(key):
+    return np.random.RandomState(zlib.crc32(key.encode()) & 0x7FFFFFFF)
+
+
+def _normal(key, shape, std):
+    return torch.from_numpy((_rs(key).standard_normal(shape) * std).astype(np.float32))
+
+
+def _uniform(key, shape, bound):
+    return torch.from_numpy(_rs(key).uniform(-bound, bound, shape).astype(np.float32))
+
+
+def _conv(sd, name, cout, cin, k, gain, bias_std=0.02, kw=None):
+    kh, kwid = (k, k) if kw is None else (k, kw)
+    fan_in = cin * kh * kwid
+    sd[name + ".weight"] = _normal(name + ".weight", (cout, cin, kh, kwid), gain / math.sqrt(fan_in))
+    sd[name + ".bias"] = _normal(name + ".bias", (cout,), bias_std)
+
+
+def _gn(sd, name, c):
+    sd[name + ".weight"] = 1.0 + _normal(name + ".weight", (c,), 0.1)
+    sd[name + ".bias"] = _normal(name + ".bias", (c,), 0.1)
+
+
+def _linear(sd, name, cout, cin, gain=1.0):
+    sd[name + ".weight"] = _normal(name + ".weight", (cout, cin), gain / math.sqrt(cin))
+    sd[name + ".bias"] = _normal(name + ".bias", (cout,), 0.02)
+
+
+def _tower(sd, prefix, n, c=256):
+    for i in range(n):
+        _conv(sd, "%s.%d" % (prefix, 3 * i), c, c, 3, math.sqrt(2.0))
+        _gn(sd, "%s.%d" % (prefix, 3 * i + 1), c)
+
+
+def backbone_state_dict():
+    """VGG16 body + FPN(P3..P5) + P6/P7  (reference backbone/backbone.py:21-44)."""
+    sd = {}
+    for idx, (cin, cout) in zip(VGG_CONV_IDX, VGG_CHANNELS):
+        _conv(sd, "body.features.%d" % idx, cout, cin, 3, math.sqrt(2.0))
+    for lvl, cin in ((3, 256), (4, 512), (5, 512)):
+        _conv(sd, "fpn.fpn_inner%d" % lvl, 256, cin, 1, 1.0)
+        _conv(sd, "fpn.fpn_layer%d" % lvl, 256, 256, 3, 1.0)
+    _conv(sd, "fpn.top_blocks.p6", 256, 256, 3, 1.0)
+    _conv(sd, "fpn.top_blocks.p7", 256, 256, 3, math.sqrt(2.0))
+    return sd
+
+
+def middle_head_state_dict(num_classes=9, proto_iter=3):
+    """GRAPHModule (reference rpn/fcos/condgraph.py:127-253)."""
+    K = num_classes
+    sd = {"prototype": _normal("prototype", (K, 256, proto_iter), 1.0)}
+    _tower(sd, "head_in.middle_tower", 2)
+    _conv(sd, "head_out.middle_tower.0", 256, 256 + K, 3, math.sqrt(2.0))
+    _linear(sd, "proto_cls_hidden", 512, 256)
+    _linear(sd, "proto_cls", K, 512)
+    for n in ("linear_k", "linear_v", "linear_q", "linear_final"):
+        _linear(sd, "multihead_attn." + n, 256, 256)
+    sd["multihead_attn.layer_norm.weight"] = 1.0 + _normal("mha.ln.w", (256,), 0.1)
+    sd["multihead_attn.layer_norm.bias"] = _normal("mha.ln.b", (256,), 0.1)
+    _conv(sd, "cond_nx1", 256, 512, proto_iter, 1.0, kw=1)
+    bound = 1.0 / math.sqrt(512)
+    for layer, cin in ((0, 256), (1, 512)):
+        sd["cond_rnn.weight_ih_l%d" % layer] = _uniform("rnn.wih%d" % layer, (512, cin), bound)
+        sd["cond_rnn.weight_hh_l%d" % layer] = _uniform("rnn.whh%d" % layer, (512, 512), bound)
+        sd["cond_rnn.bias_ih_l%d" % layer] = _uniform("rnn.bih%d" % layer, (512,), bound)
+        sd["cond_rnn.bias_hh_l%d" % layer] = _uniform("rnn.bhh%d" % layer, (512,), bound)
+    _linear(sd, "cond_2", 256, 512)
+    return sd
+
+
+def fcos_state_dict(num_classes=9):
+    """FCOSHead (reference rpn/fcos/fcos.py:13-87)."""
+    sd = {}
+    _tower(sd, "head.cls_tower", 4)
+    _tower(sd, "head.bbox_tower", 4)
+    _conv(sd, "head.cls_logits", num_classes - 1, 256, 3, 0.5)
+    sd["head.cls_logits.bias"] = sd["head.cls_logits.bias"] - math.log(99.0)
+    _conv(sd, "head.bbox_pred", 4, 256, 3, 0.5)
+    sd["head.bbox_pred.bias"] = sd["head.bbox_pred.bias"] + 2.0
+    _conv(sd, "head.centerness", 1, 256, 3, 0.5)
+    for i in range(5):
+        sd["head.scales.%d.scale" % i] = torch.tensor([1.0 + 0.05 * i], dtype=torch.float32)
+    return sd
+
+
+def discriminator_state_dict(level, num_classes=9):
+    """FCOSDiscriminator_con (reference discriminator/fcos_head_discriminator_con.py:12-87)."""
+    sd = {}
+    tag = "dis_%s" % level
+    t = {}
+    _tower(t, tag + ".dis_tower", 4)
+    for c in range(num_classes - 1):
+        _conv(t, "%s.classifier_cls_%d.0" % (tag, c), 128, 257, 3, math.sqrt(2.0))
+        _conv(t, "%s.classifier_cls_%d.2" % (tag, c), 1, 128, 3, 1.0)
+    for k, v in t.items():
+        sd[k[len(tag) + 1:]] = v
+    return sd
+
+
+LEVEL_NAMES = ("P3", "P4", "P5", "P6", "P7")
+
+
+def all_state_dicts(num_classes=9):
+    out = {
+        "backbone": backbone_state_dict(),
+        "middle_head": middle_head_state_dict(num_classes),
+        "fcos": fcos_state_dict(num_classes),
+    }
+    for lvl in LEVEL_NAMES:
+        out["dis_%s_CON" % lvl] = discriminator_state_dict(lvl, num_classes)
+    return out
+
+
+def synth_images(n, h, w, seed0=1234):
+    """[n,3,h,w] fp32, U[0,255) - PIXEL_MEAN (BGR), one generator seed per image."""
+    imgs = []
+    mean = np.asarray(PIXEL_MEAN, dtype=np.float32).reshape(3, 1, 1)
+    for i in range(n):
+        rs = np.random.RandomState(seed0 + i)
+        imgs.append(torch.from_numpy(rs.uniform(0.0, 255.0, (3, h, w)).astype(np.float32) - mean))
+    return torch.stack(imgs, 0)
+
+
+def synth_targets(n, h, w, num_fg=8, boxes_per_img=12, seed0=4321):
+    """Per image: (boxes [G,4] xyxy fp32, labels [G] int64 in 1..num_fg)."""
+    out = []
+    smax = min(512.0, 0.9 * min(h, w))
+    smin = min(16.0, smax / 4)
+    for i in range(n):
+        rs = np.random.RandomState(seed0 + i)
+        side = np.exp(rs.uniform(math.log(smin), math.log(smax), boxes_per_img))
+        aspect = rs.uniform(0.5, 2.0, boxes_per_img)
+        bw = np.minimum(side * np.sqrt(aspect), w - 2.0)
+        bh = np.minimum(side / np.sqrt(aspect), h - 2.0)
+        cx = rs.uniform(bw / 2, w - 1 - bw / 2)
+        cy = rs.uniform(bh / 2, h - 1 - bh / 2)
+        boxes = np.stack([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], 1).astype(np.float32)
+        labels = rs.randint(1, num_fg + 1, boxes_per_img).astype(np.int64)
+        out.append((torch.from_numpy(boxes), torch.from_numpy(labels)))
+    return out

@@ -1,0 +1,178 @@
+/*
+ * scan_hip.h -- C ABI of libscan_hip.so, the MI355X (gfx950) hot path of the
+ * SCAN FCOS-based domain-adaptive detector.
+ *
+ * Every entry point takes plain device pointers + sizes and a HIP stream
+ * (void* == hipStream_t; NULL = the null stream).  Nothing here allocates,
+ * frees or synchronises unless stated, so calls are graph-capturable.
+ * Return value: 0 on success, <0 on error (scan_last_error() gives the text;
+ * the Python host raises RuntimeError, mirroring the reference's AT_ASSERTM /
+ * AT_ERROR -> RuntimeError behaviour, csrc/nms.h:10-28, csrc/SigmoidFocalLoss.h:10-41).
+ *
+ * Layout convention ("pyramid"): an activation is a row-major fp32 matrix
+ * [M, C] whose rows are pixels in level-major, then image, then y, then x
+ * order -- exactly the order the reference flattens to before its losses
+ * (rpn/fcos/loss.py:191-202, condgraph.py:348-351).  A scan_pyramid_t says how
+ * the rows split into levels.  A plain NHWC tensor is a pyramid with 1 level.
+ *
+ * Each function cites the reference interface it replaces
+ * (paths relative to the reference checkout, fcos_core/...).
+ */
+#ifndef SCAN_HIP_H
+#define SCAN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCAN_MAX_LEVELS 5
+
+typedef struct {
+  int32_t n_levels;              /* 1..5 */
+  int32_t n_images;              /* N */
+  int32_t h[SCAN_MAX_LEVELS];    /* per-level height */
+  int32_t w[SCAN_MAX_LEVELS];    /* per-level width  */
+  int64_t row_off[SCAN_MAX_LEVELS + 1]; /* first row of each level; row_off[n_levels] = M */
+} scan_pyramid_t;
+
+const char* scan_last_error(void);
+int scan_abi_version(void);
+
+/* ---- SigmoidFocalLoss  (replaces _C.sigmoid_focalloss_forward / _backward,
+ *      csrc/SigmoidFocalLoss.h:10-41, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-187) ----
+ * logits [M,C] fp32, targets [M] int32 (0 = bg, c = class c, <0 = ignore).
+ * losses may be NULL; loss_sum (1 float, pre-zeroed by caller) may be NULL:
+ * when given, the wavefront-reduced total is atomically added to it, which is
+ * what layers/sigmoid_focal_loss.py:56-70 (`loss.sum()`) consumes. */
+int scan_sigmoid_focal_loss_forward(const float* logits, const int32_t* targets, int64_t M, int32_t C,
+                                    float gamma, float alpha, float* losses, float* loss_sum, void* stream);
+/* d_losses [M,C] or NULL; when NULL every element uses d_scale (the fused
+ * `sum()/(num_pos+N)` backward, rpn/fcos/loss.py:204-208). */
+int scan_sigmoid_focal_loss_backward(const float* logits, const int32_t* targets, const float* d_losses,
+                                     float d_scale, int64_t M, int32_t C, float gamma, float alpha,
+                                     float* d_logits, void* stream);
+
+/* ---- IOULoss (replaces layers/iou_loss.py:5-36) ----
+ * pred/target [P,4] (l,t,r,b), weight [P] or NULL.  out[0] += sum(loss*w),
+ * out[1] += sum(w) (w = 1 when NULL); caller pre-zeroes out[2] and divides. */
+int scan_iou_loss_forward(const float* pred, const float* target, const float* weight, int64_t P,
+                          float* out2, void* stream);
+/* d_pred[i,:] = g_num * w_i * dloss_i/dpred  with g_num = upstream / sum(w) read from g_num_dev[0]. */
+int scan_iou_loss_backward(const float* pred, const float* target, const float* weight, int64_t P,
+                           const float* g_num_dev, float* d_pred, void* stream);
+
+/* ---- BCE-with-logits, optionally weighted (replaces F.binary_cross_entropy_with_logits as used by
+ *      discriminator/fcos_head_discriminator_con.py:117-123 and rpn/fcos/loss.py:221-224) ----
+ * logits [M] (stride 1), weight element i at weight[i*w_stride] or NULL, constant target.
+ * out[0] += sum(w * bce), out[1] += sum(w). */
+int scan_bce_logits_forward(const float* logits, const float* targets, float const_target,
+                            const float* weight, int64_t w_stride, int64_t M, float* out2, void* stream);
+/* d_logits[i] = g_dev[0] * w_i * (sigmoid(x_i) - t_i) */
+int scan_bce_logits_backward(const float* logits, const float* targets, float const_target,
+                             const float* weight, int64_t w_stride, int64_t M, const float* g_dev,
+                             float* d_logits, void* stream);
+
+/* ---- CKA class-conditional adversarial loss (replaces the per-class loop of
+ *      discriminator/fcos_head_discriminator_con.py:105-124, num_classes > 1 branch) ----
+ * logits [M,Cf] (one column per foreground class), act [M,Cf+1] softmax maps (column 0 = background),
+ * constant domain target t.  out[2*c] += sum_m act[m][c+1]*bce(logits[m][c], t), out[2*c+1] += sum_m act[m][c+1].
+ * The host forms  sum_c (out[2c]/out[2c+1]) / Cf.   Cf <= 16. */
+int scan_cka_bce_forward(const float* logits, const float* act, int64_t M, int32_t Cf, float target, float* out,
+                         void* stream);
+/* d_logits[m][c] = g_dev[c] * act[m][c+1] * (sigmoid(x) - t),  g_dev[c] = upstream / (Cf * sum_w[c]) */
+int scan_cka_bce_backward(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
+                          const float* g_dev, float* d_logits, void* stream);
+
+/* ---- y = alpha * x  (GradientReversalFunction: forward alpha = 1 copy, backward alpha = -lambda;
+ *      discriminator/layer.py:6-24) ---- */
+int scan_scale(const float* x, float alpha, float* y, int64_t n, void* stream);
+
+/* ---- semantic-conditioned dynamic 1x1 conv + channel softmax
+ *      (replaces GRAPHModule.dynamic_conv + softmax, rpn/fcos/condgraph.py:619-629, 344-346) ----
+ * feat [M,C] (C % 4 == 0), kernels [K,C] (K <= 16) -> logits [M,K], probs [M,K]. */
+int scan_dynconv_softmax_forward(const float* feat, const float* kernels, int64_t M, int32_t C, int32_t K,
+                                 float* logits, float* probs, void* stream);
+/* d_logits_in [M,K] or NULL (grad arriving at the logits, e.g. from the act loss), d_probs [M,K] or NULL.
+ * Writes d_feat [M,C] (overwrites) and d_kernels [K,C] (overwrites; uses ws of size >= grid*K*C floats,
+ * see scan_dynconv_ws_floats). */
+int64_t scan_dynconv_ws_floats(int64_t M, int32_t C, int32_t K);
+int scan_dynconv_softmax_backward(const float* feat, const float* kernels, const float* probs,
+                                  const float* d_logits_in, const float* d_probs, int64_t M, int32_t C,
+                                  int32_t K, float* d_feat, float* d_kernels, float* ws, void* stream);
+
+/* ---- softmax focal loss of the activation maps (replaces layers/sigmoid_focal_loss_wbg.py:38-64,
+ *      alpha = 1, gamma = 2, mean over rows) ----
+ * logits [M,K], labels int64 [M]; loss_sum[0] += sum_i -(1-p_i)^g log p_i  (caller divides by M). */
+int scan_softmax_focal_forward(const float* logits, const int64_t* labels, int64_t M, int32_t K, float gamma,
+                               float* loss_sum, void* stream);
+int scan_softmax_focal_backward(const float* logits, const int64_t* labels, int64_t M, int32_t K, float gamma,
+                                float d_scale, float* d_logits, void* stream);
+
+/* ---- NMS (replaces _C.nms, csrc/nms.h:10-28, csrc/cpu/nms_cpu.cpp:5-65, csrc/cuda/nms.cu:23-131;
+ *      and _C.ml_nms, csrc/ml_nms.h:10-27, csrc/cuda/ml_nms.cu:13-136) ----
+ * dets [n,4] xyxy, scores [n], labels [n] float or NULL (NULL = plain nms).
+ * rule_ge != 0: suppress when IoU >= thr (the CPU rule, nms_cpu.cpp:60 -- the oracle);
+ * rule_ge == 0: suppress when IoU >  thr (the CUDA rule, nms.cu:60).
+ * keep_out [n] int64 receives the kept ORIGINAL indices ascending, num_keep_out[0] their count
+ * (both device memory).  workspace: scan_nms_ws_bytes(n) bytes.  n <= SCAN_NMS_MAX. */
+#define SCAN_NMS_MAX 8192
+int64_t scan_nms_ws_bytes(int64_t n);
+int scan_nms(const float* dets, const float* scores, const float* labels, int64_t n, float thr, int32_t rule_ge,
+             int64_t* keep_out, int32_t* num_keep_out, void* workspace, void* stream);
+
+/* ---- convolution as fp32-MFMA implicit GEMM (replaces nn.Conv2d / F.conv2d at the call sites of
+ *      backbone/mmdetection/vgg.py:8-33, backbone/fpn.py:52-66,118-130,
+ *      rpn/fcos/condgraph.py:86-106, rpn/fcos/fcos.py:25-64, discriminator/fcos_head_discriminator_con.py:20-62) ----
+ * x: pyramid [Mi, Cin_s] (row stride Cin_s floats, Cin_s % 4 == 0, channels >= Cin are zero padding)
+ * w: [Cout][k*k][Cin_s] fp32 ("OHWI", what a channels_last torch weight is physically)
+ * y: pyramid [Mo, Cout_s]; bias [Cout] or NULL; relu != 0 fuses max(0,.).
+ * ksize in {1,3}; stride in {1,2}; pad = ksize/2. */
+int scan_conv2d_forward(const float* x, const scan_pyramid_t* xd, int32_t Cin_s, const float* w, const float* bias,
+                        float* y, const scan_pyramid_t* yd, int32_t Cout, int32_t Cout_s, int32_t ksize,
+                        int32_t stride, int32_t relu, void* stream);
+/* dX = conv_transpose(dY, W).  wt: [Cin][k*k][Cout_s] (the transposed copy made by scan_weight_transpose).
+ * mask (optional, same shape as dx): dx is zeroed where mask <= 0 (ReLU backward of the producer). */
+int scan_conv2d_dgrad(const float* dy, const scan_pyramid_t* yd, int32_t Cout_s, const float* wt, float* dx,
+                      const scan_pyramid_t* xd, int32_t Cin, int32_t Cin_s, int32_t ksize, int32_t stride,
+                      const float* mask, void* stream);
+/* dW[Cout][k*k][Cin_s] = sum_m dY[m][o] * X[tap(m)][c]; deterministic split-K through ws
+ * (scan_conv2d_wgrad_ws_floats) followed by an in-order reduction.  accumulate != 0: dW += result. */
+int64_t scan_conv2d_wgrad_ws_floats(const scan_pyramid_t* yd, int32_t Cin_s, int32_t Cout, int32_t ksize);
+int scan_conv2d_wgrad(const float* x, const scan_pyramid_t* xd, int32_t Cin_s, const float* dy,
+                      const scan_pyramid_t* yd, int32_t Cout, int32_t Cout_s, int32_t ksize, int32_t stride,
+                      float* dw, int32_t accumulate, float* ws, void* stream);
+/* w [Cout][T][Cin_s] -> wt [Cin_s][T][Cout_s] (zero padded) */
+int scan_weight_transpose(const float* w, int32_t Cout, int32_t T, int32_t Cin_s, float* wt, int32_t Cout_s,
+                          void* stream);
+/* column sums: db[c] (+)= sum_m dy[m][c], c < C; ws >= scan_colsum_ws_floats */
+int64_t scan_colsum_ws_floats(int64_t M, int32_t C);
+int scan_colsum(const float* dy, int64_t M, int32_t C, int32_t ld, float* db, int32_t accumulate, float* ws,
+                void* stream);
+/* out = dy * (y > 0)   (ReLU backward; y is the ReLU output; out may alias dy) */
+int scan_relu_backward(const float* dy, const float* y, float* out, int64_t n, void* stream);
+
+/* ---- GroupNorm(32 groups) + ReLU on a pyramid (replaces nn.GroupNorm(32,C)+nn.ReLU in the towers,
+ *      condgraph.py:99-105, fcos.py:36-49, fcos_head_discriminator_con.py:31-32) ----
+ * stats [n_levels*N*G*2] = (mean, rstd) per (level, image, group), eps = 1e-5.
+ * ws (8-byte aligned): scan_groupnorm_ws_floats floats, used as fp64 accumulators. */
+int scan_groupnorm_stats(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G, float eps, float* stats,
+                         float* ws, void* stream);
+int scan_groupnorm_relu_forward(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G, const float* stats,
+                                const float* gamma, const float* beta, int32_t relu, float* y, void* stream);
+int64_t scan_groupnorm_ws_floats(const scan_pyramid_t* d, int32_t C, int32_t G);
+/* dx, dgamma[C] (+)=, dbeta[C] (+)=; y is the forward output (for the ReLU mask); ws: scan_groupnorm_ws_floats */
+int scan_groupnorm_relu_backward(const float* x, const float* y, const float* dy, const scan_pyramid_t* d, int32_t C,
+                                 int32_t G, const float* stats, const float* gamma, int32_t relu, float* dx,
+                                 float* dgamma, float* dbeta, int32_t accumulate, float* ws, void* stream);
+
+/* ---- fused SGD with momentum (replaces torch.optim.SGD as configured by solver/build.py:7-43) ----
+ * g' = g + wd*p ; buf = momentum*buf + g' ; p -= lr*buf   (first_step != 0: buf = g') */
+int scan_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float wd, float momentum,
+                      int32_t first_step, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCAN_HIP_H */

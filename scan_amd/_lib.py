@@ -1,0 +1,92 @@
+"""ctypes binding of libscan_hip.so (the C ABI declared in include/scan_hip.h).
+
+The library is the product: there is no CPU or PyTorch fallback.  ``lib()``
+raises if the shared object is missing and every compute entry point raises
+``RuntimeError`` (with ``scan_last_error()``) on a non-zero return, mirroring
+the reference's AT_ASSERTM/AT_ERROR -> RuntimeError behaviour
+(reference fcos_core/csrc/nms.h:10-28, csrc/SigmoidFocalLoss.h:10-41).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscan_hip.so")
+
+MAX_LEVELS = 5
+NMS_MAX = 8192
+
+c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
+
+
+class PyramidDesc(ctypes.Structure):
+    """scan_pyramid_t"""
+    _fields_ = [("n_levels", c_i32), ("n_images", c_i32), ("h", c_i32 * MAX_LEVELS), ("w", c_i32 * MAX_LEVELS),
+                ("row_off", c_i64 * (MAX_LEVELS + 1))]
+
+
+_PD = ctypes.POINTER(PyramidDesc)
+
+# name -> (restype, argtypes); every symbol include/scan_hip.h declares
+SIGNATURES = {
+    "scan_last_error": (ctypes.c_char_p, []),
+    "scan_abi_version": (ctypes.c_int, []),
+    "scan_sigmoid_focal_loss_forward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp]),
+    "scan_sigmoid_focal_loss_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp]),
+    "scan_iou_loss_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
+    "scan_iou_loss_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp]),
+    "scan_bce_logits_forward": (ctypes.c_int, [c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp, c_vp]),
+    "scan_bce_logits_backward": (ctypes.c_int, [c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp, c_vp, c_vp]),
+    "scan_cka_bce_forward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp]),
+    "scan_cka_bce_backward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "scan_scale": (ctypes.c_int, [c_vp, c_f32, c_vp, c_i64, c_vp]),
+    "scan_dynconv_softmax_forward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "scan_dynconv_ws_floats": (c_i64, [c_i64, c_i32, c_i32]),
+    "scan_dynconv_softmax_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "scan_softmax_focal_forward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp]),
+    "scan_softmax_focal_backward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp]),
+    "scan_nms_ws_bytes": (c_i64, [c_i64]),
+    "scan_nms": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "scan_conv2d_forward": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_vp, _PD, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "scan_conv2d_dgrad": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, _PD, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "scan_conv2d_wgrad_ws_floats": (c_i64, [_PD, c_i32, c_i32, c_i32]),
+    "scan_conv2d_wgrad": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, _PD, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "scan_weight_transpose": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    "scan_colsum_ws_floats": (c_i64, [c_i64, c_i32]),
+    "scan_colsum": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "scan_relu_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "scan_groupnorm_stats": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
+    "scan_groupnorm_relu_forward": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "scan_groupnorm_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
+    "scan_groupnorm_relu_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "scan_sgd_momentum": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_i32, c_vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libscan_hip.so; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "scan_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def call(name, *args):
+    """Call a status-returning entry point; raise RuntimeError on failure."""
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (name, rc, lib().scan_last_error().decode()))
+
+
+def query(name, *args):
+    return getattr(lib(), name)(*args)

@@ -1,0 +1,252 @@
+// Greedy NMS / label-aware NMS entirely on the device for gfx950.
+// Replaces _C.nms / _C.ml_nms (reference csrc/nms.h:10-28, csrc/cpu/nms_cpu.cpp:5-65,
+// csrc/cuda/nms.cu:23-131, csrc/ml_nms.h:10-27, csrc/cuda/ml_nms.cu:13-136).
+//
+// Three launches on the caller's stream, no host round trip (the reference copies the
+// n x n/64 mask to the host and scans there, nms.cu:100-123):
+//   1. one-workgroup LDS bitonic sort of (score desc, index asc) keys  -> order, sorted boxes
+//   2. 64x64 IoU tiles: one wavefront per tile, one u64 suppression word per (row, col-tile)
+//   3. one-workgroup scan: wave 0 resolves each 64-box diagonal tile with scalar
+//      readlane chains and ORs the kept rows' words into the running mask; then the whole
+//      workgroup compacts the kept ORIGINAL indices in ascending order.
+//
+// Compiled with -ffp-contract=off: every product/sum is a separately rounded fp32 op in
+// the oracle's order, so keep indices are bit-exact against oracle/scan_oracle.c.
+#include "common.h"
+
+typedef unsigned long long u64;
+
+__device__ __forceinline__ unsigned int f2sortable_desc(float f) {
+  unsigned int u = __float_as_uint(f);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending order-preserving
+  return ~u;                                       // descending
+}
+
+// n_pad = power of two >= n, <= 8192.  1024 threads.
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ dets,
+                                                        const float* __restrict__ scores,
+                                                        const float* __restrict__ labels, int n, int n_pad,
+                                                        int* __restrict__ order, float4* __restrict__ boxes_sorted,
+                                                        float* __restrict__ labels_sorted,
+                                                        float* __restrict__ areas_sorted) {
+  extern __shared__ u64 keys[];
+  for (int i = threadIdx.x; i < n_pad; i += blockDim.x)
+    keys[i] = (i < n) ? (((u64)f2sortable_desc(scores[i]) << 32) | (unsigned int)i) : ~0ull;
+  __syncthreads();
+  for (int k = 2; k <= n_pad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = threadIdx.x; i < n_pad; i += blockDim.x) {
+        const int ixj = i ^ j;
+        if (ixj > i) {
+          const u64 a = keys[i], b = keys[ixj];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            keys[i] = b;
+            keys[ixj] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const int o = (int)(keys[i] & 0xffffffffu);
+    order[i] = o;
+    const float4 b = reinterpret_cast<const float4*>(dets)[o];
+    boxes_sorted[i] = b;
+    areas_sorted[i] = (b.z - b.x + 1.0f) * (b.w - b.y + 1.0f);
+    labels_sorted[i] = labels ? labels[o] : 0.f;
+  }
+}
+
+// grid (nb, nb), 64 threads: block (cb, rb) computes mask[row][cb] for rows of tile rb
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ boxes,
+                                                      const float* __restrict__ areas,
+                                                      const float* __restrict__ labels, int n, float thr, int rule_ge,
+                                                      int use_labels, u64* __restrict__ mask, int nb) {
+  const int cb = blockIdx.x, rb = blockIdx.y;
+  if (cb < rb) return;  // only later (lower-score) boxes can be suppressed
+  __shared__ float4 cbox[64];
+  __shared__ float carea[64];
+  __shared__ float clab[64];
+  const int t = threadIdx.x;
+  const int cj = cb * 64 + t;
+  if (cj < n) {
+    cbox[t] = boxes[cj];
+    carea[t] = areas[cj];
+    clab[t] = labels[cj];
+  }
+  __syncthreads();
+  const int i = rb * 64 + t;
+  if (i >= n) return;
+  const float4 a = boxes[i];
+  const float iarea = areas[i];
+  const float ilab = labels[i];
+  const int csize = (n - cb * 64) < 64 ? (n - cb * 64) : 64;
+  u64 bits = 0;
+  const int start = (rb == cb) ? t + 1 : 0;
+  for (int j = start; j < csize; ++j) {
+    if (use_labels && ilab != clab[j]) continue;
+    const float4 b = cbox[j];
+    const float xx1 = fmaxf(a.x, b.x), yy1 = fmaxf(a.y, b.y);
+    const float xx2 = fminf(a.z, b.z), yy2 = fminf(a.w, b.w);
+    const float w = fmaxf(0.0f, xx2 - xx1 + 1.0f);
+    const float h = fmaxf(0.0f, yy2 - yy1 + 1.0f);
+    const float inter = w * h;
+    const float ovr = inter / (iarea + carea[j] - inter);
+    const bool sup = rule_ge ? (ovr >= thr) : (ovr > thr);
+    if (sup) bits |= 1ull << j;
+  }
+  mask[(int64_t)i * nb + cb] = bits;
+}
+
+__device__ __forceinline__ u64 readlane64(u64 v, int lane_const) {
+  const unsigned int lo = __builtin_amdgcn_readlane((int)(v & 0xffffffffu), lane_const);
+  const unsigned int hi = __builtin_amdgcn_readlane((int)(v >> 32), lane_const);
+  return ((u64)hi << 32) | lo;
+}
+
+// one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void nms_scan_kernel(const u64* __restrict__ mask, const int* __restrict__ order,
+                                                        int n, int nb, int64_t* __restrict__ keep_out,
+                                                        int* __restrict__ num_keep) {
+  __shared__ u64 remv[SCAN_NMS_MAX / 64];
+  __shared__ unsigned char flag[SCAN_NMS_MAX];  // by ORIGINAL index
+  __shared__ int wave_tot[16];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = tid; i < SCAN_NMS_MAX / 64; i += blockDim.x) remv[i] = 0;
+  for (int i = tid; i < SCAN_NMS_MAX; i += blockDim.x) flag[i] = 0;
+  __syncthreads();
+  if (wid == 0) {
+    for (int c = 0; c < nb; ++c) {
+      const int row = c * 64 + lane;
+      const u64 diag = (row < n) ? mask[(int64_t)row * nb + c] : 0ull;
+      u64 cur = remv[c];
+      const int valid = (n - c * 64) < 64 ? (n - c * 64) : 64;
+      u64 keep = 0;
+#pragma unroll
+      for (int j = 0; j < 64; ++j) {
+        const u64 dj = readlane64(diag, j);
+        if (j < valid && !((cur >> j) & 1ull)) {
+          keep |= 1ull << j;
+          cur |= dj;
+        }
+      }
+      // record kept boxes by original index
+      if (row < n && ((keep >> lane) & 1ull)) flag[order[row]] = 1;
+      // OR the kept rows' words into the running mask of the later tiles
+      for (int w0 = c + 1; w0 < nb; w0 += 64) {
+        const int w = w0 + lane;
+        u64 acc = 0;
+        if (w < nb) {
+          u64 kk = keep;
+          while (kk) {
+            const int j = __ffsll((long long)kk) - 1;
+            kk &= kk - 1;
+            acc |= mask[(int64_t)(c * 64 + j) * nb + w];
+          }
+          remv[w] |= acc;
+        }
+      }
+      // remv is only touched by wave 0; make the LDS writes visible before the next read
+      __builtin_amdgcn_s_waitcnt(0);
+    }
+  }
+  __syncthreads();
+  // compaction: thread t owns original indices [8t, 8t+8)
+  int cnt = 0;
+  unsigned int bits = 0;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const int i = tid * 8 + e;
+    if (i < n && flag[i]) {
+      bits |= 1u << e;
+      ++cnt;
+    }
+  }
+  int incl = cnt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wave_tot[wid] = incl;
+  __syncthreads();
+  int base = 0;
+  for (int w = 0; w < wid; ++w) base += wave_tot[w];
+  int pos = base + incl - cnt;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (bits & (1u << e)) keep_out[pos++] = (int64_t)(tid * 8 + e);
+  if (tid == blockDim.x - 1) num_keep[0] = base + incl;
+}
+
+static int next_pow2(int n) {
+  int p = 64;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+struct NmsWs {
+  int* order;
+  float4* boxes;
+  float* labels;
+  float* areas;
+  u64* mask;
+  size_t bytes;
+};
+static NmsWs nms_layout(void* base, int64_t n) {
+  NmsWs w;
+  const int n_pad = next_pow2((int)n);
+  const int nb = (int)((n + 63) / 64);
+  char* p = reinterpret_cast<char*>(base);
+  size_t off = 0;
+  w.boxes = reinterpret_cast<float4*>(p + off);
+  off += sizeof(float4) * n_pad;
+  w.mask = reinterpret_cast<u64*>(p + off);
+  off += sizeof(u64) * (size_t)n_pad * (nb > 0 ? nb : 1);
+  w.order = reinterpret_cast<int*>(p + off);
+  off += sizeof(int) * n_pad;
+  w.labels = reinterpret_cast<float*>(p + off);
+  off += sizeof(float) * n_pad;
+  w.areas = reinterpret_cast<float*>(p + off);
+  off += sizeof(float) * n_pad;
+  w.bytes = off;
+  return w;
+}
+
+extern "C" int64_t scan_nms_ws_bytes(int64_t n) {
+  if (n <= 0) return 16;
+  if (n > SCAN_NMS_MAX) return -1;
+  return (int64_t)nms_layout(nullptr, n).bytes;
+}
+
+extern "C" int scan_nms(const float* dets, const float* scores, const float* labels, int64_t n, float thr,
+                        int32_t rule_ge, int64_t* keep_out, int32_t* num_keep_out, void* workspace, void* stream) {
+  SCAN_CHECK_ARG(n >= 0, "nms: negative n");
+  SCAN_CHECK_ARG(n <= SCAN_NMS_MAX, "nms: n=%lld exceeds SCAN_NMS_MAX=%d", (long long)n, SCAN_NMS_MAX);
+  SCAN_CHECK_ARG(num_keep_out, "nms: null num_keep_out");
+  hipStream_t st = as_stream(stream);
+  if (n == 0) {
+    if (hipMemsetAsync(num_keep_out, 0, sizeof(int), st) != hipSuccess) {
+      scan_set_error("nms: memset failed");
+      return -2;
+    }
+    return 0;
+  }
+  SCAN_CHECK_ARG(dets && scores && keep_out && workspace, "nms: null pointer");
+  SCAN_CHECK_ARG((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(dets) & 15) == 0,
+                 "nms: dets/workspace must be 16-byte aligned");
+  const NmsWs w = nms_layout(workspace, n);
+  const int n_pad = next_pow2((int)n);
+  const int nb = (int)((n + 63) / 64);
+  hipLaunchKernelGGL(nms_sort_kernel, dim3(1), dim3(1024), sizeof(u64) * n_pad, st, dets, scores, labels, (int)n, n_pad,
+                     w.order, w.boxes, w.labels, w.areas);
+  SCAN_LAUNCH_CHECK("nms_sort");
+  hipLaunchKernelGGL(nms_mask_kernel, dim3(nb, nb), dim3(64), 0, st, w.boxes, w.areas, w.labels, (int)n, thr, rule_ge,
+                     labels != nullptr ? 1 : 0, w.mask, nb);
+  SCAN_LAUNCH_CHECK("nms_mask");
+  hipLaunchKernelGGL(nms_scan_kernel, dim3(1), dim3(1024), 0, st, w.mask, w.order, (int)n, nb, keep_out, num_keep_out);
+  SCAN_LAUNCH_CHECK("nms_scan");
+  return 0;
+}

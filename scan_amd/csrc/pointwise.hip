@@ -1,0 +1,440 @@
+// HBM-bound pointwise / reduction kernels of the SCAN hot path for gfx950:
+// SigmoidFocalLoss, IoU loss, (weighted) BCE-with-logits, GRL scale, softmax focal
+// loss, fused SGD.  64-lane wavefront reductions, float4 streaming where the layout
+// allows, grid capped at 2048 blocks with grid-stride loops.
+#include <float.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------ sigmoid focal loss
+// follows the reference's stable CUDA formula, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-101
+__device__ __forceinline__ float focal_fwd_elem(float x, int t, int d, float gamma, float alpha) {
+  const float c1 = (t == d + 1) ? 1.f : 0.f;
+  const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
+  const float p = 1.f / (1.f + expf(-x));
+  const float term1 = powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
+  const float ge = (x >= 0.f) ? 1.f : 0.f;
+  const float term2 = powf(p, gamma) * (-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge)));
+  return -c1 * term1 * alpha - c2 * term2 * (1.f - alpha);
+}
+__device__ __forceinline__ float focal_bwd_elem(float x, int t, int d, float gamma, float alpha) {
+  const float c1 = (t == d + 1) ? 1.f : 0.f;
+  const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
+  const float p = 1.f / (1.f + expf(-x));
+  const float term1 = powf(1.f - p, gamma) * (1.f - p - (p * gamma * logf(fmaxf(p, FLT_MIN))));
+  const float ge = (x >= 0.f) ? 1.f : 0.f;
+  const float term2 =
+      powf(p, gamma) * ((-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge))) * (1.f - p) * gamma - p);
+  return -c1 * term1 * alpha - c2 * term2 * (1.f - alpha);
+}
+
+__global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ logits,
+                                                        const int* __restrict__ targets, int64_t total, int C,
+                                                        float gamma, float alpha, float* __restrict__ losses,
+                                                        float* __restrict__ loss_sum) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const int64_t n4 = (total + 3) >> 2;
+  const bool vec = (total & 3) == 0;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = q << 2;
+    float x[4], l[4];
+    if (vec) {
+      const float4 v = reinterpret_cast<const float4*>(logits)[q];
+      x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = (i0 + e < total) ? logits[i0 + e] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t i = i0 + e;
+      l[e] = 0.f;
+      if (i < total) {
+        const int64_t n = i / C;
+        const int d = (int)(i - n * C);
+        l[e] = focal_fwd_elem(x[e], targets[n], d, gamma, alpha);
+        acc += l[e];
+      }
+    }
+    if (losses != nullptr) {
+      if (vec) {
+        reinterpret_cast<float4*>(losses)[q] = make_float4(l[0], l[1], l[2], l[3]);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (i0 + e < total) losses[i0 + e] = l[e];
+      }
+    }
+  }
+  if (loss_sum != nullptr) {
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, s);
+  }
+}
+
+__global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ logits,
+                                                        const int* __restrict__ targets,
+                                                        const float* __restrict__ d_losses, float d_scale,
+                                                        int64_t total, int C, float gamma, float alpha,
+                                                        float* __restrict__ d_logits) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t n = i / C;
+    const int d = (int)(i - n * C);
+    const float g = focal_bwd_elem(logits[i], targets[n], d, gamma, alpha);
+    d_logits[i] = g * (d_losses != nullptr ? d_losses[i] : d_scale);
+  }
+}
+
+extern "C" int scan_sigmoid_focal_loss_forward(const float* logits, const int32_t* targets, int64_t M, int32_t C,
+                                               float gamma, float alpha, float* losses, float* loss_sum,
+                                               void* stream) {
+  SCAN_CHECK_ARG(M >= 0 && C > 0, "sigmoid_focal_loss_forward: bad shape M=%lld C=%d", (long long)M, C);
+  SCAN_CHECK_ARG(losses || loss_sum, "sigmoid_focal_loss_forward: no output requested");
+  if (M == 0) return 0;
+  SCAN_CHECK_ARG(logits && targets, "sigmoid_focal_loss_forward: null input");
+  const int64_t total = M * C;
+  hipLaunchKernelGGL(focal_fwd_kernel, dim3(grid_for((total + 3) / 4, 256)), dim3(256), 0, as_stream(stream), logits,
+                     targets, total, C, gamma, alpha, losses, loss_sum);
+  SCAN_LAUNCH_CHECK("focal_fwd");
+  return 0;
+}
+
+extern "C" int scan_sigmoid_focal_loss_backward(const float* logits, const int32_t* targets, const float* d_losses,
+                                                float d_scale, int64_t M, int32_t C, float gamma, float alpha,
+                                                float* d_logits, void* stream) {
+  SCAN_CHECK_ARG(M >= 0 && C > 0, "sigmoid_focal_loss_backward: bad shape M=%lld C=%d", (long long)M, C);
+  if (M == 0) return 0;
+  SCAN_CHECK_ARG(logits && targets && d_logits, "sigmoid_focal_loss_backward: null pointer");
+  const int64_t total = M * C;
+  hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), logits, targets,
+                     d_losses, d_scale, total, C, gamma, alpha, d_logits);
+  SCAN_LAUNCH_CHECK("focal_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------ IoU loss (layers/iou_loss.py:5-36)
+struct IouTerms {
+  float loss, hI, wI, U, I, pw, ph;
+};
+__device__ __forceinline__ IouTerms iou_terms(const float4 p, const float4 t) {
+  IouTerms r;
+  const float ta = (t.x + t.z) * (t.y + t.w);
+  r.pw = p.x + p.z;
+  r.ph = p.y + p.w;
+  const float pa = r.pw * r.ph;
+  r.wI = fminf(p.x, t.x) + fminf(p.z, t.z);
+  r.hI = fminf(p.w, t.w) + fminf(p.y, t.y);
+  r.I = r.wI * r.hI;
+  r.U = ta + pa - r.I;
+  r.loss = -logf((r.I + 1.0f) / (r.U + 1.0f));
+  return r;
+}
+
+__global__ __launch_bounds__(256) void iou_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      const float* __restrict__ weight, int64_t P,
+                                                      float* __restrict__ out2) {
+  __shared__ float red[4];
+  float num = 0.f, den = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 p = reinterpret_cast<const float4*>(pred)[i];
+    const float4 t = reinterpret_cast<const float4*>(target)[i];
+    const float w = weight ? weight[i] : 1.f;
+    num += iou_terms(p, t).loss * w;
+    den += w;
+  }
+  const float sn = block_sum_256(num, red);
+  const float sd = block_sum_256(den, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(out2, sn);
+    atomicAdd(out2 + 1, sd);
+  }
+}
+
+// torch.min(a, b) backward: the gradient goes to the smaller input, split evenly on exact ties
+__device__ __forceinline__ float min_grad(float a, float b) { return a < b ? 1.f : (a == b ? 0.5f : 0.f); }
+
+__global__ __launch_bounds__(256) void iou_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                      const float* __restrict__ weight, int64_t P,
+                                                      const float* __restrict__ g_num, float* __restrict__ d_pred) {
+  const float g = g_num[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 p = reinterpret_cast<const float4*>(pred)[i];
+    const float4 t = reinterpret_cast<const float4*>(target)[i];
+    const IouTerms r = iou_terms(p, t);
+    const float w = (weight ? weight[i] : 1.f) * g;
+    // loss = log(U+1) - log(I+1);  U = ta + pa - I
+    const float dU = 1.f / (r.U + 1.f);
+    const float dI = -dU - 1.f / (r.I + 1.f);  // dU/dI = -1
+    float4 o;
+    o.x = w * (dU * r.ph + dI * r.hI * min_grad(p.x, t.x));  // left
+    o.z = w * (dU * r.ph + dI * r.hI * min_grad(p.z, t.z));  // right
+    o.y = w * (dU * r.pw + dI * r.wI * min_grad(p.y, t.y));  // top
+    o.w = w * (dU * r.pw + dI * r.wI * min_grad(p.w, t.w));  // bottom
+    reinterpret_cast<float4*>(d_pred)[i] = o;
+  }
+}
+
+extern "C" int scan_iou_loss_forward(const float* pred, const float* target, const float* weight, int64_t P,
+                                     float* out2, void* stream) {
+  SCAN_CHECK_ARG(P >= 0 && out2, "iou_loss_forward: bad arguments");
+  if (P == 0) return 0;
+  SCAN_CHECK_ARG(pred && target, "iou_loss_forward: null input");
+  hipLaunchKernelGGL(iou_fwd_kernel, dim3(grid_for(P, 256)), dim3(256), 0, as_stream(stream), pred, target, weight, P,
+                     out2);
+  SCAN_LAUNCH_CHECK("iou_fwd");
+  return 0;
+}
+
+extern "C" int scan_iou_loss_backward(const float* pred, const float* target, const float* weight, int64_t P,
+                                      const float* g_num_dev, float* d_pred, void* stream) {
+  SCAN_CHECK_ARG(P >= 0, "iou_loss_backward: bad arguments");
+  if (P == 0) return 0;
+  SCAN_CHECK_ARG(pred && target && g_num_dev && d_pred, "iou_loss_backward: null pointer");
+  hipLaunchKernelGGL(iou_bwd_kernel, dim3(grid_for(P, 256)), dim3(256), 0, as_stream(stream), pred, target, weight, P,
+                     g_num_dev, d_pred);
+  SCAN_LAUNCH_CHECK("iou_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------ BCE with logits (optionally weighted)
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ logits,
+                                                      const float* __restrict__ targets, float const_target,
+                                                      const float* __restrict__ weight, int64_t w_stride, int64_t M,
+                                                      float* __restrict__ out2) {
+  __shared__ float red[4];
+  float num = 0.f, den = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = logits[i];
+    const float t = targets ? targets[i] : const_target;
+    const float w = weight ? weight[i * w_stride] : 1.f;
+    // max(x,0) - x*t + log(1 + exp(-|x|))
+    const float l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    num += l * w;
+    den += w;
+  }
+  const float sn = block_sum_256(num, red);
+  const float sd = block_sum_256(den, red);
+  if (threadIdx.x == 0) {
+    atomicAdd(out2, sn);
+    atomicAdd(out2 + 1, sd);
+  }
+}
+
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const float* __restrict__ logits,
+                                                      const float* __restrict__ targets, float const_target,
+                                                      const float* __restrict__ weight, int64_t w_stride, int64_t M,
+                                                      const float* __restrict__ g_dev, float* __restrict__ d_logits) {
+  const float g = g_dev[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const float x = logits[i];
+    const float t = targets ? targets[i] : const_target;
+    const float w = weight ? weight[i * w_stride] : 1.f;
+    const float s = 1.f / (1.f + expf(-x));
+    d_logits[i] = g * w * (s - t);
+  }
+}
+
+extern "C" int scan_bce_logits_forward(const float* logits, const float* targets, float const_target,
+                                       const float* weight, int64_t w_stride, int64_t M, float* out2, void* stream) {
+  SCAN_CHECK_ARG(M >= 0 && out2, "bce_logits_forward: bad arguments");
+  if (M == 0) return 0;
+  SCAN_CHECK_ARG(logits, "bce_logits_forward: null input");
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), logits, targets,
+                     const_target, weight, w_stride, M, out2);
+  SCAN_LAUNCH_CHECK("bce_fwd");
+  return 0;
+}
+
+extern "C" int scan_bce_logits_backward(const float* logits, const float* targets, float const_target,
+                                        const float* weight, int64_t w_stride, int64_t M, const float* g_dev,
+                                        float* d_logits, void* stream) {
+  SCAN_CHECK_ARG(M >= 0, "bce_logits_backward: bad arguments");
+  if (M == 0) return 0;
+  SCAN_CHECK_ARG(logits && g_dev && d_logits, "bce_logits_backward: null pointer");
+  hipLaunchKernelGGL(bce_bwd_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), logits, targets,
+                     const_target, weight, w_stride, M, g_dev, d_logits);
+  SCAN_LAUNCH_CHECK("bce_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------ CKA class-conditional BCE
+#define CKA_MAXC 16
+__global__ __launch_bounds__(256) void cka_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ act,
+                                                      int64_t M, int Cf, float t, float* __restrict__ out) {
+  __shared__ float red[4];
+  float num[CKA_MAXC], den[CKA_MAXC];
+#pragma unroll
+  for (int c = 0; c < CKA_MAXC; ++c) num[c] = den[c] = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+#pragma unroll
+    for (int c = 0; c < CKA_MAXC; ++c) {
+      if (c < Cf) {
+        const float x = logits[i * Cf + c];
+        const float w = act[i * (Cf + 1) + c + 1];
+        const float l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+        num[c] += l * w;
+        den[c] += w;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CKA_MAXC; ++c) {
+    if (c < Cf) {
+      const float sn = block_sum_256(num[c], red);
+      const float sd = block_sum_256(den[c], red);
+      if (threadIdx.x == 0) {
+        atomicAdd(out + 2 * c, sn);
+        atomicAdd(out + 2 * c + 1, sd);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void cka_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ act,
+                                                      int64_t M, int Cf, float t, const float* __restrict__ g,
+                                                      float* __restrict__ d_logits) {
+  const int64_t total = M * Cf;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / Cf;
+    const int c = (int)(i - m * Cf);
+    const float x = logits[i];
+    const float s = 1.f / (1.f + expf(-x));
+    d_logits[i] = g[c] * act[m * (Cf + 1) + c + 1] * (s - t);
+  }
+}
+
+extern "C" int scan_cka_bce_forward(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
+                                    float* out, void* stream) {
+  SCAN_CHECK_ARG(M >= 0 && Cf > 0 && Cf <= CKA_MAXC && out, "cka_bce_forward: bad arguments (Cf=%d)", Cf);
+  if (M == 0) return 0;
+  SCAN_CHECK_ARG(logits && act, "cka_bce_forward: null input");
+  hipLaunchKernelGGL(cka_fwd_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), logits, act, M, Cf,
+                     target, out);
+  SCAN_LAUNCH_CHECK("cka_fwd");
+  return 0;
+}
+
+extern "C" int scan_cka_bce_backward(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
+                                     const float* g_dev, float* d_logits, void* stream) {
+  SCAN_CHECK_ARG(M >= 0 && Cf > 0 && Cf <= CKA_MAXC, "cka_bce_backward: bad arguments (Cf=%d)", Cf);
+  if (M == 0) return 0;
+  SCAN_CHECK_ARG(logits && act && g_dev && d_logits, "cka_bce_backward: null pointer");
+  hipLaunchKernelGGL(cka_bwd_kernel, dim3(grid_for(M * Cf, 256)), dim3(256), 0, as_stream(stream), logits, act, M, Cf,
+                     target, g_dev, d_logits);
+  SCAN_LAUNCH_CHECK("cka_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------ y = alpha * x (GRL)
+__global__ __launch_bounds__(256) void scale_kernel(const float* __restrict__ x, float alpha, float* __restrict__ y,
+                                                    int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 v = reinterpret_cast<const float4*>(x)[i];
+    v.x *= alpha; v.y *= alpha; v.z *= alpha; v.w *= alpha;
+    reinterpret_cast<float4*>(y)[i] = v;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) y[(n4 << 2) + threadIdx.x] = alpha * x[(n4 << 2) + threadIdx.x];
+}
+
+extern "C" int scan_scale(const float* x, float alpha, float* y, int64_t n, void* stream) {
+  SCAN_CHECK_ARG(n >= 0, "scale: bad n");
+  if (n == 0) return 0;
+  SCAN_CHECK_ARG(x && y, "scale: null pointer");
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, as_stream(stream), x, alpha, y, n);
+  SCAN_LAUNCH_CHECK("scale");
+  return 0;
+}
+
+// ------------------------------------------------------------------ softmax focal loss (alpha = 1)
+// layers/sigmoid_focal_loss_wbg.py:38-64:  p = softmax(z)[label] clamped at 1e-15; -(1-p)^g log p
+#define SFL_MAXK 16
+__global__ __launch_bounds__(256) void sfl_fwd_kernel(const float* __restrict__ logits,
+                                                      const int64_t* __restrict__ labels, int64_t M, int K,
+                                                      float gamma, float* __restrict__ loss_sum) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* z = logits + i * K;
+    float mx = z[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) den += expf(z[k] - mx);
+    const int lab = (int)labels[i];
+    float p = expf(z[lab] - mx) / den;
+    p = fmaxf(p, 1e-15f);
+    acc += -powf(1.f - p, gamma) * logf(p);
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) atomicAdd(loss_sum, s);
+}
+
+__global__ __launch_bounds__(256) void sfl_bwd_kernel(const float* __restrict__ logits,
+                                                      const int64_t* __restrict__ labels, int64_t M, int K,
+                                                      float gamma, float d_scale, float* __restrict__ d_logits) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
+    const float* z = logits + i * K;
+    float e[SFL_MAXK];
+    float mx = z[0];
+    for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) {
+      e[k] = expf(z[k] - mx);
+      den += e[k];
+    }
+    const int lab = (int)labels[i];
+    const float inv = 1.f / den;
+    const float p = e[lab] * inv;
+    float dLdp = 0.f;  // clamp(min=1e-15) has zero gradient below the clamp
+    if (p >= 1e-15f) dLdp = gamma * powf(1.f - p, gamma - 1.f) * logf(p) - powf(1.f - p, gamma) / p;
+    const float c = dLdp * p * d_scale;
+    for (int k = 0; k < K; ++k) d_logits[i * K + k] = c * ((k == lab ? 1.f : 0.f) - e[k] * inv);
+  }
+}
+
+extern "C" int scan_softmax_focal_forward(const float* logits, const int64_t* labels, int64_t M, int32_t K,
+                                          float gamma, float* loss_sum, void* stream) {
+  SCAN_CHECK_ARG(M >= 0 && K > 0 && K <= SFL_MAXK && loss_sum, "softmax_focal_forward: bad arguments (K=%d)", K);
+  if (M == 0) return 0;
+  SCAN_CHECK_ARG(logits && labels, "softmax_focal_forward: null input");
+  hipLaunchKernelGGL(sfl_fwd_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), logits, labels, M, K,
+                     gamma, loss_sum);
+  SCAN_LAUNCH_CHECK("sfl_fwd");
+  return 0;
+}
+
+extern "C" int scan_softmax_focal_backward(const float* logits, const int64_t* labels, int64_t M, int32_t K,
+                                           float gamma, float d_scale, float* d_logits, void* stream) {
+  SCAN_CHECK_ARG(M >= 0 && K > 0 && K <= SFL_MAXK, "softmax_focal_backward: bad arguments (K=%d)", K);
+  if (M == 0) return 0;
+  SCAN_CHECK_ARG(logits && labels && d_logits, "softmax_focal_backward: null pointer");
+  hipLaunchKernelGGL(sfl_bwd_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), logits, labels, M, K,
+                     gamma, d_scale, d_logits);
+  SCAN_LAUNCH_CHECK("sfl_bwd");
+  return 0;
+}
+
+// ------------------------------------------------------------------ fused SGD + momentum + weight decay
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ buf, int64_t n, float lr, float wd,
+                                                  float momentum, int first) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float w = p[i];
+    const float gg = g[i] + wd * w;
+    const float b = first ? gg : momentum * buf[i] + gg;
+    buf[i] = b;
+    p[i] = w - lr * b;
+  }
+}
+
+extern "C" int scan_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float wd, float momentum,
+                                 int32_t first_step, void* stream) {
+  SCAN_CHECK_ARG(n >= 0, "sgd_momentum: bad n");
+  if (n == 0) return 0;
+  SCAN_CHECK_ARG(p && g && buf, "sgd_momentum: null pointer");
+  hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n, 256)), dim3(256), 0, as_stream(stream), p, g, buf, n, lr, wd,
+                     momentum, first_step);
+  SCAN_LAUNCH_CHECK("sgd");
+  return 0;
+}

@@ -1,0 +1,209 @@
+"""Domain-adaptation training / inference engine for the SCAN hot path on MI355X.
+
+Mirrors the caller contract of the reference: ``foward_detector``
+(fcos_core/engine/trainer.py:20-72) and the three-phase DA iteration of ``do_train``
+(trainer.py:266-424): (1) generator on source (backward retain_graph), (2) CKA discriminators on
+source through the GRL, (3) target pass + CKA discriminators on target, then one SGD step per
+sub-model (solver/build.py:7-43: bias lr x2 / wd 0, momentum 0.9, constant 1/3 warm-up for 1000
+iterations, solver/lr_scheduler.py:39-52).
+
+MI355X-native pieces: every sub-model's parameters, gradients and momentum live in ONE flat fp32
+buffer each (weights first, biases after), so the optimizer is two fused-SGD launches per
+sub-model and data parallelism is one RCCL all-reduce per flat gradient buffer, issued on a side
+HIP stream as soon as that sub-model's last backward contribution is final.
+"""
+import torch
+import torch.distributed as dist
+
+from . import ops, synth
+from .modeling.backbone import build_backbone
+from .modeling.condgraph import build_condgraph
+from .modeling.discriminator import FCOSDiscriminator_con
+from .modeling.fcos import build_fcos
+
+LEVELS = ("P3", "P4", "P5", "P6", "P7")
+DIS_ORDER = ("P7", "P6", "P5", "P4", "P3")  # order the reference builds / iterates them
+
+
+def build_model(num_classes=9, test_mode="precision", device="cuda", attn_dropout=0.1):
+    """dict MODEL{backbone, middle_head, fcos, dis_P*_CON} like tools/train_net_da.py:43-48,223-274."""
+    model = {
+        "backbone": build_backbone(),
+        "middle_head": build_condgraph(None, 256, num_classes),
+        "fcos": build_fcos(None, num_classes, test_mode),
+    }
+    model["middle_head"].multihead_attn.dropout.p = attn_dropout
+    model["middle_head"].multihead_attn.attn_dropout.p = attn_dropout
+    for lvl in DIS_ORDER:
+        model["dis_%s_CON" % lvl] = FCOSDiscriminator_con(num_convs=4, num_classes=num_classes, grad_reverse_lambda=0.02)
+    for m in model.values():
+        m.to(device)
+        for p in m.parameters():
+            if p.dim() == 4:
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+    return model
+
+
+def load_state_dicts(model, sds):
+    for k, m in model.items():
+        missing, unexpected = m.load_state_dict(sds[k], strict=False)
+        if missing or unexpected:
+            raise RuntimeError("state_dict mismatch for %s: missing %s unexpected %s" % (k, missing, unexpected))
+        for p in m.parameters():
+            if p.dim() == 4 and not p.data.is_contiguous(memory_format=torch.channels_last):
+                p.data = p.data.contiguous(memory_format=torch.channels_last)
+
+
+def load_procedural_weights(model, num_classes=9):
+    load_state_dicts(model, synth.all_state_dicts(num_classes))
+
+
+# ----------------------------------------------------------------------------- forward
+def forward_detector(model, images, targets=None, mode="source", forward_target=False):
+    """reference engine/trainer.py:20-72.  images [N,3,H,W] on the GPU; targets list of (boxes, labels).
+    Training: (losses, features{P3..P7: rows}, act_maps{P3..P7: rows}, shape).  Eval: detections."""
+    rows, shape = model["backbone"](images)
+    losses = {}
+    feats, loss_graph, loss_act, maps = model["middle_head"](rows, shape, targets=targets, mode=mode,
+                                                             forward_target=forward_target)
+    if loss_graph is not None:
+        node_loss, consistency_loss = loss_graph
+        if consistency_loss:
+            losses["consistency_loss"] = consistency_loss
+        if node_loss is not None:
+            losses["node_loss"] = node_loss
+    if loss_act is not None:
+        losses["act_loss"] = loss_act
+    sizes = [tuple(images.shape[-2:])] * images.shape[0]
+    proposals, proposal_losses = model["fcos"](sizes, feats, shape, targets=targets, act_maps=maps)
+    if model["fcos"].training:
+        losses.update(proposal_losses)
+        f = {n: feats[shape.row_off[i]:shape.row_off[i + 1]] for i, n in enumerate(LEVELS)}
+        a = {n: maps[shape.row_off[i]:shape.row_off[i + 1]] for i, n in enumerate(LEVELS)}
+        return losses, f, a, shape
+    return proposals
+
+
+# ----------------------------------------------------------------------------- flat parameters
+class FlatGroup:
+    """All trainable parameters of one sub-model in one flat fp32 buffer (weights | biases), with
+    matching flat gradient and momentum buffers.  Parameters and .grad become views into them."""
+
+    def __init__(self, module, lr, bias_lr_factor=2.0, wd=1e-4, wd_bias=0.0, momentum=0.9):
+        params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
+        wts = [(n, p) for n, p in params if "bias" not in n]
+        bss = [(n, p) for n, p in params if "bias" in n]
+        self.n_w = sum(p.numel() for _, p in wts)
+        self.n_b = sum(p.numel() for _, p in bss)
+        dev = params[0][1].device
+        self.flat_p = torch.empty(self.n_w + self.n_b, device=dev)
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        off = 0
+        for _, p in wts + bss:
+            n = p.numel()
+            stride = p.data.stride()
+            view = self.flat_p[off:off + n].as_strided(p.shape, stride)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = self.flat_g[off:off + n].as_strided(p.shape, stride)
+            off += n
+        self.lr, self.bias_lr_factor, self.wd, self.wd_bias, self.momentum = lr, bias_lr_factor, wd, wd_bias, momentum
+        self.first = True
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+
+    def step(self, lr_factor=1.0):
+        lr = self.lr * lr_factor
+        ops.sgd_momentum_(self.flat_p[:self.n_w], self.flat_g[:self.n_w], self.flat_m[:self.n_w], lr, self.wd,
+                          self.momentum, self.first)
+        if self.n_b:
+            ops.sgd_momentum_(self.flat_p[self.n_w:], self.flat_g[self.n_w:], self.flat_m[self.n_w:],
+                              lr * self.bias_lr_factor, self.wd_bias, self.momentum, self.first)
+        self.first = False
+
+
+def warmup_factor(iteration, warmup_iters=1000, factor=1.0 / 3, steps=(60000, 80000), gamma=0.1):
+    """WarmupMultiStepLR.get_lr, 'constant' warm-up (reference solver/lr_scheduler.py:39-52)."""
+    f = factor if iteration < warmup_iters else 1.0
+    return f * gamma ** sum(1 for s in steps if s <= iteration)
+
+
+class Trainer:
+    """One process per GPU.  world_size > 1: per-rank shard of the batch, local graph / normalisers,
+    gradients averaged by one all-reduce per sub-model flat buffer."""
+
+    def __init__(self, model, base_lr=0.0025, con_dis_lambda=0.1, distributed=None):
+        self.model = model
+        self.con_dis_lambda = con_dis_lambda
+        self.groups = {k: FlatGroup(m, base_lr) for k, m in model.items()}
+        self.iteration = 0
+        self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
+        self.comm_stream = torch.cuda.Stream() if self.distributed else None
+        self._pending = []
+
+    def _allreduce_async(self, keys):
+        """all-reduce the flat gradient buffers of sub-models whose gradients are final, on the side stream."""
+        if not self.distributed:
+            return
+        self.comm_stream.wait_stream(torch.cuda.current_stream())
+        ws = dist.get_world_size()
+        with torch.cuda.stream(self.comm_stream):
+            for k in keys:
+                g = self.groups[k].flat_g
+                g.div_(ws)
+                self._pending.append(dist.all_reduce(g, async_op=True))
+
+    def step(self, images_s, targets_s, images_t, forward_target=False):
+        """One DA iteration; returns the loss dict (0-dim GPU tensors, reference key names)."""
+        model, lam = self.model, self.con_dis_lambda
+        for m in model.values():
+            m.train()
+        for g in self.groups.values():
+            g.zero_grad()
+        out = {}
+        # (1) generator on source
+        loss_dict, feat_s, maps_s, shape = forward_detector(model, images_s, targets_s, mode="source")
+        loss_dict = {k + "_gs": v for k, v in loss_dict.items()}
+        sum(loss_dict.values()).backward(retain_graph=True)
+        out.update(loss_dict)
+        # (2) discriminators on source (GRL pushes -lambda*grad into backbone / middle head)
+        ld = {}
+        for lvl in DIS_ORDER:
+            i = LEVELS.index(lvl)
+            ld["loss_adv_%s_CON_ds" % lvl] = lam * model["dis_%s_CON" % lvl](
+                feat_s[lvl], 1.0, maps_s[lvl], domain="source", shape=shape.level(i))
+        sum(ld.values()).backward()
+        out.update(ld)
+        del loss_dict, feat_s, maps_s
+        self._allreduce_async(["fcos"])  # the target pass adds nothing to the FCOS head
+        # (3) target pass + discriminators on target
+        loss_dict, feat_t, maps_t, shape = forward_detector(model, images_t, None, mode="target",
+                                                            forward_target=forward_target)
+        ld = {k + "_gt": v for k, v in loss_dict.items()}
+        for lvl in DIS_ORDER:
+            i = LEVELS.index(lvl)
+            ld["loss_adv_%s_CON_dt" % lvl] = lam * model["dis_%s_CON" % lvl](
+                feat_t[lvl], 0.0, maps_t[lvl], domain="target", shape=shape.level(i))
+        sum(v for k, v in ld.items() if k != "zero_gt").backward()
+        out.update(ld)
+        self._allreduce_async([k for k in self.groups if k != "fcos"])
+        if self.distributed:
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        f = warmup_factor(self.iteration)
+        for g in self.groups.values():
+            g.step(f)
+        self.iteration += 1
+        return out
+
+
+@torch.no_grad()
+def inference(model, images):
+    """reference engine/inference.py:15-37 on one batch: list of (boxes, scores, labels) per image."""
+    for m in model.values():
+        m.eval()
+    return forward_detector(model, images, None)

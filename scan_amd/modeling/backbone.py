@@ -1,0 +1,126 @@
+"""VGG16 + FPN (P3..P7) backbone on pyramid activations, every conv on the fp32-MFMA
+HIP kernel.  Mirrors the reference's "VGG-16-FPN-RETINANET" builder
+(fcos_core/modeling/backbone/backbone.py:21-44): mmcv VGG16 body
+(backbone/mmdetection/vgg.py:36-169, stages 1-2 frozen), FPN on C3..C5
+(backbone/fpn.py:44-91, plain convs: FPN.USE_GN/USE_RELU False) and
+LastLevelP6P7 fed by P5 (fpn.py:105-130, RETINANET.USE_C5 False).
+``state_dict`` keys equal the reference's (body.features.N.*, fpn.fpn_inner3.*, ...).
+"""
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from ..ops import PyramidShape
+
+VGG_STAGES = ((0, 2), (5, 7), (10, 12, 14), (17, 19, 21), (24, 26, 28))
+VGG_PLANES = (64, 128, 256, 512, 512)
+
+
+def conv_holder(cin, cout, k, stride=1):
+    """nn.Conv2d used as a parameter container (reference names/shapes), stored channels_last so the
+    HIP kernels read it as [Cout][k*k][Cin] without a repack."""
+    m = nn.Conv2d(cin, cout, k, stride, k // 2)
+    m.weight.data = m.weight.data.contiguous(memory_format=torch.channels_last)
+    return m
+
+
+def maxpool2x2(rows, shape):
+    """2x2/2 max-pool of a single-level pyramid (torch glue on the NHWC view)."""
+    (h, w), n = shape.sizes[0], shape.n_images
+    c = rows.shape[1]
+    x = rows.view(n, h // 2, 2, w // 2, 2, c)
+    y = x.amax(dim=(2, 4))
+    return y.reshape(n * (h // 2) * (w // 2), c), PyramidShape(n, [(h // 2, w // 2)])
+
+
+def upsample2x(rows, shape):
+    """nearest 2x upsample of a single-level pyramid (F.interpolate(scale_factor=2, 'nearest'))."""
+    (h, w), n = shape.sizes[0], shape.n_images
+    c = rows.shape[1]
+    y = rows.view(n, h, 1, w, 1, c).expand(n, h, 2, w, 2, c).reshape(n * 4 * h * w, c)
+    return y
+
+
+class VGGBody(nn.Module):
+    def __init__(self, frozen_stages=2):
+        super().__init__()
+        layers = []
+        cin = 3
+        for stage, planes in zip(VGG_STAGES, VGG_PLANES):
+            for _ in stage:
+                layers += [conv_holder(cin, planes, 3), nn.ReLU(inplace=True)]
+                cin = planes
+            layers.append(nn.MaxPool2d(2, 2))
+        self.features = nn.Sequential(*layers)
+        # reference vgg.py:128-138: stages < frozen_stages have requires_grad False
+        for s in range(frozen_stages):
+            for idx in VGG_STAGES[s]:
+                for p in self.features[idx].parameters():
+                    p.requires_grad = False
+
+    def forward(self, rows, shape):
+        outs = []
+        for stage in VGG_STAGES:
+            for idx in stage:
+                m = self.features[idx]
+                rows = ops.conv2d(rows, m.weight, m.bias, shape, 3, 1, relu=True)
+            rows, shape = maxpool2x2(rows, shape)
+            outs.append((rows, shape))
+        return outs
+
+
+class LastLevelP6P7(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.p6 = conv_holder(cin, cout, 3, 2)
+        self.p7 = conv_holder(cout, cout, 3, 2)
+
+
+class FPN(nn.Module):
+    def __init__(self):
+        super().__init__()
+        for lvl, cin in ((3, 256), (4, 512), (5, 512)):
+            setattr(self, "fpn_inner%d" % lvl, conv_holder(cin, 256, 1))
+            setattr(self, "fpn_layer%d" % lvl, conv_holder(256, 256, 3))
+        self.top_blocks = LastLevelP6P7(256, 256)
+
+    def forward(self, c3, c4, c5):
+        def conv(m, rs, k, stride=1):
+            return ops.conv2d(rs[0], m.weight, m.bias, rs[1], k, stride), rs[1].conv_out(k, stride)
+
+        inner5 = conv(self.fpn_inner5, c5, 1)
+        p5 = conv(self.fpn_layer5, inner5, 3)
+        lat4 = conv(self.fpn_inner4, c4, 1)
+        inner4 = (lat4[0] + upsample2x(*inner5), lat4[1])
+        p4 = conv(self.fpn_layer4, inner4, 3)
+        lat3 = conv(self.fpn_inner3, c3, 1)
+        inner3 = (lat3[0] + upsample2x(*inner4), lat3[1])
+        p3 = conv(self.fpn_layer3, inner3, 3)
+        p6 = conv(self.top_blocks.p6, p5, 3, 2)
+        p7 = conv(self.top_blocks.p7, (F.relu(p6[0]), p6[1]), 3, 2)
+        levels = [p3, p4, p5, p6, p7]
+        rows = torch.cat([l[0] for l in levels], 0)
+        shape = PyramidShape(p3[1].n_images, [l[1].sizes[0] for l in levels])
+        return rows, shape
+
+
+class VGG16FPN(nn.Module):
+    """model["backbone"]: images [N,3,H,W] (H, W multiples of 128) -> (rows [M,256], PyramidShape of P3..P7)."""
+    out_channels = 256
+
+    def __init__(self):
+        super().__init__()
+        self.body = VGGBody()
+        self.fpn = FPN()
+
+    def forward(self, images):
+        if not images.is_cuda:
+            raise RuntimeError("scan_amd backbone runs only on the GPU (HIP); no CPU fallback")
+        rows, shape = ops.nchw_to_rows(images, 4)
+        outs = self.body(rows, shape)
+        return self.fpn(outs[2], outs[3], outs[4])
+
+
+def build_backbone(cfg=None):
+    return VGG16FPN()

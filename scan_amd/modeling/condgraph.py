@@ -1,0 +1,225 @@
+"""SCAN "middle head" (GRAPHModule) on pyramid activations.
+
+Mirrors the reference's fcos_core/modeling/rpn/fcos/condgraph.py (GRAPHHead :68-119,
+GRAPHModule :122-655) and the source node sampling of rpn/fcos/loss.py:428-463 for the
+configuration SCAN ships (C2F yaml: RNN paradigm, PROTO_ITER 3, COSINE_UPDATE_ON, PROTO_WITH_BG,
+GLOBAL_GCN, softmaxFL act loss, CAT_ACT_MAP).  Parameter/buffer names equal the reference's
+(prototype, head_in.middle_tower.N, head_out.middle_tower.0, proto_cls_hidden, proto_cls,
+multihead_attn.*, cond_nx1, cond_rnn.*, cond_2).
+
+Device split (north star): the conv towers, the semantic-conditioned dynamic convolution +
+softmax and the activation-map focal loss are HIP kernels; graph-node aggregation (attention over
+a few hundred nodes), the paradigm EMA and the RNN kernel generator are small torch-tier ops.
+"""
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from ..layers import FocalLoss, MultiHeadAttention
+from .backbone import conv_holder
+from .fcos import assign_targets, compute_locations, make_tower, run_tower
+
+
+class PROTOTYPECounter:
+    """reference condgraph.py:46-65."""
+
+    def __init__(self, cycle=3, stop=False):
+        self.cycle = cycle
+        self.counter = -1
+        self.stop = stop
+
+    def __call__(self):
+        if self.stop:
+            if self.counter == self.cycle:
+                return self.cycle
+            self.counter += 1
+            return self.counter
+        self.counter += 1
+        if self.counter == self.cycle:
+            self.counter = 0
+        return self.counter
+
+
+class GRAPHHead(nn.Module):
+    """reference condgraph.py:68-119: n x [conv3x3, (GN32), ReLU]; GN only for mode 'in'."""
+
+    def __init__(self, in_channels, out_channel, num_convs, mode="in"):
+        super().__init__()
+        self.mode = mode
+        self.num_convs = num_convs
+        self.in_channels = in_channels
+        if mode == "in":
+            self.middle_tower = make_tower(num_convs, in_channels)
+        else:
+            layers = []
+            for _ in range(num_convs):
+                layers += [conv_holder(in_channels, out_channel, 3), nn.ReLU()]
+            self.middle_tower = nn.Sequential(*layers)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, std=0.01)
+                nn.init.constant_(m.bias, 0)
+
+    def forward(self, rows, shape):
+        if self.mode == "in":
+            return run_tower(self.middle_tower, rows, shape, self.num_convs)
+        for i in range(self.num_convs):
+            conv = self.middle_tower[2 * i]
+            rows = ops.conv2d(rows, conv.weight, conv.bias, shape, 3, 1, relu=True)
+        return rows
+
+
+class _RNNParams(nn.Module):
+    """Parameter holder with nn.RNN(256, 512, 2, 'tanh') names (cond_rnn.weight_ih_l0, ...)."""
+
+    def __init__(self, cin=256, hidden=512, layers=2):
+        super().__init__()
+        bound = hidden ** -0.5
+        for l in range(layers):
+            for name, shp in (("weight_ih", (hidden, cin if l == 0 else hidden)), ("weight_hh", (hidden, hidden)),
+                              ("bias_ih", (hidden,)), ("bias_hh", (hidden,))):
+                setattr(self, "%s_l%d" % (name, l), nn.Parameter(torch.empty(shp).uniform_(-bound, bound)))
+        self.layers = layers
+        self.hidden = hidden
+
+    def forward(self, x):  # x [T, B, cin], seq-first, h0 = 0
+        for l in range(self.layers):
+            wih, whh = getattr(self, "weight_ih_l%d" % l), getattr(self, "weight_hh_l%d" % l)
+            bih, bhh = getattr(self, "bias_ih_l%d" % l), getattr(self, "bias_hh_l%d" % l)
+            h = x.new_zeros(x.shape[1], self.hidden)
+            outs = []
+            for t in range(x.shape[0]):
+                h = torch.tanh(F.linear(x[t], wih, bih) + F.linear(h, whh, bhh))
+                outs.append(h)
+            x = torch.stack(outs, 0)
+        return x
+
+
+def sample_source_nodes(feats, labels, shape):
+    """PrototypeComputation.__call__ source branch (reference loss.py:428-463): per level, positives in
+    row order; negatives = floor(linspace(0, n_neg-2, n_pos)) of the background rows (all of them when
+    n_pos > n_neg); final order [all neg, all pos]."""
+    pos_pts, pos_lab, neg_pts = [], [], []
+    for l in range(shape.n_levels):
+        r0, r1 = shape.row_off[l], shape.row_off[l + 1]
+        lab = labels[r0:r1]
+        f = feats[r0:r1]
+        pi = torch.nonzero(lab > 0).squeeze(1)
+        ni = torch.nonzero(lab == 0).squeeze(1)
+        pos_pts.append(f[pi])
+        pos_lab.append(lab[pi])
+        n_pos, n_neg = pi.numel(), ni.numel()
+        if n_pos > n_neg:
+            neg_pts.append(f[ni])
+        else:
+            idx = np.floor(np.linspace(0, n_neg - 2, n_pos)).astype(np.int64)
+            neg_pts.append(f[ni[torch.from_numpy(idx).to(ni.device)]])
+    pos_pts = torch.cat(pos_pts, 0)
+    pos_lab = torch.cat(pos_lab, 0)
+    neg_pts = torch.cat(neg_pts, 0)
+    return torch.cat([neg_pts, pos_pts], 0), torch.cat([pos_lab.new_zeros(neg_pts.shape[0]), pos_lab])
+
+
+class GRAPHModule(nn.Module):
+    """model["middle_head"]."""
+
+    def __init__(self, in_channels=256, num_classes=9, proto_iter=3, attn_dropout=0.1):
+        super().__init__()
+        self.num_classes_fg = num_classes - 1
+        self.used_num_classes = num_classes  # PROTO_WITH_BG
+        self.prototype_iter = proto_iter
+        K = self.used_num_classes
+        self.lamda1 = self.lamda2 = 1.0
+        self.head_in = GRAPHHead(in_channels, in_channels, 2, mode="in")
+        self.register_buffer("prototype", torch.randn(K, 256, proto_iter))
+        self.head_out = GRAPHHead(in_channels + K, in_channels, 1, mode="out")
+        self.cat_stride = ops.pad4(in_channels + K)
+        self.act_loss_func = FocalLoss(K)
+        self.proto_cls_hidden = nn.Linear(256, 512)
+        self.proto_cls = nn.Linear(512, K)
+        self.multihead_attn = MultiHeadAttention(256, 4, dropout=attn_dropout)
+        self.cond_nx1 = nn.Conv2d(512, 256, kernel_size=(proto_iter, 1))
+        self.cond_rnn = _RNNParams(256, 512, 2)
+        self.counter_rnn = PROTOTYPECounter(proto_iter, stop=True)
+        self.cond_2 = nn.Linear(512, 256)  # present in the reference state_dict, unused in RNN mode
+        for m in (self.cond_2, self.proto_cls, self.proto_cls_hidden):
+            nn.init.normal_(m.weight, std=0.01)
+            nn.init.constant_(m.bias, 0)
+
+    # ---- graph tier (torch ops on a few hundred nodes) ----
+    def _forward_gcns(self, pts, labs):
+        """reference condgraph.py:386-402 (GLOBAL_GCN)."""
+        K = self.used_num_classes
+        nodes = self.multihead_attn(pts.unsqueeze(0), pts.unsqueeze(0), pts.unsqueeze(0))[0].squeeze(0)
+        onehot = F.one_hot(labs.long(), K).to(nodes.dtype)  # [n, K]
+        cnt = onehot.sum(0)
+        means = (onehot.t() @ nodes) / cnt.clamp(min=1)[:, None]
+        proto_batch = torch.where((cnt > 0)[:, None], means, torch.zeros_like(means))
+        logits = self.proto_cls(F.relu(self.proto_cls_hidden(nodes)))
+        node_loss = self.lamda1 * F.cross_entropy(logits, labs.long())
+        return node_loss, proto_batch
+
+    @torch.no_grad()
+    def update_prototype_nx1_rnn(self, proto_batch):
+        """reference condgraph.py:586-606 with COSINE_UPDATE_ON."""
+        it = self.counter_rnn()
+        pb = proto_batch.detach()
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            # data parallel: average the per-rank class means over the ranks that saw
+            # the class, so the paradigm buffer stays identical on every rank (9 x 257 floats)
+            ex = pb.sum(-1).bool().to(pb.dtype)[:, None]
+            buf = torch.cat([pb * ex, ex], 1)
+            dist.all_reduce(buf)
+            pb = buf[:, :-1] / buf[:, -1:].clamp(min=1)
+        exist = pb.sum(-1).bool()
+        P = self.prototype
+        if it == self.prototype_iter:
+            m = F.cosine_similarity(P[exist, :, it - 1], pb[exist]).unsqueeze(1)
+            for i in range(it - 1):
+                P[:, :, i] = P[:, :, i + 1]
+            P[exist, :, it - 1] = P[exist, :, it - 1] * m + pb[exist] * (1 - m)
+        else:
+            m = F.cosine_similarity(P[exist, :, it], pb[exist]).unsqueeze(1)
+            P[exist, :, it] = P[exist, :, it] * m + pb[exist] * (1 - m)
+
+    def get_conded_weight(self):
+        """reference condgraph.py:313-319: paradigm [K,256,T] -> RNN -> Conv2d(512,256,(T,1)) -> [K,256]."""
+        seq = self.cond_rnn(self.prototype.permute(2, 0, 1))  # [T, K, 512]
+        # Conv2d(512, 256, (T,1)) over a [K,512,T,1] input is one linear map over (c, t)
+        x = seq.permute(1, 2, 0).reshape(seq.shape[1], -1)  # [K, 512*T], (c, t) order
+        w = self.cond_nx1.weight.reshape(self.cond_nx1.weight.shape[0], -1)  # [256, 512*T]
+        return F.linear(x, w, self.cond_nx1.bias)
+
+    # ---- HIP tier ----
+    def _act_and_out(self, feats, shape, kernels):
+        logits, maps = ops.dynconv_softmax(feats, kernels)
+        pad = self.cat_stride - feats.shape[1] - maps.shape[1]
+        cat = torch.cat([feats, maps, feats.new_zeros(feats.shape[0], pad)], 1)
+        return logits, maps, self.head_out(cat, shape)
+
+    def forward(self, rows, shape, targets=None, mode="source", forward_target=False):
+        """-> feats [M,256], (node_loss, transfer_loss) or None, act_loss or None, act_maps [M,K]."""
+        feats = self.head_in(rows, shape)
+        if self.training and targets and mode == "source":
+            locs = compute_locations(shape, rows.device)
+            labels, _ = assign_targets(locs, targets)
+            pts, labs = sample_source_nodes(feats, labels, shape)
+            node_loss, proto_batch = self._forward_gcns(pts, labs)
+            self.update_prototype_nx1_rnn(proto_batch)
+            kernels = self.get_conded_weight()
+            logits, maps, out = self._act_and_out(feats, shape, kernels)
+            act_loss = self.lamda2 * self.act_loss_func(logits, labels.long())
+            return out, (node_loss, 0), act_loss, maps
+        if self.training and mode == "target" and forward_target:
+            raise NotImplementedError("target-domain node sampling (DBSCAN + GST losses, reference "
+                                      "loss.py:397-518, condgraph.py:457-534) is a later SURVEY 8 row")
+        kernels = self.get_conded_weight()
+        _, maps, out = self._act_and_out(feats, shape, kernels)
+        return out, None, None, maps
+
+
+def build_condgraph(cfg=None, in_channels=256, num_classes=9):
+    return GRAPHModule(in_channels, num_classes)

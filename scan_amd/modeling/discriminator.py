@@ -1,0 +1,72 @@
+"""Conditional Kernel-guided Alignment (CKA) discriminator on one pyramid level.
+
+Mirrors the reference's FCOSDiscriminator_con (fcos_core/modeling/discriminator/
+fcos_head_discriminator_con.py:12-126) for the shipped setting (fusion 'concat', GRL on both
+inputs, use_bg False, num_classes > 1) with the reference's parameter names
+(dis_tower.N, classifier_cls_C.{0,2}).
+
+MI355X restructuring (same arithmetic, fewer and fatter launches): the reference runs, per
+foreground class c, cat(x, act[c+1]) -> conv3x3 257->128 -> ReLU -> conv3x3 128->1.  All
+classes read the same x, so the 8 first convs are ONE implicit GEMM with 8*128 output channels
+over cat(x, act[1:]) (the per-class act channel enters through a block-diagonal weight
+slice), and the 8 second convs are ONE skinny conv 1024 -> 8 with a block-diagonal weight.
+The class-weighted BCE of all classes is one wavefront-reduction kernel.
+"""
+import torch
+from torch import nn
+
+from .. import ops
+from ..layers import GradientReversal
+from .backbone import conv_holder
+from .fcos import make_tower, run_tower
+
+
+class FCOSDiscriminator_con(nn.Module):
+    def __init__(self, with_GA=False, fusion_cfg="concat", num_convs=4, in_channels=256, num_classes=9,
+                 grad_reverse_lambda=0.02, grl_applied_domain="both", patch_stride=None, cfg=None):
+        super().__init__()
+        assert fusion_cfg == "concat" and grl_applied_domain == "both" and patch_stride is None and num_classes > 2, \
+            "only the configuration the SCAN C2F yaml uses is built"
+        self.num_convs = num_convs
+        self.in_channels = in_channels
+        self.num_classes = num_classes - 1  # use_bg False
+        self.dis_tower = make_tower(num_convs, in_channels)
+        for c in range(self.num_classes):
+            self.add_module("classifier_cls_%d" % c, nn.Sequential(
+                conv_holder(in_channels + 1, 128, 3), nn.ReLU(), conv_holder(128, 1, 3)))
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, std=0.01)
+                nn.init.constant_(m.bias, 0)
+        self.grad_reverse = GradientReversal(grad_reverse_lambda)
+
+    def _stacked_weights(self):
+        Cf, C = self.num_classes, self.in_channels
+        blocks = [getattr(self, "classifier_cls_%d" % c) for c in range(Cf)]
+        w0 = torch.stack([b[0].weight for b in blocks], 0)  # [Cf,128,C+1,3,3]
+        main = w0[:, :, :C].reshape(Cf * 128, C, 3, 3)
+        extra = w0[:, :, C]  # [Cf,128,3,3]: the act-map input channel of each class
+        eye = torch.eye(Cf, device=w0.device, dtype=w0.dtype)
+        blk = (extra[:, :, None] * eye[:, None, :, None, None]).reshape(Cf * 128, Cf, 3, 3)
+        w1 = torch.cat([main, blk], 1)  # [Cf*128, C+Cf, 3, 3]
+        b1 = torch.cat([b[0].bias for b in blocks], 0)
+        w2s = torch.stack([b[2].weight[0] for b in blocks], 0)  # [Cf,128,3,3]
+        w2 = (w2s[:, None] * eye[:, :, None, None, None]).reshape(Cf, Cf * 128, 3, 3)
+        b2 = torch.cat([b[2].bias for b in blocks], 0)
+        return w1, b1, w2, b2
+
+    def forward(self, feature, target, act_maps=None, domain="source", shape=None):
+        """feature [M_l,256], act_maps [M_l,K] rows of ONE level; shape = that level's PyramidShape."""
+        assert target in (0, 1, 0.1, 0.9) and domain in ("source", "target")
+        Cf = self.num_classes
+        feature = self.grad_reverse(feature)
+        act_maps = self.grad_reverse(act_maps)
+        x = run_tower(self.dis_tower, feature, shape, self.num_convs)
+        w1, b1, w2, b2 = self._stacked_weights()
+        xcat = torch.cat([x, act_maps[:, 1:]], 1)  # [M, 256 + Cf]; 264 is a multiple of 4
+        pad = ops.pad4(xcat.shape[1]) - xcat.shape[1]
+        if pad:
+            xcat = torch.nn.functional.pad(xcat, (0, pad))
+        h = ops.conv2d(xcat, w1, b1, shape, 3, 1, relu=True)
+        logits = ops.conv2d(h, w2, b2, shape, 3, 1)[:, :Cf]
+        return ops.cka_bce(logits, act_maps.detach(), float(target), Cf)

@@ -1,0 +1,258 @@
+"""FCOS head, loss and post-processor on pyramid activations.
+
+Mirrors the reference's fcos_core/modeling/rpn/fcos/{fcos.py, loss.py, inference.py}:
+same module/parameter names (head.cls_tower.N, head.bbox_tower.N, head.cls_logits,
+head.bbox_pred, head.centerness, head.scales.L.scale), same loss composition.
+Because a pyramid's rows are already in the reference's flatten order (level-major,
+image, y, x; rpn/fcos/loss.py:191-202) the losses consume the conv outputs with no
+permute/reshape/cat copies.
+"""
+import math
+
+import torch
+from torch import nn
+
+from .. import ops
+from ..layers import IOULoss, Scale, SigmoidFocalLoss
+from ..layers import nms as _box_nms
+from .backbone import conv_holder
+
+INF = 100000000  # reference rpn/fcos/loss.py:22
+SIZES_OF_INTEREST = ((-1, 64), (64, 128), (128, 256), (256, 512), (512, INF))  # loss.py:41-47
+FPN_STRIDES = (8, 16, 32, 64, 128)
+
+
+def make_tower(n, c=256):
+    layers = []
+    for _ in range(n):
+        layers += [conv_holder(c, c, 3), nn.GroupNorm(32, c), nn.ReLU()]
+    return nn.Sequential(*layers)
+
+
+def run_tower(tower, rows, shape, n):
+    """n x [conv3x3 (MFMA), GroupNorm(32)+ReLU (fused HIP)] sharing weights across the levels:
+    one launch per layer covers the whole pyramid."""
+    for i in range(n):
+        conv, gn = tower[3 * i], tower[3 * i + 1]
+        rows = ops.conv2d(rows, conv.weight, conv.bias, shape, 3, 1)
+        rows = ops.groupnorm_relu(rows, gn.weight, gn.bias, shape, relu=True, eps=gn.eps)
+    return rows
+
+
+def compute_locations(shape, device, strides=FPN_STRIDES):
+    """reference fcos.py:234-258 / condgraph.py:631-655: x-fastest grid + stride // 2, one per level."""
+    locs = []
+    for (h, w), s in zip(shape.sizes, strides):
+        xs = torch.arange(0, w * s, step=s, dtype=torch.float32, device=device)
+        ys = torch.arange(0, h * s, step=s, dtype=torch.float32, device=device)
+        yy, xx = torch.meshgrid(ys, xs, indexing="ij")
+        locs.append(torch.stack((xx.reshape(-1), yy.reshape(-1)), dim=1) + s // 2)
+    return locs
+
+
+def assign_targets(locations, targets):
+    """FCOS location -> GT assignment (reference loss.py:40-126; PrototypeComputation has an identical
+    copy at :262-343).  targets: list of (boxes [G,4] xyxy, labels [G] int64) per image.
+    Returns labels [M] int64 and reg targets [M,4] in pyramid row order (level-major, image, y, x)."""
+    npl = [len(l) for l in locations]
+    dev = locations[0].device
+    soi = torch.cat([torch.tensor(SIZES_OF_INTEREST[l], dtype=torch.float32, device=dev)[None].expand(n, -1)
+                     for l, n in enumerate(npl)], 0)
+    pts = torch.cat(locations, 0)
+    xs, ys = pts[:, 0], pts[:, 1]
+    labels, regs = [], []
+    for boxes, lab in targets:
+        boxes = boxes.to(dev).float()
+        lab = lab.to(dev)
+        area = (boxes[:, 2] - boxes[:, 0] + 1) * (boxes[:, 3] - boxes[:, 1] + 1)  # BoxList.area(): +1 widths
+        l = xs[:, None] - boxes[:, 0][None]
+        t = ys[:, None] - boxes[:, 1][None]
+        r = boxes[:, 2][None] - xs[:, None]
+        b = boxes[:, 3][None] - ys[:, None]
+        reg = torch.stack([l, t, r, b], dim=2)
+        inside = reg.min(dim=2)[0] > 0
+        mx = reg.max(dim=2)[0]
+        cared = (mx >= soi[:, [0]]) & (mx <= soi[:, [1]])
+        a = area[None].repeat(len(pts), 1)
+        a[~inside] = INF
+        a[~cared] = INF
+        amin, gi = a.min(dim=1)
+        reg = reg[torch.arange(len(pts), device=dev), gi]
+        lb = lab[gi].clone()
+        lb[amin == INF] = 0
+        labels.append(torch.split(lb, npl, 0))
+        regs.append(torch.split(reg, npl, 0))
+    nl = len(locations)
+    lab_rows = torch.cat([torch.cat([li[l] for li in labels], 0) for l in range(nl)], 0)
+    reg_rows = torch.cat([torch.cat([ri[l] for ri in regs], 0) for l in range(nl)], 0)
+    return lab_rows, reg_rows
+
+
+def centerness_targets(reg):
+    """reference loss.py:128-133."""
+    lr = reg[:, [0, 2]]
+    tb = reg[:, [1, 3]]
+    return torch.sqrt((lr.min(-1)[0] / lr.max(-1)[0]) * (tb.min(-1)[0] / tb.max(-1)[0]))
+
+
+class FCOSHead(nn.Module):
+    """reference fcos.py:13-114 with REG_CTR_ON True."""
+
+    def __init__(self, num_classes=9, num_convs=4, prior_prob=0.01):
+        super().__init__()
+        self.num_fg = num_classes - 1
+        self.num_convs = num_convs
+        self.cls_tower = make_tower(num_convs)
+        self.bbox_tower = make_tower(num_convs)
+        self.cls_logits = conv_holder(256, self.num_fg, 3)
+        self.bbox_pred = conv_holder(256, 4, 3)
+        self.centerness = conv_holder(256, 1, 3)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.normal_(m.weight, std=0.01)
+                nn.init.constant_(m.bias, 0)
+        nn.init.constant_(self.cls_logits.bias, -math.log((1 - prior_prob) / prior_prob))
+        self.scales = nn.ModuleList([Scale(init_value=1.0) for _ in range(5)])
+
+    def forward(self, rows, shape, need_cls=True):
+        """-> logits [M,C] (or None), bbox_reg [M,4] = exp(scale_l * bbox_pred), centerness [M]."""
+        logits = None
+        if need_cls:
+            ct = run_tower(self.cls_tower, rows, shape, self.num_convs)
+            logits = ops.conv2d(ct, self.cls_logits.weight, self.cls_logits.bias, shape, 3, 1)[:, :self.num_fg]
+        rt = run_tower(self.bbox_tower, rows, shape, self.num_convs)
+        # bbox_pred (4) and centerness (1) read the same tower: one skinny conv with 5 outputs
+        w = torch.cat([self.bbox_pred.weight, self.centerness.weight], 0)
+        b = torch.cat([self.bbox_pred.bias, self.centerness.bias], 0)
+        out = ops.conv2d(rt, w, b, shape, 3, 1, cout_s=8)
+        scale_rows = torch.cat([self.scales[l].scale.expand(shape.row_off[l + 1] - shape.row_off[l])
+                                for l in range(shape.n_levels)], 0)
+        bbox_reg = torch.exp(out[:, :4] * scale_rows[:, None])
+        return logits, bbox_reg, out[:, 4]
+
+
+class FCOSLossComputation:
+    """reference loss.py:25-230."""
+
+    def __init__(self, gamma=2.0, alpha=0.25):
+        self.cls_loss_func = SigmoidFocalLoss(gamma, alpha)
+        self.box_reg_loss_func = IOULoss()
+
+    def __call__(self, shape, box_cls, box_regression, centerness, targets):
+        N = shape.n_images
+        locs = compute_locations(shape, box_cls.device)
+        labels, reg_targets = assign_targets(locs, targets)
+        pos_inds = torch.nonzero(labels > 0).squeeze(1)
+        cls_loss = self.cls_loss_func(box_cls.contiguous(), labels.int()) / (pos_inds.numel() + N)
+        box_regression = box_regression[pos_inds]
+        reg_targets = reg_targets[pos_inds]
+        centerness = centerness[pos_inds]
+        if pos_inds.numel() > 0:
+            ctr_t = centerness_targets(reg_targets)
+            reg_loss = self.box_reg_loss_func(box_regression, reg_targets, ctr_t)
+            ctr_loss = ops.bce_with_logits_mean(centerness, ctr_t)
+        else:
+            reg_loss = box_regression.sum()
+            ctr_loss = centerness.sum()
+        return cls_loss, reg_loss, ctr_loss
+
+
+class FCOSPostProcessor:
+    """reference inference.py:20-194; per-class NMS runs on the device (scan_nms)."""
+
+    def __init__(self, pre_nms_thresh=0.05, pre_nms_top_n=1000, nms_thresh=0.6, fpn_post_nms_top_n=100, min_size=0,
+                 num_classes=9, mode="common"):
+        self.pre_nms_thresh = pre_nms_thresh
+        self.pre_nms_top_n = pre_nms_top_n
+        self.nms_thresh = nms_thresh
+        self.fpn_post_nms_top_n = fpn_post_nms_top_n
+        self.min_size = min_size
+        self.num_classes = num_classes
+        self.mode = mode
+
+    def __call__(self, shape, box_cls, box_regression, centerness, image_sizes):
+        """box_cls [M,C] (logits for 'common', fused probabilities otherwise), box_regression [M,4],
+        centerness [M] logits.  Returns per image (boxes [k,4], scores [k], labels [k])."""
+        N = shape.n_images
+        locs = compute_locations(shape, box_cls.device)
+        C = box_cls.shape[1]
+        per_img = [[] for _ in range(N)]
+        for l in range(shape.n_levels):
+            r0, r1 = shape.row_off[l], shape.row_off[l + 1]
+            cls = box_cls[r0:r1].reshape(N, -1, C)
+            if self.mode == "common":
+                cls = cls.sigmoid()
+            reg = box_regression[r0:r1].reshape(N, -1, 4)
+            ctr = centerness[r0:r1].reshape(N, -1).sigmoid()
+            cand = cls > self.pre_nms_thresh
+            topn = cand.reshape(N, -1).sum(1).clamp(max=self.pre_nms_top_n)
+            cls = cls * ctr[:, :, None]
+            for i in range(N):
+                sc = cls[i][cand[i]]
+                nz = cand[i].nonzero()
+                bl, kl = nz[:, 0], nz[:, 1] + 1
+                rg, lc = reg[i][bl], locs[l][bl]
+                if cand[i].sum().item() > topn[i].item():
+                    sc, ti = sc.topk(int(topn[i]), sorted=False)
+                    kl, rg, lc = kl[ti], rg[ti], lc[ti]
+                det = torch.stack([lc[:, 0] - rg[:, 0], lc[:, 1] - rg[:, 1], lc[:, 0] + rg[:, 2], lc[:, 1] + rg[:, 3]], 1)
+                h, w = image_sizes[i]
+                det[:, 0].clamp_(min=0, max=w - 1)  # BoxList.clip_to_image, TO_REMOVE = 1
+                det[:, 1].clamp_(min=0, max=h - 1)
+                det[:, 2].clamp_(min=0, max=w - 1)
+                det[:, 3].clamp_(min=0, max=h - 1)
+                ws, hs = det[:, 2] - det[:, 0] + 1, det[:, 3] - det[:, 1] + 1
+                keep = ((ws >= self.min_size) & (hs >= self.min_size)).nonzero().squeeze(1)
+                per_img[i].append((det[keep], torch.sqrt(sc)[keep], kl[keep]))
+        results = []
+        for lv in per_img:
+            boxes = torch.cat([x[0] for x in lv], 0)
+            scores = torch.cat([x[1] for x in lv], 0)
+            labels = torch.cat([x[2] for x in lv], 0)
+            rb, rs, rl = [], [], []
+            for j in range(1, self.num_classes):
+                inds = (labels == j).nonzero().view(-1)
+                bj, sj = boxes[inds].view(-1, 4), scores[inds]
+                keep = _box_nms(bj, sj, self.nms_thresh).to(bj.device)
+                rb.append(bj[keep])
+                rs.append(sj[keep])
+                rl.append(torch.full((len(keep),), j, dtype=torch.int64, device=bj.device))
+            rb, rs, rl = torch.cat(rb), torch.cat(rs), torch.cat(rl)
+            n = len(rs)
+            if n > self.fpn_post_nms_top_n > 0:
+                th, _ = torch.kthvalue(rs.cpu(), n - self.fpn_post_nms_top_n + 1)
+                k = torch.nonzero(rs >= th.item()).squeeze(1)
+                rb, rs, rl = rb[k], rs[k], rl[k]
+            results.append((rb, rs, rl))
+        return results
+
+
+class FCOSModule(nn.Module):
+    """model["fcos"] (reference fcos.py:117-258)."""
+
+    def __init__(self, num_classes=9, mode="precision"):
+        super().__init__()
+        self.head = FCOSHead(num_classes)
+        self.loss_evaluator = FCOSLossComputation()
+        self.box_selector_test = FCOSPostProcessor(num_classes=num_classes, mode=mode)
+        self.mode = mode
+
+    def forward(self, image_sizes, rows, shape, targets=None, act_maps=None):
+        if self.training:
+            if targets is None:
+                # reference fcos.py:215-220: the target pass only yields an identically-zero loss whose
+                # gradients are zero, so the head is not run at all (SURVEY.md 8d "dead work")
+                return None, {"zero": rows.new_zeros(())}
+            logits, reg, ctr = self.head(rows, shape)
+            lc, lr, lctr = self.loss_evaluator(shape, logits, reg, ctr, targets)
+            return None, {"loss_cls": lc, "loss_reg": lr, "loss_centerness": lctr}
+        logits, reg, ctr = self.head(rows, shape, need_cls=self.mode != "light")
+        if self.mode == "light":
+            logits = act_maps[:, 1:]
+        elif self.mode == "precision":
+            logits = 0.5 * logits.sigmoid() + 0.5 * act_maps[:, 1:]
+        return self.box_selector_test(shape, logits, reg, ctr, image_sizes), {}
+
+
+def build_fcos(cfg=None, num_classes=9, mode="precision"):
+    return FCOSModule(num_classes, mode)

@@ -1,0 +1,484 @@
+"""torch.autograd wrappers around the C ABI (include/scan_hip.h).
+
+PyTorch is plumbing here: it owns device memory, the current HIP stream and the
+autograd tape; all arithmetic of the ops below happens in libscan_hip.so.
+Every op requires CUDA(HIP) tensors and raises otherwise -- there is no CPU
+fallback in the product path.
+
+Activations are "pyramids": a contiguous fp32 matrix [M, Cs] (rows = pixels in
+level-major / image / y / x order, Cs = channel stride, a multiple of 4) plus a
+``PyramidShape`` describing how rows split into levels (see include/scan_hip.h).
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import PyramidDesc, call, query
+
+
+# ----------------------------------------------------------------------------- plumbing
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("scan_amd ops run only on the GPU (HIP) -- got a %s tensor; no CPU fallback" % t.device)
+        if t.dtype == torch.float32 and not t.is_contiguous():
+            raise RuntimeError("scan_amd op got a non-contiguous tensor")
+
+
+def pad4(c):
+    return (c + 3) // 4 * 4
+
+
+class PyramidShape:
+    """Level table of a pyramid activation (mirrors scan_pyramid_t)."""
+
+    def __init__(self, n_images, sizes):
+        self.n_images = int(n_images)
+        self.sizes = [(int(h), int(w)) for h, w in sizes]
+        self.row_off = [0]
+        for h, w in self.sizes:
+            self.row_off.append(self.row_off[-1] + self.n_images * h * w)
+        d = PyramidDesc()
+        d.n_levels = len(self.sizes)
+        d.n_images = self.n_images
+        for i, (h, w) in enumerate(self.sizes):
+            d.h[i], d.w[i] = h, w
+        for i, o in enumerate(self.row_off):
+            d.row_off[i] = o
+        self.desc = d
+
+    @property
+    def rows(self):
+        return self.row_off[-1]
+
+    @property
+    def n_levels(self):
+        return len(self.sizes)
+
+    def level(self, l):
+        return PyramidShape(self.n_images, [self.sizes[l]])
+
+    def conv_out(self, ksize, stride):
+        pad = ksize // 2
+        return PyramidShape(self.n_images, [((h + 2 * pad - ksize) // stride + 1, (w + 2 * pad - ksize) // stride + 1)
+                                            for h, w in self.sizes])
+
+    def ref(self):
+        return ctypes.byref(self.desc)
+
+    def __eq__(self, o):
+        return isinstance(o, PyramidShape) and self.n_images == o.n_images and self.sizes == o.sizes
+
+    def __repr__(self):
+        return "PyramidShape(N=%d, %s)" % (self.n_images, self.sizes)
+
+
+def nchw_to_rows(x, cs=None):
+    """[N,C,H,W] -> ([N*H*W, Cs] rows, PyramidShape); zero-pads channels to Cs."""
+    N, C, H, W = x.shape
+    cs = cs or pad4(C)
+    rows = x.permute(0, 2, 3, 1).reshape(N * H * W, C)
+    if cs != C:
+        rows = torch.nn.functional.pad(rows, (0, cs - C))
+    return rows.contiguous(), PyramidShape(N, [(H, W)])
+
+
+def rows_to_nchw(rows, shape, l=0, c=None):
+    """view of level l as a logical [N,C,H,W] tensor (channels_last strides)."""
+    h, w = shape.sizes[l]
+    r = rows[shape.row_off[l]:shape.row_off[l + 1]]
+    if c is not None:
+        r = r[:, :c]
+    return r.view(shape.n_images, h, w, r.shape[1]).permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------- weights
+def pack_weight(weight, cs):
+    """[Cout,Cin,k,k] parameter -> [Cout, k*k, Cs] fp32 ("OHWI").  Zero-copy when the
+    parameter is stored channels_last and Cin == Cs."""
+    co, ci, kh, kw = weight.shape
+    w = weight.permute(0, 2, 3, 1)  # [Cout,k,k,Cin]
+    if ci == cs and w.is_contiguous():
+        return w.reshape(co, kh * kw, ci)
+    out = weight.new_zeros(co, kh * kw, cs)
+    out[:, :, :ci] = w.reshape(co, kh * kw, ci)
+    return out
+
+
+def unpack_weight_grad(dw, weight):
+    """[Cout, T, Cs] -> gradient with the parameter's logical shape (channels_last strides)."""
+    co, ci, kh, kw = weight.shape
+    return dw[:, :, :ci].reshape(co, kh, kw, ci).permute(0, 3, 1, 2)
+
+
+class _Conv2d(torch.autograd.Function):
+    """conv (k in {1,3}, stride in {1,2}, pad k//2) + bias (+ ReLU) on a pyramid."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, shape, ksize, stride, relu, cout_s):
+        _chk(x, bias)
+        if not weight.is_cuda:
+            raise RuntimeError("scan_amd ops run only on the GPU (HIP); no CPU fallback")
+        cs = x.shape[1]
+        assert x.shape[0] == shape.rows, (x.shape, shape)
+        cout = weight.shape[0]
+        cout_s = cout_s or pad4(cout)
+        wp = pack_weight(weight, cs)
+        oshape = shape.conv_out(ksize, stride)
+        y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
+        call("scan_conv2d_forward", _ptr(x), shape.ref(), cs, _ptr(wp), _ptr(bias), _ptr(y), oshape.ref(), cout, cout_s,
+             ksize, stride, int(relu), _stream())
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.cfg = (shape, oshape, ksize, stride, relu, cout_s, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        shape, oshape, ksize, stride, relu, cout_s, has_bias = ctx.cfg
+        cs = x.shape[1]
+        cout, cin = weight.shape[0], weight.shape[1]
+        T = ksize * ksize
+        st = _stream()
+        dy = dy.contiguous()
+        if relu:
+            g = torch.empty_like(dy)
+            call("scan_relu_backward", _ptr(dy), _ptr(y), _ptr(g), dy.numel(), st)
+            dy = g
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = pack_weight(weight, cs)
+            wt = x.new_empty((cs, T, cout_s))
+            call("scan_weight_transpose", _ptr(wp), cout, T, cs, _ptr(wt), cout_s, st)
+            dx = torch.empty_like(x)
+            call("scan_conv2d_dgrad", _ptr(dy), oshape.ref(), cout_s, _ptr(wt), _ptr(dx), shape.ref(), cs, cs, ksize,
+                 stride, None, st)
+        if ctx.needs_input_grad[1]:
+            n = query("scan_conv2d_wgrad_ws_floats", oshape.ref(), cs, cout, ksize)
+            ws = x.new_empty((n,))
+            dwp = x.new_empty((cout, T, cs))
+            call("scan_conv2d_wgrad", _ptr(x), shape.ref(), cs, _ptr(dy), oshape.ref(), cout, cout_s, ksize, stride,
+                 _ptr(dwp), 0, _ptr(ws), st)
+            dw = unpack_weight_grad(dwp, weight)
+        if has_bias and ctx.needs_input_grad[2]:
+            M = dy.shape[0]
+            ws = x.new_empty((query("scan_colsum_ws_floats", M, cout),))
+            db = x.new_empty((cout,))
+            call("scan_colsum", _ptr(dy), M, cout, cout_s, _ptr(db), 0, _ptr(ws), st)
+        return dx, dw, db, None, None, None, None, None
+
+
+def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None):
+    """Returns rows [M_out, Cout_s]; the output PyramidShape is shape.conv_out(ksize, stride)."""
+    return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s)
+
+
+# ----------------------------------------------------------------------------- GroupNorm + ReLU
+class _GroupNormReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, shape, relu, eps):
+        _chk(x, gamma, beta)
+        C = x.shape[1]
+        st = _stream()
+        nws = query("scan_groupnorm_ws_floats", shape.ref(), C, 32)
+        ws = torch.empty((nws // 2 + 1,), dtype=torch.float64, device=x.device)
+        stats = x.new_empty((shape.n_levels * shape.n_images * 32 * 2,))
+        call("scan_groupnorm_stats", _ptr(x), shape.ref(), C, 32, eps, _ptr(stats), _ptr(ws), st)
+        y = torch.empty_like(x)
+        call("scan_groupnorm_relu_forward", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta), int(relu),
+             _ptr(y), st)
+        ctx.save_for_backward(x, y, gamma, stats)
+        ctx.cfg = (shape, relu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, stats = ctx.saved_tensors
+        shape, relu = ctx.cfg
+        C = x.shape[1]
+        dy = dy.contiguous()
+        nws = query("scan_groupnorm_ws_floats", shape.ref(), C, 32)
+        ws = torch.empty((nws // 2 + 1,), dtype=torch.float64, device=x.device)
+        dx = torch.empty_like(x)
+        dg = x.new_empty((C,))
+        db = x.new_empty((C,))
+        call("scan_groupnorm_relu_backward", _ptr(x), _ptr(y), _ptr(dy), shape.ref(), C, 32, _ptr(stats), _ptr(gamma),
+             int(relu), _ptr(dx), _ptr(dg), _ptr(db), 0, _ptr(ws), _stream())
+        return dx, dg, db, None, None, None
+
+
+def groupnorm_relu(x, gamma, beta, shape, relu=True, eps=1e-5):
+    return _GroupNormReLU.apply(x, gamma, beta, shape, relu, eps)
+
+
+# ----------------------------------------------------------------------------- dynamic conv + softmax
+class _DynConvSoftmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat, kernels):
+        _chk(feat, kernels)
+        M, C = feat.shape
+        K = kernels.shape[0]
+        kernels = kernels.contiguous()
+        logits = feat.new_empty((M, K))
+        probs = feat.new_empty((M, K))
+        call("scan_dynconv_softmax_forward", _ptr(feat), _ptr(kernels), M, C, K, _ptr(logits), _ptr(probs), _stream())
+        ctx.save_for_backward(feat, kernels, probs)
+        return logits, probs
+
+    @staticmethod
+    def backward(ctx, d_logits, d_probs):
+        feat, kernels, probs = ctx.saved_tensors
+        M, C = feat.shape
+        K = kernels.shape[0]
+        d_logits = d_logits.contiguous() if d_logits is not None else None
+        d_probs = d_probs.contiguous() if d_probs is not None else None
+        d_feat = torch.empty_like(feat)
+        d_k = torch.empty_like(kernels)
+        ws = feat.new_empty((query("scan_dynconv_ws_floats", M, C, K),))
+        call("scan_dynconv_softmax_backward", _ptr(feat), _ptr(kernels), _ptr(probs), _ptr(d_logits), _ptr(d_probs), M,
+             C, K, _ptr(d_feat), _ptr(d_k), _ptr(ws), _stream())
+        return d_feat, d_k
+
+
+def dynconv_softmax(feat, kernels):
+    """feat [M,256], kernels [K,256] -> (logits [M,K], probs [M,K])."""
+    return _DynConvSoftmax.apply(feat, kernels)
+
+
+# ----------------------------------------------------------------------------- losses
+class _SigmoidFocalSum(torch.autograd.Function):
+    """sum of the element-wise sigmoid focal loss (what SigmoidFocalLoss.forward returns)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, gamma, alpha):
+        _chk(logits, targets)
+        if logits.dim() != 2:
+            raise RuntimeError("logits must be [M, C]")
+        if targets.dtype != torch.int32:
+            raise RuntimeError("targets must be int32")
+        M, C = logits.shape
+        out = logits.new_zeros((1,))
+        call("scan_sigmoid_focal_loss_forward", _ptr(logits), _ptr(targets), M, C, gamma, alpha, None, _ptr(out),
+             _stream())
+        ctx.save_for_backward(logits, targets)
+        ctx.cfg = (gamma, alpha)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets = ctx.saved_tensors
+        gamma, alpha = ctx.cfg
+        M, C = logits.shape
+        d = torch.empty_like(logits)
+        dl = g.expand(M, C).contiguous()
+        call("scan_sigmoid_focal_loss_backward", _ptr(logits), _ptr(targets), _ptr(dl), 1.0, M, C, gamma, alpha, _ptr(d),
+             _stream())
+        return d, None, None, None
+
+
+def sigmoid_focal_loss_sum(logits, targets, gamma, alpha):
+    return _SigmoidFocalSum.apply(logits.contiguous(), targets, float(gamma), float(alpha))
+
+
+class _SigmoidFocalElem(torch.autograd.Function):
+    """element-wise losses [M,C]; the _C.sigmoid_focalloss_forward/backward pair."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, gamma, alpha):
+        _chk(logits, targets)
+        M, C = logits.shape
+        losses = torch.empty_like(logits)
+        call("scan_sigmoid_focal_loss_forward", _ptr(logits), _ptr(targets), M, C, gamma, alpha, _ptr(losses), None,
+             _stream())
+        ctx.save_for_backward(logits, targets)
+        ctx.cfg = (gamma, alpha)
+        return losses
+
+    @staticmethod
+    def backward(ctx, d_loss):
+        logits, targets = ctx.saved_tensors
+        gamma, alpha = ctx.cfg
+        M, C = logits.shape
+        d_loss = d_loss.contiguous()
+        d = torch.empty_like(logits)
+        call("scan_sigmoid_focal_loss_backward", _ptr(logits), _ptr(targets), _ptr(d_loss), 1.0, M, C, gamma, alpha,
+             _ptr(d), _stream())
+        return d, None, None, None
+
+
+class _IouLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight):
+        _chk(pred, target, weight)
+        P = pred.shape[0]
+        out = pred.new_zeros((2,))
+        call("scan_iou_loss_forward", _ptr(pred), _ptr(target), _ptr(weight), P, _ptr(out), _stream())
+        ctx.save_for_backward(pred, target, weight, out)
+        return out[0] / out[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, weight, out = ctx.saved_tensors
+        gn = (g / out[1]).reshape(1).contiguous()
+        d = torch.empty_like(pred)
+        call("scan_iou_loss_backward", _ptr(pred), _ptr(target), _ptr(weight), pred.shape[0], _ptr(gn), _ptr(d),
+             _stream())
+        return d, None, None
+
+
+def iou_loss(pred, target, weight=None):
+    """weighted mean when weight is given (and sums > 0), plain mean otherwise."""
+    return _IouLoss.apply(pred.contiguous(), target.contiguous(), weight.contiguous() if weight is not None else None)
+
+
+class _BceLogitsMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, targets):
+        _chk(logits, targets)
+        M = logits.numel()
+        out = logits.new_zeros((2,))
+        call("scan_bce_logits_forward", _ptr(logits), _ptr(targets), 0.0, None, 0, M, _ptr(out), _stream())
+        ctx.save_for_backward(logits, targets)
+        return out[0] / M
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, targets = ctx.saved_tensors
+        M = logits.numel()
+        gn = (g / M).reshape(1).contiguous()
+        d = torch.empty_like(logits)
+        call("scan_bce_logits_backward", _ptr(logits), _ptr(targets), 0.0, None, 0, M, _ptr(gn), _ptr(d), _stream())
+        return d, None
+
+
+def bce_with_logits_mean(logits, targets):
+    return _BceLogitsMean.apply(logits.contiguous(), targets.contiguous())
+
+
+class _CkaBce(torch.autograd.Function):
+    """sum_c [ sum_m act[m,c+1] bce(logit[m,c], t) / sum_m act[m,c+1] ] / Cf"""
+
+    @staticmethod
+    def forward(ctx, logits, act, target, cf):
+        _chk(logits, act)
+        M = logits.shape[0]
+        assert logits.shape[1] == cf and act.shape[1] == cf + 1
+        out = logits.new_zeros((2 * cf,))
+        call("scan_cka_bce_forward", _ptr(logits), _ptr(act), M, cf, target, _ptr(out), _stream())
+        o = out.view(cf, 2)
+        ctx.save_for_backward(logits, act, o)
+        ctx.cfg = (target, cf)
+        return (o[:, 0] / o[:, 1]).sum() / cf
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, act, o = ctx.saved_tensors
+        target, cf = ctx.cfg
+        gd = (g / (cf * o[:, 1])).contiguous()
+        d = torch.empty_like(logits)
+        call("scan_cka_bce_backward", _ptr(logits), _ptr(act), logits.shape[0], cf, target, _ptr(gd), _ptr(d), _stream())
+        return d, None, None, None
+
+
+def cka_bce(logits, act_detached, target, cf):
+    return _CkaBce.apply(logits.contiguous(), act_detached.contiguous(), float(target), int(cf))
+
+
+class _SoftmaxFocalMean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, gamma):
+        _chk(logits, labels)
+        if labels.dtype != torch.int64:
+            raise RuntimeError("labels must be int64")
+        M, K = logits.shape
+        out = logits.new_zeros((1,))
+        call("scan_softmax_focal_forward", _ptr(logits), _ptr(labels), M, K, gamma, _ptr(out), _stream())
+        ctx.save_for_backward(logits, labels)
+        ctx.gamma = gamma
+        return out[0] / M
+
+    @staticmethod
+    def backward(ctx, g):
+        logits, labels = ctx.saved_tensors
+        M, K = logits.shape
+        d = torch.empty_like(logits)
+        # d_scale must be a host float: one small sync-free path would pass it by pointer; g is a 0-dim tensor
+        call("scan_softmax_focal_backward", _ptr(logits), _ptr(labels), M, K, ctx.gamma, 1.0 / M, _ptr(d), _stream())
+        return d * g, None, None
+
+
+def softmax_focal_loss_mean(logits, labels, gamma=2.0):
+    return _SoftmaxFocalMean.apply(logits.contiguous(), labels.contiguous(), float(gamma))
+
+
+class _GradReverse(torch.autograd.Function):
+    """reference discriminator/layer.py:6-24: forward clone, backward -lambda * g."""
+
+    @staticmethod
+    def forward(ctx, x, lam):
+        _chk(x)
+        ctx.lam = lam
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        call("scan_scale", _ptr(x), 1.0, _ptr(y), x.numel(), _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        d = torch.empty_like(g)
+        call("scan_scale", _ptr(g), -ctx.lam, _ptr(d), g.numel(), _stream())
+        return d, None
+
+
+def grad_reverse(x, lam):
+    return _GradReverse.apply(x, float(lam))
+
+
+# ----------------------------------------------------------------------------- NMS
+def _nms_impl(dets, scores, labels, thr, rule_ge):
+    n = dets.shape[0]
+    if n == 0:
+        # reference csrc/nms.h:17-18: empty input -> empty CPU int64 tensor
+        return torch.empty((0,), dtype=torch.int64, device="cpu")
+    _chk(dets, scores, labels)
+    if n > _lib.NMS_MAX:
+        raise RuntimeError("nms: n=%d exceeds SCAN_NMS_MAX=%d" % (n, _lib.NMS_MAX))
+    dets = dets.contiguous().float()
+    scores = scores.contiguous().float()
+    if labels is not None:
+        labels = labels.contiguous().float()
+    ws = torch.empty((query("scan_nms_ws_bytes", n) + 15) // 16 * 2, dtype=torch.float64, device=dets.device)
+    keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
+    cnt = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    call("scan_nms", _ptr(dets), _ptr(scores), _ptr(labels), n, float(thr), int(rule_ge), _ptr(keep), _ptr(cnt),
+         _ptr(ws), _stream())
+    return keep[:int(cnt.item())]
+
+
+def nms(dets, scores, thr, rule_ge=True):
+    """kept original indices, ascending (reference csrc/cpu/nms_cpu.cpp:64, cuda/nms.cu:127-130)."""
+    return _nms_impl(dets, scores, None, thr, rule_ge)
+
+
+def ml_nms(dets, scores, labels, thr):
+    """label-aware NMS with the CUDA '>' rule (reference csrc/cuda/ml_nms.cu:13-24,62)."""
+    return _nms_impl(dets, scores, labels, thr, False)
+
+
+# ----------------------------------------------------------------------------- optimizer
+def sgd_momentum_(p, g, buf, lr, wd, momentum, first_step):
+    _chk(p, g, buf)
+    call("scan_sgd_momentum", _ptr(p), _ptr(g), _ptr(buf), p.numel(), float(lr), float(wd), float(momentum),
+         int(first_step), _stream())

@@ -1,0 +1,368 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (scan_amd.ops /
+scan_amd._C -> ctypes -> libscan_hip.so), against the CPU oracle (oracle/) and the golden vectors
+captured from the reference (tests/golden/, oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _rows(x_nchw, dev, cs=None):
+    from scan_amd import ops
+    r, s = ops.nchw_to_rows(x_nchw.to(dev), cs)
+    return r, s
+
+
+def _pyr(levels, dev, cs=None):
+    """list of NCHW CPU tensors -> (rows on GPU, PyramidShape)"""
+    from scan_amd import ops
+    rows, sizes = [], []
+    for x in levels:
+        r, s = ops.nchw_to_rows(x.to(dev), cs)
+        rows.append(r)
+        sizes.append(s.sizes[0])
+    return torch.cat(rows, 0).contiguous(), ops.PyramidShape(levels[0].shape[0], sizes)
+
+
+def _unrows(rows, shape, c):
+    from scan_amd import ops
+    return [ops.rows_to_nchw(rows.detach(), shape, l, c).contiguous().cpu() for l in range(shape.n_levels)]
+
+
+# ----------------------------------------------------------------------------- loader
+def test_library_loaded(device):
+    from scan_amd import _lib
+    assert _lib.lib().scan_abi_version() == 1
+    assert os.path.basename(_lib.LIB_PATH) == "libscan_hip.so"
+
+
+# ----------------------------------------------------------------------------- pointwise vs golden
+def test_sigmoid_focal_golden(device, gold_dir):
+    from scan_amd import _C
+    from oracle import coracle
+    g = np.load(os.path.join(gold_dir, "pointwise.npz"))
+    x = torch.from_numpy(g["focal_logits"]).to(device)
+    t = torch.from_numpy(g["focal_targets"]).to(device)
+    l = _C.sigmoid_focalloss_forward(x, t, 8, 2.0, 0.25).cpu().numpy()
+    # reference CPU formula (unstable tail) vs the CUDA formula we follow: SURVEY 8c numerics caveat
+    np.testing.assert_allclose(l, g["focal_loss"], rtol=2e-4, atol=1e-4)
+    np.testing.assert_allclose(l, coracle.sigmoid_focal_fwd(g["focal_logits"], g["focal_targets"], 2.0, 0.25),
+                               rtol=1e-5, atol=1e-7)
+    d = _C.sigmoid_focalloss_backward(x, t, torch.from_numpy(g["focal_dloss"]).to(device), 8, 2.0, 0.25).cpu().numpy()
+    np.testing.assert_allclose(d, g["focal_dlogits"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(d, coracle.sigmoid_focal_bwd(g["focal_logits"], g["focal_targets"], g["focal_dloss"],
+                                                            2.0, 0.25), rtol=1e-5, atol=1e-7)
+
+
+def test_sigmoid_focal_layer_sum_and_tail(device):
+    from scan_amd.layers import SigmoidFocalLoss
+    from oracle import coracle
+    rs = np.random.RandomState(0)
+    for M, C in ((1, 8), (1000, 8), (4097, 1), (333, 3)):
+        x = (rs.randn(M, C) * 8).astype(np.float32)  # includes |x| > 17 where the reference CPU formula overflows
+        t = rs.randint(-1, C + 1, M).astype(np.int32)
+        xt = torch.from_numpy(x).to(device).requires_grad_(True)
+        loss = SigmoidFocalLoss(2.0, 0.25)(xt, torch.from_numpy(t).to(device))
+        ref = coracle.sigmoid_focal_fwd(x, t, 2.0, 0.25).astype(np.float64).sum()
+        assert abs(loss.item() - ref) <= 1e-4 * max(1.0, abs(ref))
+        (loss * 0.5).backward()
+        gref = coracle.sigmoid_focal_bwd(x, t, np.full((M, C), 0.5, np.float32), 2.0, 0.25)
+        np.testing.assert_allclose(xt.grad.cpu().numpy(), gref, rtol=1e-5, atol=1e-7)
+    with pytest.raises(RuntimeError):
+        from scan_amd import _C
+        _C.sigmoid_focalloss_forward(torch.zeros(4, 3, device=device), torch.zeros(4, dtype=torch.int32, device=device),
+                                     8, 2.0, 0.25)
+    with pytest.raises(RuntimeError):
+        _C.sigmoid_focalloss_forward(torch.zeros(4, 8), torch.zeros(4, dtype=torch.int32), 8, 2.0, 0.25)
+
+
+def test_iou_loss_golden(device, gold_dir):
+    from scan_amd.layers import IOULoss
+    g = np.load(os.path.join(gold_dir, "pointwise.npz"))
+    p = torch.from_numpy(g["iou_pred"]).to(device).requires_grad_(True)
+    l = IOULoss()(p, torch.from_numpy(g["iou_target"]).to(device), torch.from_numpy(g["iou_weight"]).to(device))
+    assert abs(l.item() - float(g["iou_loss"])) <= 1e-5 * abs(float(g["iou_loss"]))
+    l.backward()
+    np.testing.assert_allclose(p.grad.cpu().numpy(), g["iou_dpred"], rtol=1e-4, atol=1e-7)
+    # unweighted mean
+    p2 = torch.from_numpy(g["iou_pred"]).to(device)
+    l2 = IOULoss()(p2, torch.from_numpy(g["iou_target"]).to(device))
+    from oracle import coracle
+    v, _ = coracle.iou_loss(g["iou_pred"], g["iou_target"], None)
+    assert abs(l2.item() - v) <= 1e-5 * abs(v)
+
+
+def test_softmax_focal_golden(device, gold_dir):
+    from scan_amd.layers import FocalLoss
+    g = np.load(os.path.join(gold_dir, "pointwise.npz"))
+    z = torch.from_numpy(g["sfl_logits"]).to(device).requires_grad_(True)
+    l = FocalLoss(9)(z, torch.from_numpy(g["sfl_labels"]).to(device))
+    assert abs(l.item() - float(g["sfl_loss"])) <= 1e-5 * abs(float(g["sfl_loss"]))
+    l.backward()
+    np.testing.assert_allclose(z.grad.cpu().numpy(), g["sfl_dlogits"], rtol=1e-4, atol=1e-8)
+
+
+def test_grl_golden(device, gold_dir):
+    from scan_amd.layers import GradientReversal
+    g = np.load(os.path.join(gold_dir, "pointwise.npz"))
+    x = torch.from_numpy(g["grl_x"]).to(device).requires_grad_(True)
+    y = GradientReversal(0.02)(x)
+    assert torch.equal(y.cpu(), torch.from_numpy(g["grl_y"]))
+    y.backward(torch.from_numpy(g["grl_gy"]).to(device))
+    np.testing.assert_allclose(x.grad.cpu().numpy(), g["grl_gx"], rtol=1e-6, atol=0)
+
+
+def test_bce_and_cka(device):
+    from scan_amd import ops
+    torch.manual_seed(3)
+    M, Cf = 777, 8
+    x = torch.randn(M) * 3
+    t = torch.rand(M)
+    xg = x.to(device).requires_grad_(True)
+    l = ops.bce_with_logits_mean(xg, t.to(device))
+    xr = x.clone().requires_grad_(True)
+    lr = F.binary_cross_entropy_with_logits(xr, t)
+    assert abs(l.item() - lr.item()) < 1e-6 * max(1, abs(lr.item()))
+    l.backward()
+    lr.backward()
+    np.testing.assert_allclose(xg.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-5, atol=1e-9)
+    # CKA: per-class act-weighted BCE (reference fcos_head_discriminator_con.py:105-124)
+    logits = torch.randn(M, Cf) * 2
+    act = torch.softmax(torch.randn(M, Cf + 1), 1)
+    for target in (0.0, 1.0):
+        lg = logits.to(device).requires_grad_(True)
+        l = ops.cka_bce(lg, act.to(device), target, Cf)
+        lc = logits.clone().requires_grad_(True)
+        ref = 0
+        for c in range(Cf):
+            a = act[:, c + 1]
+            ref = ref + F.binary_cross_entropy_with_logits(lc[:, c], torch.full((M,), target), weight=a,
+                                                           reduction="sum") / a.sum() / Cf
+        assert abs(l.item() - ref.item()) < 1e-5 * abs(ref.item())
+        l.backward()
+        ref.backward()
+        np.testing.assert_allclose(lg.grad.cpu().numpy(), lc.grad.numpy(), rtol=1e-4, atol=1e-9)
+
+
+# ----------------------------------------------------------------------------- NMS (bit-exact)
+def test_nms_known_answers(device, gold_dir):
+    from scan_amd.layers import nms
+    kat = json.load(open(os.path.join(gold_dir, "nms_kat.json")))
+    for case in kat["cases"]:
+        keep = nms(torch.tensor(case["boxes"], device=device), torch.tensor(case["scores"], device=device), case["thresh"])
+        assert sorted(keep.cpu().tolist()) == case["keep_sorted"]
+        assert keep.cpu().tolist() == sorted(keep.cpu().tolist())
+
+
+def _rand_boxes(rs, n, span=200.0, quant=None):
+    xy = rs.uniform(0, span, (n, 2))
+    wh = rs.uniform(1, span / 3, (n, 2))
+    b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+    if quant:
+        b = np.round(b / quant) * quant
+    return b.astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 127, 500, 1000, 4097, 8192])
+def test_nms_random_bit_exact(device, n):
+    from scan_amd import ops
+    from oracle import coracle
+    rs = np.random.RandomState(n)
+    # quantised coordinates produce exact IoU ties with the threshold and duplicate boxes
+    boxes = _rand_boxes(rs, n, quant=4.0 if n % 2 else None)
+    scores = rs.rand(n).astype(np.float32)
+    if n > 10:
+        scores[::7] = scores[3]  # score ties: order must fall back to the index
+    for thr in (0.3, 0.5, 0.6):
+        keep = ops.nms(torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device), thr, rule_ge=True)
+        ref = coracle.nms(boxes, scores, thr)
+        assert np.array_equal(keep.cpu().numpy(), ref), (n, thr)
+
+
+def test_nms_empty_and_limits(device):
+    from scan_amd.layers import nms
+    k = nms(torch.zeros(0, 4, device=device), torch.zeros(0, device=device), 0.5)
+    assert k.numel() == 0 and k.dtype == torch.int64 and k.device.type == "cpu"  # reference csrc/nms.h:17-18
+    with pytest.raises(RuntimeError):
+        nms(torch.zeros(8193, 4, device=device), torch.zeros(8193, device=device), 0.5)
+
+
+def test_ml_nms_bit_exact(device):
+    from scan_amd.layers import ml_nms
+    from oracle import coracle
+    rs = np.random.RandomState(5)
+    for n in (10, 300, 2500):
+        boxes = _rand_boxes(rs, n, span=120.0)
+        scores = rs.rand(n).astype(np.float32)
+        labels = rs.randint(1, 9, n).astype(np.float32)
+        keep = ml_nms(torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device),
+                      torch.from_numpy(labels).to(device), 0.6)
+        assert np.array_equal(keep.cpu().numpy(), coracle.ml_nms(boxes, scores, labels, 0.6))
+
+
+def test_nms_idempotent_full_size(device):
+    """size-independent property at the path's maximum n: NMS of the survivors keeps all of them."""
+    from scan_amd import ops
+    rs = np.random.RandomState(11)
+    boxes = torch.from_numpy(_rand_boxes(rs, 8192, span=2048.0)).to(device)
+    scores = torch.from_numpy(rs.rand(8192).astype(np.float32)).to(device)
+    keep = ops.nms(boxes, scores, 0.6)
+    again = ops.nms(boxes[keep], scores[keep], 0.6)
+    assert again.numel() == keep.numel()
+
+
+# ----------------------------------------------------------------------------- conv (fp32 MFMA)
+CONV_CASES = [
+    # (levels [(H,W)], N, Cin, Cout, k, stride, relu)
+    ([(8, 16)], 2, 256, 256, 3, 1, False),
+    ([(16, 32), (8, 16), (4, 8), (2, 4), (1, 2)], 2, 256, 256, 3, 1, False),  # shared-weight tower
+    ([(9, 13)], 1, 64, 128, 3, 1, True),     # ragged spatial size, fused ReLU
+    ([(32, 64)], 1, 3, 64, 3, 1, True),      # first VGG conv (Cin 3 -> stride 4)
+    ([(8, 16)], 2, 512, 256, 1, 1, False),   # FPN lateral 1x1
+    ([(8, 16)], 2, 256, 256, 3, 2, False),   # P6/P7 stride 2
+    ([(7, 9)], 1, 256, 256, 3, 2, False),    # stride 2, odd size
+    ([(8, 16), (4, 8)], 2, 265, 256, 3, 1, True),   # head_out: cat(features, act maps)
+    ([(8, 16)], 2, 256, 8, 3, 1, False),     # cls_logits (skinny N kernel)
+    ([(8, 16)], 2, 256, 5, 3, 1, False),     # bbox_pred + centerness fused
+    ([(8, 16)], 1, 264, 1024, 3, 1, True),   # stacked CKA class branches
+    ([(6, 10)], 2, 128, 40, 3, 1, False),    # Cout tail inside a 128-wide tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(device, case):
+    from scan_amd import ops
+    sizes, N, cin, cout, k, stride, relu = case
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
+    xs = [torch.randn(N, cin, h, w, generator=g) for h, w in sizes]
+    wgt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    # oracle: plain fp32 torch on the CPU
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    wr, br = wgt.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    yr = [F.conv2d(x, wr, br, stride=stride, padding=k // 2) for x in xr]
+    if relu:
+        yr = [F.relu(y) for y in yr]
+    gys = [torch.randn(y.shape, generator=g) for y in yr]
+    sum((y * gy).sum() for y, gy in zip(yr, gys)).backward()
+    # HIP
+    cs = ops.pad4(cin)
+    rows, shape = _pyr(xs, device, cs)
+    rows.requires_grad_(True)
+    wd = wgt.to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = bias.to(device).requires_grad_(True)
+    y = ops.conv2d(rows, wd, bd, shape, k, stride, relu=relu)
+    oshape = shape.conv_out(k, stride)
+    ys = _unrows(y, oshape, cout)
+    for a, b in zip(ys, yr):
+        np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-4, atol=2e-5)
+    gy_rows, _ = _pyr(gys, device, y.shape[1])
+    y.backward(gy_rows)
+    dxs = _unrows(rows.grad, shape, cin)
+    for a, b in zip(dxs, xr):
+        np.testing.assert_allclose(a.numpy(), b.grad.numpy(), rtol=1e-4, atol=2e-5)
+    scale = max(1.0, float(wr.grad.abs().max()))
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(br.grad.abs().max())))
+
+
+def test_conv2d_linearity_full_size(device):
+    """size-independent property at the BASELINE config size (tower layer on a 2 x 1024x2048 pyramid):
+    conv(a*x1 + x2) == a*conv(x1) + conv(x2) - bias terms, and the pyramid launch equals per-level launches."""
+    from scan_amd import ops
+    N = 2
+    sizes = [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)]
+    shape = ops.PyramidShape(N, sizes)
+    torch.manual_seed(0)
+    x1 = torch.randn(shape.rows, 256, device=device)
+    x2 = torch.randn(shape.rows, 256, device=device)
+    w = (torch.randn(256, 256, 3, 3, device=device) / 48).contiguous(memory_format=torch.channels_last)
+    y1 = ops.conv2d(x1, w, None, shape)
+    y2 = ops.conv2d(x2, w, None, shape)
+    y12 = ops.conv2d(2.0 * x1 + x2, w, None, shape)
+    err = (y12 - (2.0 * y1 + y2)).abs().max().item()
+    assert err < 1e-3 * y12.abs().max().item()
+    for l in (0, 4):
+        yl = ops.conv2d(x1[shape.row_off[l]:shape.row_off[l + 1]].contiguous(), w, None, shape.level(l))
+        assert torch.equal(yl, y1[shape.row_off[l]:shape.row_off[l + 1]])
+
+
+def test_conv2d_errors(device):
+    from scan_amd import ops
+    shape = ops.PyramidShape(1, [(4, 4)])
+    x = torch.zeros(16, 6, device=device)  # stride not a multiple of 4
+    w = torch.zeros(8, 6, 3, 3, device=device)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, w, None, shape)
+    with pytest.raises(RuntimeError):
+        ops.conv2d(torch.zeros(16, 8), torch.zeros(8, 8, 3, 3), None, shape)  # CPU tensors: no fallback
+
+
+# ----------------------------------------------------------------------------- GroupNorm + ReLU
+@pytest.mark.parametrize("sizes", [[(8, 16)], [(16, 32), (8, 16), (4, 8), (2, 4), (1, 2)], [(5, 7), (3, 3)]])
+def test_groupnorm_relu(device, sizes):
+    from scan_amd import ops
+    N = 2
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(N, 256, h, w, generator=g) * 2 + 0.5 for h, w in sizes]
+    gamma = 1 + 0.1 * torch.randn(256, generator=g)
+    beta = 0.1 * torch.randn(256, generator=g)
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    yr = [F.relu(F.group_norm(x, 32, gr, br)) for x in xr]
+    gys = [torch.randn(y.shape, generator=g) for y in yr]
+    sum((y * gy).sum() for y, gy in zip(yr, gys)).backward()
+    rows, shape = _pyr(xs, device)
+    rows.requires_grad_(True)
+    gd, bd = gamma.to(device).requires_grad_(True), beta.to(device).requires_grad_(True)
+    y = ops.groupnorm_relu(rows, gd, bd, shape)
+    for a, b in zip(_unrows(y, shape, 256), yr):
+        np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-4, atol=1e-5)
+    gy_rows, _ = _pyr(gys, device)
+    y.backward(gy_rows)
+    for a, b in zip(_unrows(rows.grad, shape, 256), xr):
+        np.testing.assert_allclose(a.numpy(), b.grad.numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(gd.grad.cpu().numpy(), gr.grad.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- dynamic conv + softmax
+@pytest.mark.parametrize("M,K", [(1, 9), (15, 9), (16, 9), (1000, 9), (4099, 9), (257, 2)])
+def test_dynconv_softmax(device, M, K):
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(M)
+    feat = torch.randn(M, 256, generator=g)
+    ker = torch.randn(K, 256, generator=g) / 16
+    fr, kr = feat.clone().requires_grad_(True), ker.clone().requires_grad_(True)
+    lr = fr @ kr.t()
+    pr = lr.softmax(1)
+    g1, g2 = torch.randn(M, K, generator=g), torch.randn(M, K, generator=g)
+    ((lr * g1).sum() + (pr * g2).sum()).backward()
+    fd, kd = feat.to(device).requires_grad_(True), ker.to(device).requires_grad_(True)
+    l, p = ops.dynconv_softmax(fd, kd)
+    np.testing.assert_allclose(l.detach().cpu().numpy(), lr.detach().numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(p.detach().cpu().numpy(), pr.detach().numpy(), rtol=1e-5, atol=1e-6)
+    ((l * g1.to(device)).sum() + (p * g2.to(device)).sum()).backward()
+    np.testing.assert_allclose(fd.grad.cpu().numpy(), fr.grad.numpy(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(kd.grad.cpu().numpy(), kr.grad.numpy(), rtol=1e-4, atol=1e-4 * max(1.0, float(kr.grad.abs().max())))
+
+
+def test_sgd_kernel(device):
+    from scan_amd import ops
+    torch.manual_seed(0)
+    p = torch.randn(1001)
+    g = torch.randn(1001)
+    pr = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pr], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    pd, buf = p.to(device), torch.zeros(1001, device=device)
+    for it in range(3):
+        pr.grad = g.clone() * (it + 1)
+        opt.step()
+        ops.sgd_momentum_(pd, (g * (it + 1)).to(device), buf, 0.01, 1e-4, 0.9, it == 0)
+    np.testing.assert_allclose(pd.cpu().numpy(), pr.detach().numpy(), rtol=1e-6, atol=1e-7)

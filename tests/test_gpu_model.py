@@ -1,0 +1,117 @@
+"""GPU parity of the assembled hot path (backbone + condgraph + FCOS + CKA discriminators, the
+three-phase DA iteration, inference + NMS) against the golden vectors captured from the imported
+reference (tests/golden/step_128x256.*, inference_128x256.npz; oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+LOSS_RTOL = 1e-4  # north star: fp32 losses within 1e-4 rel of the reference
+
+
+def _digest(g):
+    flat = g.detach().double().reshape(-1).cpu()
+    idx = torch.linspace(0, flat.numel() - 1, 8).long()
+    return [flat.sum().item(), flat.abs().sum().item()] + flat[idx].tolist()
+
+
+@pytest.fixture(scope="module")
+def step_result(device, gold_dir):
+    from scan_amd import engine, synth
+    gold = json.load(open(os.path.join(gold_dir, "step_128x256.json")))
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    model = engine.build_model(9, device=device, attn_dropout=0.0)
+    engine.load_procedural_weights(model)
+    trainer = engine.Trainer(model)
+    # logical-order gradient digests need the params' grads before the optimizer step: do the phases by
+    # hand through Trainer.step but with lr 0 so parameters stay put
+    for g in trainer.groups.values():
+        g.lr = 0.0
+    imgs_s = synth.synth_images(N, H, W, gold["seeds"]["src"]).to(device)
+    imgs_t = synth.synth_images(N, H, W, gold["seeds"]["tgt"]).to(device)
+    tg = synth.synth_targets(N, H, W, 8, 12, gold["seeds"]["boxes"])
+    losses = trainer.step(imgs_s, tg, imgs_t)
+    torch.cuda.synchronize()
+    return gold, model, {k: float(v) for k, v in losses.items()}
+
+
+def test_step_losses_match_reference(step_result):
+    gold, model, losses = step_result
+    for k, ref in gold["losses"].items():
+        assert k in losses, k
+        if ref == 0.0:
+            assert losses[k] == 0.0
+        else:
+            assert abs(losses[k] - ref) <= LOSS_RTOL * abs(ref), (k, losses[k], ref)
+
+
+def test_step_gradients_match_reference(step_result):
+    gold, model, _ = step_result
+    worst = 0.0
+    for mk, m in model.items():
+        for name, p in m.named_parameters():
+            if not p.requires_grad:
+                assert name not in gold["grad_digest"][mk]
+                continue
+            ref = gold["grad_digest"][mk].get(name)
+            if ref is None:  # cond_2: no gradient in RNN mode (reference condgraph.py:237 vs 315-319)
+                assert float(p.grad.abs().sum()) == 0.0, name
+                continue
+            mine = _digest(p.grad)
+            tol = 1e-3 * max(ref[1], 1e-3)
+            assert abs(mine[1] - ref[1]) <= tol, (mk, name, mine[1], ref[1])
+            assert abs(mine[0] - ref[0]) <= tol, (mk, name, mine[0], ref[0])
+            for a, b in zip(mine[2:], ref[2:]):
+                assert abs(a - b) <= 1e-3 * abs(b) + 1e-4 * ref[1] / max(1, p.numel()) ** 0.5 + 1e-7, (mk, name, a, b)
+            worst = max(worst, abs(mine[1] - ref[1]) / max(ref[1], 1e-3))
+    assert worst < 1e-3
+
+
+def test_prototype_and_kernels_match_reference(step_result, gold_dir):
+    gold, model, _ = step_result
+    g = np.load(os.path.join(gold_dir, "step_128x256.npz"))
+    mh = model["middle_head"]
+    np.testing.assert_allclose(mh.prototype.cpu().numpy(), g["prototype_after"], rtol=1e-4, atol=1e-5)
+    with torch.no_grad():
+        np.testing.assert_allclose(mh.get_conded_weight().cpu().numpy(), g["kernels"], rtol=1e-3, atol=1e-5)
+
+
+def test_inference_matches_reference(device, gold_dir):
+    from scan_amd import engine, synth
+    g = np.load(os.path.join(gold_dir, "inference_128x256.npz"))
+    imgs = synth.synth_images(2, 128, 256, 3234).to(device)
+    for mode in ("common", "precision"):
+        model = engine.build_model(9, test_mode=mode, device=device)
+        engine.load_procedural_weights(model)
+        res = engine.inference(model, imgs)
+        for i, (b, s, l) in enumerate(res):
+            rb, rs, rl = g["%s_boxes_%d" % (mode, i)], g["%s_scores_%d" % (mode, i)], g["%s_labels_%d" % (mode, i)]
+            assert len(b) == len(rb), (mode, i, len(b), len(rb))
+            if len(b) == 0:
+                continue
+            b, s, l = b.cpu().numpy(), s.cpu().numpy(), l.cpu().numpy()
+            o1, o2 = np.lexsort((s, l)), np.lexsort((rs, rl))
+            assert np.array_equal(l[o1], rl[o2])  # per-class sets equal (set-equal per class)
+            np.testing.assert_allclose(s[o1], rs[o2], rtol=0, atol=1e-5)
+            np.testing.assert_allclose(b[o1], rb[o2], rtol=0, atol=2e-3)
+
+
+def test_two_steps_run_and_update(device):
+    """optimizer path: parameters move, momentum buffers fill, losses stay finite over 2 iterations."""
+    from scan_amd import engine, synth
+    model = engine.build_model(9, device=device, attn_dropout=0.1)
+    engine.load_procedural_weights(model)
+    trainer = engine.Trainer(model)
+    imgs_s = synth.synth_images(1, 128, 128, 1).to(device)
+    imgs_t = synth.synth_images(1, 128, 128, 2).to(device)
+    tg = synth.synth_targets(1, 128, 128, 8, 6, 3)
+    before = trainer.groups["fcos"].flat_p.clone()
+    for _ in range(2):
+        losses = trainer.step(imgs_s, tg, imgs_t)
+        assert all(torch.isfinite(v).item() for v in losses.values())
+    assert not torch.equal(before, trainer.groups["fcos"].flat_p)
+    assert trainer.groups["backbone"].flat_m.abs().sum().item() > 0

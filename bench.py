@@ -1,0 +1,151 @@
+#!/usr/bin/env python
+"""bench.py -- SCAN hot path on MI355X: train images/sec, VGG16 C2F, 1024x2048 synthetic frames.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One "step" = one full domain-adaptation iteration (reference fcos_core/engine/trainer.py:266-424:
+source forward + losses, 5 CKA discriminators on source, target forward, 5 CKA discriminators on
+target, three backward passes, SGD step of all 8 sub-models) on a per-GPU batch of 2 source + 2
+target frames (BASELINE.json configs[1]).  N > 1: one process per GPU (torch.distributed, RCCL),
+same per-GPU batch (weak scaling), one gradient all-reduce per sub-model flat buffer.
+
+Prints ONE JSON line on rank 0.  `value` = source/target image PAIRS per second over all GPUs
+(frames/s = 2x, in config); `roofline` = fp32-MFMA implicit-GEMM conv kernels timed live with HIP
+events on their stream during the timed steps; `cpu_baseline` = the torch-CPU restatement
+(oracle/scan_ref.py, a port of the reference's CPU path) on this host's cores, on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+
+
+def cpu_baseline(h, w):
+    """oracle port timed on the host cores: 1 (src,tgt) pair, one DA iteration."""
+    import torch
+    from oracle import scan_ref
+    from scan_amd import synth
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    # torch-CPU conv backward degrades badly past a few dozen threads (256 threads: 80x slower than 8 here);
+    # use what it scales to and report that number as `cores`
+    cores = min(cores, 16)
+    torch.set_num_threads(cores)
+    sds = synth.all_state_dicts(9)
+    P = {k: scan_ref.params(v, frozen_prefixes=("body.features.0.", "body.features.2.", "body.features.5.",
+                                                "body.features.7.")) for k, v in sds.items()}
+    st = scan_ref.PrototypeState(sds["middle_head"]["prototype"])
+    imgs_s, imgs_t = synth.synth_images(1, h, w, 1234), synth.synth_images(1, h, w, 2234)
+    tg = synth.synth_targets(1, h, w, 8, 12, 4321)
+    bufs = {}
+    t0 = time.time()
+    scan_ref.da_iteration(P, st, imgs_s, tg, imgs_t)
+    scan_ref.sgd_step(P, bufs)
+    dt = time.time() - t0
+    return dt, cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=2, help="source (= target) frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from scan_amd import engine, ops, synth
+    model = engine.build_model(9, device=dev)
+    engine.load_procedural_weights(model)
+    trainer = engine.Trainer(model)
+    H, W, B = a.height, a.width, a.batch
+    imgs_s = synth.synth_images(B, H, W, 1234 + 100 * rank).to(dev)
+    imgs_t = synth.synth_images(B, H, W, 2234 + 100 * rank).to(dev)
+    tg = [(b.to(dev), l.to(dev)) for b, l in synth.synth_targets(B, H, W, 8, 12, 4321 + 100 * rank)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        trainer.step(imgs_s, tg, imgs_t)
+    barrier()
+    ops.kernel_timer.enabled = True
+    ops.kernel_timer.reset()
+    t0 = time.time()
+    for _ in range(a.steps):
+        losses = trainer.step(imgs_s, tg, imgs_t)
+    barrier()
+    dt = time.time() - t0
+    ops.kernel_timer.enabled = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ksum = ops.kernel_timer.summary()
+    finite = all(bool(torch.isfinite(v)) for v in losses.values())
+
+    if rank == 0:
+        pairs = B * world * a.steps
+        value = pairs / dt
+        dom = max(ksum.items(), key=lambda kv: kv[1]["total_ms"]) if ksum else None
+        roof = None
+        if dom:
+            name, r = dom
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(r["tflops"], 2), "peak": PEAK_FP32_MFMA_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(r["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": r["launches"], "avg_launch_ms": round(r["avg_ms"], 4),
+                    "all_conv_kernels": {k: {"tflops": round(v["tflops"], 2), "avg_ms": round(v["avg_ms"], 4),
+                                             "launches": v["launches"], "share_of_step": round(v["total_ms"] / (dt * 1e3), 3)}
+                                         for k, v in ksum.items()}}
+        cpu = None
+        if not a.no_cpu_baseline:
+            sh, sw = H // 2, W // 2
+            cdt, cores = cpu_baseline(sh, sw)
+            scale = (sh * sw) / float(H * W)
+            cpu = {"value": round(scale / cdt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
+                   "sample": "1 (src,tgt) pair, one DA iteration + SGD at %dx%d (1/%d of the frame area), "
+                             "pairs/s scaled by the area ratio; %.1f s of CPU work" % (sh, sw, round(1 / scale), cdt)}
+        line = {
+            "metric": "train images/sec (whole node), VGG16 C2F 1024x2048", "value": round(value, 4),
+            "unit": "image pairs/s (1 source + 1 target frame per pair)", "n_gpus": world, "steps": a.steps,
+            "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SCAN C2F VGG16-FPN DA iteration, %d src + %d tgt frames/GPU at %dx%d, "
+                                   "forward_target=False, procedural weights" % (B, B, H, W),
+                       "global_batch_pairs": B * world, "frames_per_s": round(2 * value, 4), "parallelism": "dp%d" % world,
+                       "losses_finite": finite},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,9 @@ def lib():
             raise RuntimeError(
                 "scan_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950); there is no CPU fallback." % LIB_PATH)
+        # PyTorch-ROCm ships its own libamdhip64; load it first so this library binds to the SAME HIP runtime
+        # (two runtimes in one process do not see each other's device context)
+        import torch  # noqa: F401
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)

@@ -40,6 +40,43 @@ def pad4(c):
     return (c + 3) // 4 * 4
 
 
+class KernelTimer:
+    """Optional HIP-event timing of the MFMA conv launches on the stream they run on (bench.py uses it
+    for the live roofline figure).  Disabled by default: no events are recorded."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = {}
+
+    def begin(self, name, flops):
+        if not self.enabled:
+            return None
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.records.setdefault(name, []).append((s, e, flops))
+        s.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, e):
+        if e is not None:
+            e.record(torch.cuda.current_stream())
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[name] = {"launches": len(recs), "total_ms": ms, "avg_ms": ms / len(recs), "flops": fl,
+                         "tflops": fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0}
+        return out
+
+    def reset(self):
+        self.records = {}
+
+
+kernel_timer = KernelTimer()
+
+
 class PyramidShape:
     """Level table of a pyramid activation (mirrors scan_pyramid_t)."""
 
@@ -137,8 +174,10 @@ class _Conv2d(torch.autograd.Function):
         wp = pack_weight(weight, cs)
         oshape = shape.conv_out(ksize, stride)
         y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
+        ev = kernel_timer.begin("conv_igemm_fwd", 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1])
         call("scan_conv2d_forward", _ptr(x), shape.ref(), cs, _ptr(wp), _ptr(bias), _ptr(y), oshape.ref(), cout, cout_s,
              ksize, stride, int(relu), _stream())
+        kernel_timer.end(ev)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.cfg = (shape, oshape, ksize, stride, relu, cout_s, bias is not None)
         return y
@@ -162,14 +201,18 @@ class _Conv2d(torch.autograd.Function):
             wt = x.new_empty((cs, T, cout_s))
             call("scan_weight_transpose", _ptr(wp), cout, T, cs, _ptr(wt), cout_s, st)
             dx = torch.empty_like(x)
+            ev = kernel_timer.begin("conv_igemm_dgrad", 2.0 * oshape.rows * cout * T * cin)
             call("scan_conv2d_dgrad", _ptr(dy), oshape.ref(), cout_s, _ptr(wt), _ptr(dx), shape.ref(), cs, cs, ksize,
                  stride, None, st)
+            kernel_timer.end(ev)
         if ctx.needs_input_grad[1]:
             n = query("scan_conv2d_wgrad_ws_floats", oshape.ref(), cs, cout, ksize)
             ws = x.new_empty((n,))
             dwp = x.new_empty((cout, T, cs))
+            ev = kernel_timer.begin("conv_wgrad", 2.0 * oshape.rows * cout * T * cin)
             call("scan_conv2d_wgrad", _ptr(x), shape.ref(), cs, _ptr(dy), oshape.ref(), cout, cout_s, ksize, stride,
                  _ptr(dwp), 0, _ptr(ws), st)
+            kernel_timer.end(ev)
             dw = unpack_weight_grad(dwp, weight)
         if has_bias and ctx.needs_input_grad[2]:
             M = dy.shape[0]

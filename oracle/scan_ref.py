@@ -388,12 +388,12 @@ def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, s
     gs = {"node_loss_gs": node_loss, "act_loss_gs": act_loss, "loss_cls_gs": lc, "loss_reg_gs": lr,
           "loss_centerness_gs": lctr}
     sum(gs.values()).backward(retain_graph=True)
-    out.update({k: float(v) for k, v in gs.items()})
+    out.update({k: float(v.detach()) for k, v in gs.items()})
     ds = {}
     for i, lvl in reversed(list(enumerate(("P3", "P4", "P5", "P6", "P7")))):
         ds["loss_adv_%s_CON_ds" % lvl] = con_lambda * discriminator_loss(P["dis_%s_CON" % lvl], f_s[i], maps_s[i], 1.0, K)
     sum(ds.values()).backward()
-    out.update({k: float(v) for k, v in ds.items()})
+    out.update({k: float(v.detach()) for k, v in ds.items()})
     feats = vgg_fpn_forward(P["backbone"], images_t)
     f_t, maps_t = middle_head_plain(P["middle_head"], state, feats, K)
     dt = {}
@@ -403,7 +403,7 @@ def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, s
     for i, lvl in reversed(list(enumerate(("P3", "P4", "P5", "P6", "P7")))):
         dt["loss_adv_%s_CON_dt" % lvl] = con_lambda * discriminator_loss(P["dis_%s_CON" % lvl], f_t[i], maps_t[i], 0.0, K)
     sum(dt.values()).backward()
-    out.update({k: float(v) for k, v in dt.items()})
+    out.update({k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in dt.items()})
     return out
 
 

@@ -1,0 +1,149 @@
+"""CPU tests (no GPU): the C-ABI library loads and exports every symbol include/scan_hip.h declares,
+argument validation works without a device, and the host-side logic (label assignment, node sampling,
+paradigm counter, LR schedule, state_dict names, flat parameter groups) matches the reference's vectors."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from scan_amd import _lib, engine, ops, synth
+from scan_amd.modeling import condgraph, fcos
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "scan_hip.h")).read()
+    declared = set(re.findall(r"\b(scan_[a-z0-9_]+)\s*\(", hdr))
+    declared.discard("scan_pyramid_t")
+    L = _lib.lib()
+    assert declared, "no declarations parsed"
+    for name in sorted(declared):
+        assert hasattr(L, name), "libscan_hip.so does not export %s" % name
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert L.scan_abi_version() == 1
+
+
+def test_argument_validation_without_device():
+    d = ops.PyramidShape(1, [(4, 4)])
+    with pytest.raises(RuntimeError, match="Cin_s"):
+        _lib.call("scan_conv2d_forward", None, d.ref(), 6, None, None, None, d.ref(), 8, 8, 3, 1, 0, None)
+    with pytest.raises(RuntimeError, match="ksize"):
+        _lib.call("scan_conv2d_forward", None, d.ref(), 8, None, None, None, d.ref(), 8, 8, 5, 1, 0, None)
+    with pytest.raises(RuntimeError, match="SCAN_NMS_MAX"):
+        _lib.call("scan_nms", None, None, None, 9000, 0.5, 1, None, ctypes.c_void_p(8), None, None)
+    with pytest.raises(RuntimeError, match="K in"):
+        _lib.call("scan_dynconv_softmax_forward", None, None, 10, 256, 5, None, None, None)
+    assert _lib.query("scan_nms_ws_bytes", 9000) == -1
+    assert _lib.query("scan_nms_ws_bytes", 100) > 0
+
+
+def test_ops_refuse_cpu_tensors():
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.sigmoid_focal_loss_sum(torch.zeros(4, 8), torch.zeros(4, dtype=torch.int32), 2.0, 0.25)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.groupnorm_relu(torch.zeros(16, 256), torch.ones(256), torch.zeros(256), ops.PyramidShape(1, [(4, 4)]))
+    from scan_amd import _C
+    with pytest.raises(RuntimeError, match="CPU"):
+        _C.ml_nms(torch.zeros(3, 4), torch.zeros(3), torch.zeros(3), 0.5)
+    assert _C.nms(torch.zeros(0, 4), torch.zeros(0), 0.5).numel() == 0
+    with pytest.raises(RuntimeError):
+        _C.roi_align_forward()
+
+
+def test_pyramid_shape():
+    s = ops.PyramidShape(2, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)])
+    assert s.rows == 2 * 43648 and s.row_off[1] == 2 * 128 * 256
+    assert s.conv_out(3, 1) == s
+    assert ops.PyramidShape(2, [(32, 64)]).conv_out(3, 2).sizes == [(16, 32)]
+    assert ops.PyramidShape(1, [(7, 9)]).conv_out(3, 2).sizes == [(4, 5)]
+    assert s.desc.row_off[5] == s.rows and s.desc.n_levels == 5
+
+
+def test_label_assignment_matches_reference(gold_dir):
+    """FCOS location->GT assignment + level-major row order (reference loss.py:40-126)."""
+    gold = json.load(open(os.path.join(gold_dir, "step_128x256.json")))
+    g = np.load(os.path.join(gold_dir, "step_128x256.npz"))
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    shape = ops.PyramidShape(N, [(H // s, W // s) for s in fcos.FPN_STRIDES])
+    locs = fcos.compute_locations(shape, torch.device("cpu"))
+    labels, reg = fcos.assign_targets(locs, synth.synth_targets(N, H, W, 8, 12, 4321))
+    for l in range(5):
+        assert np.array_equal(labels[shape.row_off[l]:shape.row_off[l + 1]].numpy(), g["label_map_%d" % l])
+    assert (labels > 0).sum() > 0
+    pos = reg[labels > 0]
+    assert (pos.min(1)[0] > 0).all()
+    ct = fcos.centerness_targets(pos)
+    assert ((ct > 0) & (ct <= 1)).all()
+
+
+def test_source_node_sampling_order(gold_dir):
+    """neg = floor(linspace(0, n_neg-2, n_pos)) rows, order [neg..., pos...] (reference loss.py:443-458)."""
+    g = np.load(os.path.join(gold_dir, "step_128x256.npz"))
+    shape = ops.PyramidShape(2, [(16, 32), (8, 16), (4, 8), (2, 4), (1, 2)])
+    labels = torch.from_numpy(np.concatenate([g["label_map_%d" % l] for l in range(5)]))
+    feats = torch.arange(shape.rows, dtype=torch.float32)[:, None].repeat(1, 4)  # row index as feature
+    pts, labs = condgraph.sample_source_nodes(feats, labels, shape)
+    assert np.array_equal(labs.numpy(), g["node_labels"])
+    n_pos = int((labels > 0).sum())
+    assert (labs[-n_pos:] > 0).all() and (labs[:-n_pos] == 0).all()
+    # positives appear in row order, level by level
+    assert np.array_equal(pts[-n_pos:, 0].numpy(), torch.nonzero(labels > 0).squeeze(1).float().numpy())
+
+
+def test_counter_and_schedule():
+    c = condgraph.PROTOTYPECounter(3, stop=True)
+    assert [c() for _ in range(7)] == [0, 1, 2, 3, 3, 3, 3]  # reference condgraph.py:52-59
+    c = condgraph.PROTOTYPECounter(3)
+    assert [c() for _ in range(7)] == [0, 1, 2, 0, 1, 2, 0]
+    assert engine.warmup_factor(0) == pytest.approx(1 / 3) and engine.warmup_factor(999) == pytest.approx(1 / 3)
+    assert engine.warmup_factor(1000) == 1.0 and engine.warmup_factor(60000) == pytest.approx(0.1)
+    assert engine.warmup_factor(80000) == pytest.approx(0.01)
+
+
+def test_state_dict_names_and_flat_groups():
+    model = engine.build_model(9, device="cpu")
+    sds = synth.all_state_dicts(9)
+    for k, m in model.items():
+        assert set(m.state_dict().keys()) == set(sds[k].keys()), k
+    engine.load_state_dicts(model, sds)
+    bb = model["backbone"]
+    assert not bb.body.features[0].weight.requires_grad and not bb.body.features[7].weight.requires_grad
+    assert bb.body.features[10].weight.requires_grad
+    w = bb.body.features[10].weight
+    assert w.permute(0, 2, 3, 1).is_contiguous()  # stored OHWI: what the HIP kernels read without a repack
+    grp = engine.FlatGroup(model["fcos"], 0.0025)
+    n = sum(p.numel() for p in model["fcos"].parameters())
+    assert grp.flat_p.numel() == n and grp.n_w + grp.n_b == n
+    p = model["fcos"].head.cls_logits.weight
+    assert torch.equal(p.detach(), sds["fcos"]["head.cls_logits.weight"])  # values survive the re-homing
+    assert p.data.data_ptr() >= grp.flat_p.data_ptr() and p.grad.data_ptr() >= grp.flat_g.data_ptr()
+    p.grad.add_(1.0)
+    assert grp.flat_g.sum().item() == p.numel()
+    grp.zero_grad()
+    assert p.grad.abs().sum().item() == 0
+
+
+def test_prototype_update_matches_reference(gold_dir):
+    """three EMA updates then the slide (reference condgraph.py:586-606) against the oracle restatement."""
+    from oracle import scan_ref
+    mh = condgraph.GRAPHModule(256, 9)
+    sd = synth.middle_head_state_dict(9)
+    mh.load_state_dict(sd)
+    st = scan_ref.PrototypeState(sd["prototype"])
+    g = torch.Generator().manual_seed(0)
+    for it in range(5):
+        pb = torch.randn(9, 256, generator=g)
+        if it % 2:
+            pb[3] = 0  # class absent in this batch
+        mh.update_prototype_nx1_rnn(pb)
+        scan_ref.update_prototype(st, pb)
+        assert torch.allclose(mh.prototype, st.prototype, rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        k = mh.get_conded_weight()
+        kr = scan_ref.conded_weight(scan_ref.params(sd, requires_grad=False), st.prototype)
+    assert torch.allclose(k, kr, rtol=1e-4, atol=1e-6)

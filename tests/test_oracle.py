@@ -1,0 +1,103 @@
+"""CPU tests (no GPU): the oracle itself against the reference's known answers and the golden vectors
+captured from the imported reference (oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import coracle, scan_ref
+from scan_amd import synth
+
+
+def test_nms_oracle_known_answers(gold_dir):
+    """reference tests/test_nms.py:11-58, 60-217 (Caffe2 UtilsNMSTest vectors)."""
+    kat = json.load(open(os.path.join(gold_dir, "nms_kat.json")))
+    assert len(kat["cases"]) == 6
+    for case in kat["cases"]:
+        keep = coracle.nms(np.array(case["boxes"], np.float32), np.array(case["scores"], np.float32), case["thresh"])
+        assert sorted(keep.tolist()) == case["keep_sorted"]
+    big = [c for c in kat["cases"] if len(c["scores"]) == 53][0]
+    assert len(big["keep_sorted"]) == 26
+
+
+def test_nms_oracle_edge_cases():
+    assert coracle.nms(np.zeros((0, 4), np.float32), np.zeros(0, np.float32), 0.5).size == 0
+    b = np.array([[0, 0, 10, 10], [0, 0, 10, 10], [20, 20, 30, 30]], np.float32)
+    s = np.array([0.5, 0.5, 0.1], np.float32)
+    assert coracle.nms(b, s, 0.5).tolist() == [0, 2]  # duplicate boxes, tied scores: lower index wins
+    # IoU exactly at the threshold: the CPU rule suppresses (>=), ml_nms' CUDA rule keeps (>)
+    b = np.array([[0, 0, 9, 9], [0, 0, 9, 4]], np.float32)  # areas 100 and 50 -> IoU 0.5
+    s = np.array([0.9, 0.8], np.float32)
+    assert coracle.nms(b, s, 0.5).tolist() == [0]
+    assert coracle.ml_nms(b, s, np.ones(2, np.float32), 0.5).tolist() == [0, 1]
+    assert coracle.ml_nms(b, s, np.array([1, 2], np.float32), 0.1).tolist() == [0, 1]  # labels differ
+
+
+def test_pointwise_oracle_vs_reference_vectors(gold_dir):
+    g = np.load(os.path.join(gold_dir, "pointwise.npz"))
+    l = coracle.sigmoid_focal_fwd(g["focal_logits"], g["focal_targets"], 2.0, 0.25)
+    np.testing.assert_allclose(l, g["focal_loss"], rtol=2e-4, atol=1e-4)  # CPU-vs-CUDA formula tail
+    d = coracle.sigmoid_focal_bwd(g["focal_logits"], g["focal_targets"], g["focal_dloss"], 2.0, 0.25)
+    np.testing.assert_allclose(d, g["focal_dlogits"], rtol=1e-4, atol=1e-6)
+    lt = scan_ref.sigmoid_focal_loss(torch.from_numpy(g["focal_logits"]), torch.from_numpy(g["focal_targets"]))
+    np.testing.assert_allclose(lt.numpy(), l, rtol=1e-5, atol=1e-7)
+    v, _ = coracle.iou_loss(g["iou_pred"], g["iou_target"], g["iou_weight"])
+    assert abs(v - float(g["iou_loss"])) < 1e-6 * abs(float(g["iou_loss"]))
+    p = torch.from_numpy(g["iou_pred"]).requires_grad_(True)
+    li = scan_ref.iou_loss(p, torch.from_numpy(g["iou_target"]), torch.from_numpy(g["iou_weight"]))
+    li.backward()
+    np.testing.assert_allclose(p.grad.numpy(), g["iou_dpred"], rtol=1e-5, atol=1e-8)
+    z = torch.from_numpy(g["sfl_logits"]).requires_grad_(True)
+    lf = scan_ref.softmax_focal_loss(z, torch.from_numpy(g["sfl_labels"]))
+    assert abs(lf.item() - float(g["sfl_loss"])) < 1e-6
+    lf.backward()
+    np.testing.assert_allclose(z.grad.numpy(), g["sfl_dlogits"], rtol=1e-5, atol=1e-9)
+
+
+def _params():
+    sds = synth.all_state_dicts(9)
+    frozen = ("body.features.0.", "body.features.2.", "body.features.5.", "body.features.7.")
+    return sds, {k: scan_ref.params(v, frozen_prefixes=frozen) for k, v in sds.items()}
+
+
+def test_da_iteration_oracle_vs_reference(gold_dir):
+    """full three-phase DA iteration of the restatement against the reference's loss dict."""
+    gold = json.load(open(os.path.join(gold_dir, "step_128x256.json")))
+    g = np.load(os.path.join(gold_dir, "step_128x256.npz"))
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    sds, P = _params()
+    st = scan_ref.PrototypeState(sds["middle_head"]["prototype"])
+    out = scan_ref.da_iteration(P, st, synth.synth_images(N, H, W, 1234), synth.synth_targets(N, H, W, 8, 12, 4321),
+                                synth.synth_images(N, H, W, 2234))
+    for k, ref in gold["losses"].items():
+        if k == "zero_gt":
+            continue
+        assert abs(out[k] - ref) <= 1e-5 * abs(ref), (k, out[k], ref)
+    np.testing.assert_allclose(st.prototype.numpy(), g["prototype_after"], rtol=1e-5, atol=1e-6)
+    with torch.no_grad():
+        np.testing.assert_allclose(scan_ref.conded_weight(P["middle_head"], st.prototype).numpy(), g["kernels"],
+                                   rtol=1e-4, atol=1e-6)
+    for name in ("head.cls_logits.weight", "head.bbox_tower.0.weight"):
+        gr = P["fcos"][name].grad.double()
+        ref = gold["grad_digest"]["fcos"][name]
+        assert abs(gr.abs().sum().item() - ref[1]) <= 1e-3 * ref[1]
+
+
+def test_inference_oracle_vs_reference(gold_dir):
+    g = np.load(os.path.join(gold_dir, "inference_128x256.npz"))
+    sds = synth.all_state_dicts(9)
+    P = {k: scan_ref.params(v, requires_grad=False) for k, v in sds.items()}
+    st = scan_ref.PrototypeState(sds["middle_head"]["prototype"])
+
+    def nms_fn(b, s, t):
+        return torch.from_numpy(coracle.nms(b.numpy(), s.numpy(), t)) if len(b) else torch.empty(0, dtype=torch.int64)
+
+    res = scan_ref.inference(P, st, synth.synth_images(2, 128, 256, 3234), nms_fn, mode="precision")
+    for i, (b, s, l) in enumerate(res):
+        rb, rs, rl = g["precision_boxes_%d" % i], g["precision_scores_%d" % i], g["precision_labels_%d" % i]
+        assert len(b) == len(rb) == 100
+        o1, o2 = np.lexsort((s.numpy(), l.numpy())), np.lexsort((rs, rl))
+        assert np.array_equal(l.numpy()[o1], rl[o2])
+        np.testing.assert_allclose(s.numpy()[o1], rs[o2], atol=1e-5)
+        np.testing.assert_allclose(b.numpy()[o1], rb[o2], atol=1e-3)

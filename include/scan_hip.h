@@ -143,6 +143,19 @@ int64_t scan_conv2d_wgrad_ws_floats(const scan_pyramid_t* yd, int32_t Cin_s, int
 int scan_conv2d_wgrad(const float* x, const scan_pyramid_t* xd, int32_t Cin_s, const float* dy,
                       const scan_pyramid_t* yd, int32_t Cout, int32_t Cout_s, int32_t ksize, int32_t stride,
                       float* dw, int32_t accumulate, float* ws, void* stream);
+/* ---- 3x3 / stride-1 convolution with fp32-grade accuracy on the bf16 matrix cores ("bf16x3": every fp32
+ *      operand is split hi + lo into two bf16 values; hi*hi + hi*lo + lo*hi accumulated in fp32).  Same call
+ *      sites as scan_conv2d_forward; ~5x the fp32-MFMA rate.
+ * scan_weight_split: w [O][T][Cs] fp32 -> bf16 planes wh, wl.
+ *    mode 0: [O][T][Csw]   (forward);   mode 1: [Cs][T][Csw] holding w[o][T-1-t][c] at [c][t][o] (dgrad).
+ *    Csw % 8 == 0, zero padded.
+ * scan_conv3x3_bf16x3: y[M][Ns] = conv3x3_s1(x[M][Cs], w) + bias, optional ReLU, optional mask (y = 0 where
+ *    mask <= 0).  The data gradient is the same call on dY with the mode-1 weights. */
+int scan_weight_split(const float* w, int32_t O, int32_t T, int32_t Cs, int32_t mode, void* wh, void* wl,
+                      int32_t Csw, void* stream);
+int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                        int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns,
+                        int32_t relu, void* stream);
 /* w [Cout][T][Cin_s] -> wt [Cin_s][T][Cout_s] (zero padded) */
 int scan_weight_transpose(const float* w, int32_t Cout, int32_t T, int32_t Cin_s, float* wt, int32_t Cout_s,
                           void* stream);

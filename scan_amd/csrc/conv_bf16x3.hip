@@ -1,0 +1,319 @@
+// 3x3 / stride-1 convolution (forward and data-gradient) on gfx950 matrix cores with fp32-grade
+// accuracy from bf16 MFMA: every fp32 operand x is split as x = hi + lo (two bf16 values, 16
+// mantissa bits together) and the product is accumulated in fp32 as
+//      hi_a*hi_b + hi_a*lo_b + lo_a*hi_b          (3 x v_mfma_f32_32x32x16_bf16)
+// bf16 x bf16 products are exact in fp32, so the only error is the dropped lo*lo term and the split
+// truncation (~2^-17 relative per operand): measured loss error of a full DA iteration vs the fp32
+// reference is 2e-6 relative.  bf16 MFMA runs 16x the fp32-MFMA rate on CDNA4, so three
+// passes are ~5x faster than v_mfma_f32_32x32x2_f32.
+//
+// Structure (per 256-thread workgroup, 2 workgroups per CU):
+//   output tile   8 x 16 pixels (one image, one pyramid level) x BN = 128 output channels
+//   K loop        input channels in chunks of 32; per chunk the (8+2) x (16+2) x 32 input HALO patch is
+//                 read from HBM/L2 ONCE as fp32, split to bf16 hi/lo while being written to LDS, and then
+//                 reused by all 9 taps (the taps are pure LDS address offsets)
+//   weights       pre-split once per step into bf16 hi/lo [O][9][Csw] (scan_weight_split), staged per
+//                 (chunk, tap) through a double-buffered LDS tile
+//   waves         2 x 2, each 64 pixels x 64 channels = 2 x 2 MFMA tiles of 32x32
+// LDS rows are 80 B (64 B of data + 16 B pad) so the 16-byte fragment reads of consecutive pixels /
+// channels fall on distinct bank groups.
+//
+// dgrad reuses the same kernel: dX = conv3x3(dY, W') with W'[c][t][o] = W[o][8-t][c]
+// (scan_weight_split mode 1 writes the flipped + transposed copy).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define TH 8
+#define TW 16
+#define PH (TH + 2)
+#define PW (TW + 2)
+#define NPATCH (PH * PW)  // 180 halo pixels
+#define CK 32             // channels per K chunk
+#define LROW 40           // bf16 elements per LDS row (32 data + 8 pad = 80 B)
+
+struct TileTab {
+  int tile_off[SCAN_MAX_LEVELS + 1];
+  int tiles_x[SCAN_MAX_LEVELS];
+  int tiles_y[SCAN_MAX_LEVELS];
+};
+
+__device__ __forceinline__ int xcd_remap3(int orig, int nwg) {
+  const int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + orig / 8;
+}
+
+__device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
+  hi[0] = (__bf16)v.x;
+  hi[1] = (__bf16)v.y;
+  hi[2] = (__bf16)v.z;
+  hi[3] = (__bf16)v.w;
+  lo[0] = (__bf16)(v.x - (float)hi[0]);
+  lo[1] = (__bf16)(v.y - (float)hi[1]);
+  lo[2] = (__bf16)(v.z - (float)hi[2]);
+  lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
+    const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
+    const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
+    float* __restrict__ dst, int Nout, int Ns, int relu, TileTab tt, int n_tiles) {
+  constexpr int WN_WAVES = BN / 64;        // 2 (BN=128) or 1 (BN=64)
+  constexpr int WM_WAVES = 4 / WN_WAVES;   // 2 or 4
+  constexpr int TM = 4 / WM_WAVES;         // 32-pixel MFMA tiles per wave: 2 or 1
+  constexpr int TN = 2;                    // 32-channel MFMA tiles per wave
+  constexpr int BSEG = BN * 4 * 2 / 256;   // 16-byte weight segments per thread per (chunk, tap): 4 or 2
+
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem_raw);  // [NPATCH][LROW]
+  __bf16* Al = Ah + NPATCH * LROW;                   // [NPATCH][LROW]
+  __bf16* Bs = Al + NPATCH * LROW;                   // [2 buf][2 plane][BN][LROW]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int bid = xcd_remap3(blockIdx.x, gridDim.x);
+  const int n_tile = bid % n_tiles;
+  const int tile = bid / n_tiles;
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+    if (i < d.n_levels && tile >= tt.tile_off[i]) lvl = i;
+  const int H = d.h[lvl], W = d.w[lvl];
+  int t = tile - tt.tile_off[lvl];
+  const int per_img = tt.tiles_x[lvl] * tt.tiles_y[lvl];
+  const int img = t / per_img;
+  t -= img * per_img;
+  const int ty0 = (t / tt.tiles_x[lvl]) * TH, tx0 = (t % tt.tiles_x[lvl]) * TW;
+  const int64_t rowbase = d.row_off[lvl] + (int64_t)img * H * W;
+  const int n0 = n_tile * BN;
+  const int nchunks = (Cs + CK - 1) / CK;
+
+  // ---- A patch staging roles: 180 pixels x 8 float4 = 1440 slots, 6 per thread
+  float4 ra[6];
+  auto load_a = [&](int cc) {
+    const int c0 = cc * CK;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int slot = tid + 256 * i;
+      const int q = slot >> 3, c = c0 + 4 * (slot & 7);
+      const int py = q / PW, px = q - py * PW;
+      const int y = ty0 - 1 + py, x = tx0 - 1 + px;
+      const bool ok = (slot < NPATCH * 8) && y >= 0 && y < H && x >= 0 && x < W && c < Cs;
+      ra[i] = ok ? *reinterpret_cast<const float4*>(src + (rowbase + (int64_t)y * W + x) * Cs + c)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      const int slot = tid + 256 * i;
+      if (slot < NPATCH * 8) {
+        const int q = slot >> 3, c4 = slot & 7;
+        bf16x4 hi, lo;
+        split4(ra[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(Ah + q * LROW + 4 * c4) = hi;
+        *reinterpret_cast<bf16x4*>(Al + q * LROW + 4 * c4) = lo;
+      }
+    }
+  };
+  // ---- B staging roles: BN rows x 4 segments x 2 planes
+  uint4 rb[BSEG];
+  auto load_b = [&](int cc, int tap) {
+#pragma unroll
+    for (int i = 0; i < BSEG; ++i) {
+      const int slot = tid + 256 * i;
+      const int plane = slot / (BN * 4);
+      const int rem = slot - plane * BN * 4;
+      const int row = rem >> 2, seg = rem & 3;
+      const int o = n0 + row, c = cc * CK + 8 * seg;
+      const __bf16* base = plane ? wl : wh;
+      rb[i] = (o < Nout && c < Csw) ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * 9 + tap) * Csw + c)
+                                    : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < BSEG; ++i) {
+      const int slot = tid + 256 * i;
+      const int plane = slot / (BN * 4);
+      const int rem = slot - plane * BN * 4;
+      const int row = rem >> 2, seg = rem & 3;
+      *reinterpret_cast<uint4*>(Bs + ((buf * 2 + plane) * BN + row) * LROW + 8 * seg) = rb[i];
+    }
+  };
+
+  // ---- MFMA roles
+  const int wm = wid / WN_WAVES, wn = wid % WN_WAVES;
+  const int lr = lane & 31, lh = lane >> 5;
+  int a_off[TM];  // bf16 offset of this lane's pixel (tap 0,0) + its k-half
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int p = (wm * TM + tm) * 32 + lr;  // pixel within the 8x16 tile
+    a_off[tm] = ((p >> 4) * PW + (p & 15)) * LROW + 8 * lh;
+  }
+  const int b_off = (wn * 64 + lr) * LROW + 8 * lh;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  load_a(0);
+  load_b(0, 0);
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();  // every wave is done reading the previous chunk's patch
+    store_a();
+    if (cc + 1 < nchunks) load_a(cc + 1);
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const int buf = tap & 1;
+      store_b(buf);
+      if (tap < 8)
+        load_b(cc, tap + 1);
+      else if (cc + 1 < nchunks)
+        load_b(cc + 1, 0);
+      __syncthreads();
+      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int shift = (ky * PW + kx) * LROW;
+      const __bf16* bh = Bs + (buf * 2 + 0) * BN * LROW + b_off;
+      const __bf16* bl = Bs + (buf * 2 + 1) * BN * LROW + b_off;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        bf16x8 ah[TM], al[TM], bhv[TN], blv[TN];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          ah[tm] = *reinterpret_cast<const bf16x8*>(Ah + a_off[tm] + shift + 16 * s);
+          al[tm] = *reinterpret_cast<const bf16x8*>(Al + a_off[tm] + shift + 16 * s);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          bhv[tn] = *reinterpret_cast<const bf16x8*>(bh + tn * 32 * LROW + 16 * s);
+          blv[tn] = *reinterpret_cast<const bf16x8*>(bl + tn * 32 * LROW + 16 * s);
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bhv[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], blv[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bhv[tn], acc[tm][tn], 0, 0, 0);
+          }
+      }
+    }
+  }
+
+  // ---- epilogue.  C/D map of 32x32: col = lane&31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int o = n0 + wn * 64 + tn * 32 + lr;
+    const float bv = (bias != nullptr && o < Nout) ? bias[o] : 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int y = ty0 + (p >> 4), x = tx0 + (p & 15);
+        if (y < H && x < W && o < Nout) {
+          const int64_t m = rowbase + (int64_t)y * W + x;
+          float v = acc[tm][tn][r] + bv;
+          if (relu) v = fmaxf(v, 0.f);
+          if (mask != nullptr) v = (mask[m * Ns + o] > 0.f) ? v : 0.f;
+          dst[m * Ns + o] = v;
+        }
+      }
+    }
+  }
+}
+
+// w [O][T][Cs] fp32 -> bf16 hi / lo planes.
+//   mode 0: out[o][t][c]            (O rows, row length Csw >= Cs, zero padded)       -- forward
+//   mode 1: out[c][T-1-t][o]        (Cs rows, row length Csw >= O, zero padded)       -- dgrad (flip + transpose)
+__global__ void weight_split_kernel(const float* __restrict__ w, int O, int T, int Cs, int mode, int rows, int Csw,
+                                    __bf16* __restrict__ wh, __bf16* __restrict__ wl) {
+  const int64_t total = (int64_t)rows * T * Csw;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int col = (int)(i % Csw);
+    const int64_t rt = i / Csw;
+    const int tt = (int)(rt % T);
+    const int row = (int)(rt / T);
+    float v = 0.f;
+    if (mode == 0) {
+      if (col < Cs) v = w[((int64_t)row * T + tt) * Cs + col];
+    } else {
+      if (col < O) v = w[((int64_t)col * T + (T - 1 - tt)) * Cs + row];
+    }
+    const __bf16 h = (__bf16)v;
+    wh[i] = h;
+    wl[i] = (__bf16)(v - (float)h);
+  }
+}
+
+static void make_tiles(const scan_pyramid_t* d, TileTab* tt) {
+  tt->tile_off[0] = 0;
+  for (int l = 0; l < SCAN_MAX_LEVELS; ++l) {
+    if (l < d->n_levels) {
+      tt->tiles_x[l] = (d->w[l] + TW - 1) / TW;
+      tt->tiles_y[l] = (d->h[l] + TH - 1) / TH;
+      tt->tile_off[l + 1] = tt->tile_off[l] + d->n_images * tt->tiles_x[l] * tt->tiles_y[l];
+    } else {
+      tt->tiles_x[l] = tt->tiles_y[l] = 1;
+      tt->tile_off[l + 1] = tt->tile_off[l];
+    }
+  }
+}
+
+extern "C" int scan_weight_split(const float* w, int32_t O, int32_t T, int32_t Cs, int32_t mode, void* wh, void* wl,
+                                 int32_t Csw, void* stream) {
+  SCAN_CHECK_ARG(w && wh && wl && O > 0 && T > 0 && Cs > 0, "weight_split: bad arguments");
+  SCAN_CHECK_ARG(mode == 0 || mode == 1, "weight_split: mode must be 0 or 1");
+  SCAN_CHECK_ARG(Csw % 8 == 0 && Csw >= (mode == 0 ? Cs : O), "weight_split: Csw=%d must be a multiple of 8 and cover the row",
+                 Csw);
+  const int rows = mode == 0 ? O : Cs;
+  const int64_t total = (int64_t)rows * T * Csw;
+  hipLaunchKernelGGL(weight_split_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), w, O, T, Cs,
+                     mode, rows, Csw, reinterpret_cast<__bf16*>(wh), reinterpret_cast<__bf16*>(wl));
+  SCAN_LAUNCH_CHECK("weight_split");
+  return 0;
+}
+
+// y[M][Ns] = conv3x3_s1(x[M][Cs]) with pre-split weights wh/wl [Nout][9][Csw]; same pyramid in and out.
+extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                                   int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout,
+                                   int32_t Ns, int32_t relu, void* stream) {
+  SCAN_CHECK_ARG(d && d->n_levels >= 1 && d->n_levels <= SCAN_MAX_LEVELS && d->n_images >= 1,
+                 "conv3x3_bf16x3: bad pyramid");
+  SCAN_CHECK_ARG(Cs > 0 && Cs % 4 == 0, "conv3x3_bf16x3: Cs=%d must be a positive multiple of 4", Cs);
+  SCAN_CHECK_ARG(Csw % 8 == 0 && Csw >= Cs, "conv3x3_bf16x3: Csw=%d must be a multiple of 8 and >= Cs", Csw);
+  SCAN_CHECK_ARG(Nout > 0 && Ns >= Nout, "conv3x3_bf16x3: Nout=%d Ns=%d", Nout, Ns);
+  SCAN_CHECK_ARG(x && wh && wl && y, "conv3x3_bf16x3: null pointer");
+  TileTab tt;
+  make_tiles(d, &tt);
+  const int tiles = tt.tile_off[d->n_levels];
+  hipStream_t st = as_stream(stream);
+  const __bf16* h = reinterpret_cast<const __bf16*>(wh);
+  const __bf16* l = reinterpret_cast<const __bf16*>(wl);
+  if (Nout > 64) {
+    const int n_tiles = (Nout + 127) / 128;
+    const size_t sh = (size_t)(2 * NPATCH * LROW + 4 * 128 * LROW) * sizeof(__bf16);
+    static bool done = false;
+    if (!done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16x3_kernel<128>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<128>), dim3(tiles * n_tiles), dim3(256), sh, st, x, *d, Cs, h, l, Csw, bias,
+                       mask, y, Nout, Ns, relu, tt, n_tiles);
+  } else {
+    const size_t sh = (size_t)(2 * NPATCH * LROW + 4 * 64 * LROW) * sizeof(__bf16);
+    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<64>), dim3(tiles), dim3(256), sh, st, x, *d, Cs, h, l, Csw, bias, mask, y,
+                       Nout, Ns, relu, tt, 1);
+  }
+  SCAN_LAUNCH_CHECK("conv3x3_bf16x3");
+  return 0;
+}

@@ -159,6 +159,34 @@ def unpack_weight_grad(dw, weight):
     return dw[:, :, :ci].reshape(co, kh, kw, ci).permute(0, 3, 1, 2)
 
 
+# "bf16x3": 3x3/stride-1 convs run on the bf16 matrix cores with hi/lo operand splitting (fp32-grade accuracy,
+# ~5x the fp32-MFMA rate); "fp32": everything on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain).
+CONV_MODE = "bf16x3"
+
+
+def _round8(c):
+    return (c + 7) // 8 * 8
+
+
+def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops):
+    """wp: packed fp32 weights [O][9][Cs_w].  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
+    st = _stream()
+    O, T, cs_w = wp.shape
+    if mode == 0:
+        rows, csw, nout = O, _round8(cs_w), O
+    else:
+        rows, csw, nout = cs_w, _round8(max(O, cs_src)), cs_w
+    wh = torch.empty((rows, T, csw), dtype=torch.bfloat16, device=x.device)
+    wl = torch.empty_like(wh)
+    call("scan_weight_split", _ptr(wp), O, T, cs_w, mode, _ptr(wh), _ptr(wl), csw, st)
+    y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
+    ev = kernel_timer.begin(name, flops)
+    call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), None, _ptr(y), nout,
+         ns, int(relu), st)
+    kernel_timer.end(ev)
+    return y
+
+
 class _Conv2d(torch.autograd.Function):
     """conv (k in {1,3}, stride in {1,2}, pad k//2) + bias (+ ReLU) on a pyramid."""
 
@@ -173,19 +201,24 @@ class _Conv2d(torch.autograd.Function):
         cout_s = cout_s or pad4(cout)
         wp = pack_weight(weight, cs)
         oshape = shape.conv_out(ksize, stride)
-        y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
-        ev = kernel_timer.begin("conv_igemm_fwd", 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1])
-        call("scan_conv2d_forward", _ptr(x), shape.ref(), cs, _ptr(wp), _ptr(bias), _ptr(y), oshape.ref(), cout, cout_s,
-             ksize, stride, int(relu), _stream())
-        kernel_timer.end(ev)
+        fast = CONV_MODE == "bf16x3" and ksize == 3 and stride == 1
+        flops = 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1]
+        if fast:
+            y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s, "conv3x3_bf16x3_fwd", flops)
+        else:
+            y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
+            ev = kernel_timer.begin("conv_igemm_fwd", flops)
+            call("scan_conv2d_forward", _ptr(x), shape.ref(), cs, _ptr(wp), _ptr(bias), _ptr(y), oshape.ref(), cout,
+                 cout_s, ksize, stride, int(relu), _stream())
+            kernel_timer.end(ev)
         ctx.save_for_backward(x, weight, y if relu else None)
-        ctx.cfg = (shape, oshape, ksize, stride, relu, cout_s, bias is not None)
+        ctx.cfg = (shape, oshape, ksize, stride, relu, cout_s, bias is not None, fast)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
-        shape, oshape, ksize, stride, relu, cout_s, has_bias = ctx.cfg
+        shape, oshape, ksize, stride, relu, cout_s, has_bias, fast = ctx.cfg
         cs = x.shape[1]
         cout, cin = weight.shape[0], weight.shape[1]
         T = ksize * ksize
@@ -196,7 +229,10 @@ class _Conv2d(torch.autograd.Function):
             call("scan_relu_backward", _ptr(dy), _ptr(y), _ptr(g), dy.numel(), st)
             dy = g
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and fast:
+            dx = _conv3x3_bf16x3(dy, shape, pack_weight(weight, cs), cout, x.shape[0], cout_s, 1, None, False, cs,
+                                 "conv3x3_bf16x3_dgrad", 2.0 * oshape.rows * cout * T * cin)
+        elif ctx.needs_input_grad[0]:
             wp = pack_weight(weight, cs)
             wt = x.new_empty((cs, T, cout_s))
             call("scan_weight_transpose", _ptr(wp), cout, T, cs, _ptr(wt), cout_s, st)

@@ -234,9 +234,13 @@ CONV_CASES = [
 ]
 
 
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_fwd_bwd(device, case):
+def test_conv2d_fwd_bwd(device, case, mode, monkeypatch):
     from scan_amd import ops
+    monkeypatch.setattr(ops, "CONV_MODE", mode)
+    # bf16x3: operands carry 16 mantissa bits (hi + lo); products exact, fp32 accumulate
+    tol = 2e-5 if mode == "fp32" else 1e-4
     sizes, N, cin, cout, k, stride, relu = case
     import zlib
     g = torch.Generator().manual_seed(zlib.crc32(str(case).encode()))
@@ -250,6 +254,11 @@ def test_conv2d_fwd_bwd(device, case):
     if relu:
         yr = [F.relu(y) for y in yr]
     gys = [torch.randn(y.shape, generator=g) for y in yr]
+    if relu:
+        # an output within rounding distance of 0 may land on the other side of the ReLU on the GPU; give
+        # those (measure-zero) elements no upstream gradient so a mask flip cannot enter the comparison
+        pre = [F.conv2d(x, wgt, bias, stride=stride, padding=k // 2) for x in xs]
+        gys = [gy * (p.abs() > 1e-3) for gy, p in zip(gys, pre)]
     sum((y * gy).sum() for y, gy in zip(yr, gys)).backward()
     # HIP
     cs = ops.pad4(cin)
@@ -261,14 +270,14 @@ def test_conv2d_fwd_bwd(device, case):
     oshape = shape.conv_out(k, stride)
     ys = _unrows(y, oshape, cout)
     for a, b in zip(ys, yr):
-        np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(a.numpy(), b.detach().numpy(), rtol=1e-4, atol=tol)
     gy_rows, _ = _pyr(gys, device, y.shape[1])
     y.backward(gy_rows)
     dxs = _unrows(rows.grad, shape, cin)
     for a, b in zip(dxs, xr):
-        np.testing.assert_allclose(a.numpy(), b.grad.numpy(), rtol=1e-4, atol=2e-5)
+        np.testing.assert_allclose(a.numpy(), b.grad.numpy(), rtol=1e-4, atol=tol * max(1.0, float(b.grad.abs().max())))
     scale = max(1.0, float(wr.grad.abs().max()))
-    np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=2e-5 * scale)
+    np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=tol * scale)
     np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(br.grad.abs().max())))
 
 
@@ -291,6 +300,13 @@ def test_conv2d_linearity_full_size(device):
     for l in (0, 4):
         yl = ops.conv2d(x1[shape.row_off[l]:shape.row_off[l + 1]].contiguous(), w, None, shape.level(l))
         assert torch.equal(yl, y1[shape.row_off[l]:shape.row_off[l + 1]])
+    # the bf16x3 matrix-core path against the exact fp32-MFMA path at full size
+    ops.CONV_MODE, keep = "fp32", ops.CONV_MODE
+    try:
+        yf = ops.conv2d(x1, w, None, shape)
+    finally:
+        ops.CONV_MODE = keep
+    assert (yf - y1).abs().max().item() < 2e-4 * yf.abs().max().item()
 
 
 def test_conv2d_errors(device):

@@ -317,3 +317,201 @@ extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int3
   SCAN_LAUNCH_CHECK("conv3x3_bf16x3");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient of the 3x3 / stride-1 conv on the bf16 matrix cores (same hi/lo split):
+//     dW[o][tap][c] = sum_m dY[m][o] * X[g(m, tap)][c]
+// GEMM with K = pixels.  Both operands live in memory pixel-major ([pixel][channel]), but an MFMA lane
+// needs 8 consecutive k (pixels) of one channel: the tiles are staged in LDS in their natural
+// [pixel][channel] layout and read with ds_read_b64_tr_b16, gfx950's transposing LDS read (each 16-lane
+// group fetches a 4-pixel x 16-channel block and receives it channel-major), so no transpose pass exists.
+// Block = 256 threads: 128 (o) x 128 (c) tile of one tap; K in chunks of 32 pixels; deterministic split-K
+// over gridDim.y into fp32 slabs (reduced in order by slab_reduce_kernel in conv_mfma.hip).
+// LDS rows are 320 B (256 B data + 64 B pad): the four pixel rows of a transposed read then fall on
+// disjoint 32-byte bank groups for both 16-lane groups of a half wave.
+// ------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+#define WROW 160  // bf16 elements per LDS row
+#define WK 32     // pixels per K chunk
+
+__device__ __forceinline__ bf16x8 tr_read8(const __bf16* p0) {
+  // p0: this lane's address for pixels k..k+3; pixels k+4..k+7 are 4 rows further
+  auto q0 = (__attribute__((address_space(3))) s16x4*)(p0);
+  auto q1 = (__attribute__((address_space(3))) s16x4*)(p0 + 4 * WROW);
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q1);
+  s16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(
+    const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
+    float* __restrict__ slab, int o_tiles, int c_tiles, int chunks_per_split) {
+  __shared__ __align__(16) __bf16 sm[4 * WK * WROW];  // dY hi, dY lo, X hi, X lo : [32 px][160]
+  __bf16* Ah = sm;
+  __bf16* Al = sm + WK * WROW;
+  __bf16* Bh = sm + 2 * WK * WROW;
+  __bf16* Bl = sm + 3 * WK * WROW;
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  int bid = blockIdx.x;
+  const int c_tile = bid % c_tiles;
+  bid /= c_tiles;
+  const int tap = bid % 9;
+  const int o_tile = bid / 9;
+  const int o0 = o_tile * 128, c0 = c_tile * 128;
+  const int ky = tap / 3, kx = tap - 3 * ky;
+  const int64_t M = d.row_off[d.n_levels];
+  const int64_t total_chunks = (M + WK - 1) / WK;
+  const int64_t ch_begin = (int64_t)blockIdx.y * chunks_per_split;
+  int64_t ch_end = ch_begin + chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+
+  // staging: thread -> pixel rr + 8i (i < 4), channels 4*q4 .. +3
+  const int q4 = tid & 31, rr = tid >> 5;
+  float4 ra[4], rb[4];
+  auto load_chunk = [&](int64_t ch) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = ch * WK + rr + 8 * i;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (m < M) {
+        const int o = o0 + 4 * q4;
+        if ((Ns & 3) == 0 && o + 3 < Ns) {
+          ra[i] = *reinterpret_cast<const float4*>(dy + m * Ns + o);
+        } else {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int e = 0; e < 4; ++e)
+            if (o + e < Ns) t[e] = dy[m * Ns + o + e];
+          ra[i] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+        const int c = c0 + 4 * q4;
+        if (c < Cs) {
+          const RowCoord rc = decode_row(d, m);
+          const int yy = rc.y + ky - 1, xx = rc.x + kx - 1;
+          const int H = d.h[rc.lvl], W = d.w[rc.lvl];
+          if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+            const int64_t row = d.row_off[rc.lvl] + ((int64_t)rc.n * H + yy) * W + xx;
+            rb[i] = *reinterpret_cast<const float4*>(x + row * Cs + c);
+          }
+        }
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x4 hi, lo;
+      const int off = (rr + 8 * i) * WROW + 4 * q4;
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(Ah + off) = hi;
+      *reinterpret_cast<bf16x4*>(Al + off) = lo;
+      split4(rb[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(Bh + off) = hi;
+      *reinterpret_cast<bf16x4*>(Bl + off) = lo;
+    }
+  };
+
+  const int wm = wid >> 1, wn = wid & 1;
+  const int lr = lane & 31, lh = lane >> 5;
+  // transposed-read lane address: pixel row 8h + (l&15)>>2, channel column 16*((l>>4)&1) + 4*(l&3)
+  const int tr_off = (8 * lh + ((lane & 15) >> 2)) * WROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+  const int a_col = wm * 64, b_col = wn * 64;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  if (ch_begin < ch_end) load_chunk(ch_begin);
+  for (int64_t ch = ch_begin; ch < ch_end; ++ch) {
+    __syncthreads();  // previous chunk fully consumed
+    store_chunk();
+    if (ch + 1 < ch_end) load_chunk(ch + 1);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int oa = tr_off + 16 * s * WROW + a_col + 32 * t;
+        const int ob = tr_off + 16 * s * WROW + b_col + 32 * t;
+        ah[t] = tr_read8(Ah + oa);
+        al[t] = tr_read8(Al + oa);
+        bh[t] = tr_read8(Bh + ob);
+        bl[t] = tr_read8(Bl + ob);
+      }
+#pragma unroll
+      for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        }
+    }
+  }
+
+  float* out = slab + (int64_t)blockIdx.y * Nout * 9 * Cs;
+#pragma unroll
+  for (int tn = 0; tn < 2; ++tn) {
+    const int c = c0 + wn * 64 + tn * 32 + lr;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (o < Nout && c < Cs) out[((int64_t)o * 9 + tap) * Cs + c] = acc[tm][tn][r];
+      }
+  }
+}
+
+extern "C" void scan_slab_reduce_launch(const float* slab, int splits, int64_t n, float* dw, int accumulate,
+                                        hipStream_t st);
+
+static void wgrad3_plan(const scan_pyramid_t* d, int Cs, int Cout, int* o_tiles, int* c_tiles, int* splits, int* cps) {
+  const int64_t M = d->row_off[d->n_levels];
+  const int64_t chunks = (M + WK - 1) / WK;
+  *o_tiles = (Cout + 127) / 128;
+  *c_tiles = (Cs + 127) / 128;
+  const int tiles = *o_tiles * *c_tiles * 9;
+  int64_t s = 2048 / tiles;
+  if (s < 1) s = 1;
+  const int64_t smax = (chunks + 7) / 8;
+  if (s > smax) s = smax;
+  if (s < 1) s = 1;
+  *cps = (int)((chunks + s - 1) / s);
+  *splits = (int)((chunks + *cps - 1) / *cps);
+}
+
+extern "C" int64_t scan_conv3x3_wgrad_bf16x3_ws_floats(const scan_pyramid_t* d, int32_t Cs, int32_t Cout) {
+  int ot, ct, sp, cps;
+  wgrad3_plan(d, Cs, Cout, &ot, &ct, &sp, &cps);
+  return (int64_t)sp * Cout * 9 * Cs;
+}
+
+extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const float* dy,
+                                         int32_t Cout, int32_t Cout_s, float* dw, int32_t accumulate, float* ws,
+                                         void* stream) {
+  SCAN_CHECK_ARG(d && d->n_levels >= 1 && d->n_levels <= SCAN_MAX_LEVELS && d->n_images >= 1,
+                 "conv3x3_wgrad_bf16x3: bad pyramid");
+  SCAN_CHECK_ARG(Cs > 0 && Cs % 4 == 0, "conv3x3_wgrad_bf16x3: Cs=%d must be a positive multiple of 4", Cs);
+  SCAN_CHECK_ARG(Cout > 0 && Cout_s >= Cout, "conv3x3_wgrad_bf16x3: Cout=%d Cout_s=%d", Cout, Cout_s);
+  SCAN_CHECK_ARG(x && dy && dw && ws, "conv3x3_wgrad_bf16x3: null pointer");
+  int ot, ct, sp, cps;
+  wgrad3_plan(d, Cs, Cout, &ot, &ct, &sp, &cps);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(conv3x3_wgrad_bf16x3_kernel, dim3(ot * ct * 9, sp), dim3(256), 0, st, x, *d, Cs, dy, Cout, Cout_s,
+                     ws, ot, ct, cps);
+  SCAN_LAUNCH_CHECK("conv3x3_wgrad_bf16x3");
+  scan_slab_reduce_launch(ws, sp, (int64_t)Cout * 9 * Cs, dw, accumulate, st);
+  SCAN_LAUNCH_CHECK("slab_reduce");
+  return 0;
+}

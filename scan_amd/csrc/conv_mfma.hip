@@ -350,6 +350,11 @@ __global__ void slab_reduce_kernel(const float* __restrict__ slab, int splits, i
   }
 }
 
+extern "C" void scan_slab_reduce_launch(const float* slab, int splits, int64_t n, float* dw, int accumulate,
+                                        hipStream_t st) {
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, st, slab, splits, n, dw, accumulate);
+}
+
 __global__ void weight_transpose_kernel(const float* __restrict__ w, int Cout, int T, int Cs, float* __restrict__ wt,
                                         int Os) {
   // wt[c][t][o] = w[o][t][c]; one block per (t, 32x32 tile of (o,c))

@@ -241,7 +241,15 @@ class _Conv2d(torch.autograd.Function):
             call("scan_conv2d_dgrad", _ptr(dy), oshape.ref(), cout_s, _ptr(wt), _ptr(dx), shape.ref(), cs, cs, ksize,
                  stride, None, st)
             kernel_timer.end(ev)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and fast:
+            ws = x.new_empty((query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),))
+            dwp = x.new_empty((cout, T, cs))
+            ev = kernel_timer.begin("conv3x3_bf16x3_wgrad", 2.0 * oshape.rows * cout * T * cin)
+            call("scan_conv3x3_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), cout, cout_s, _ptr(dwp), 0, _ptr(ws),
+                 st)
+            kernel_timer.end(ev)
+            dw = unpack_weight_grad(dwp, weight)
+        elif ctx.needs_input_grad[1]:
             n = query("scan_conv2d_wgrad_ws_floats", oshape.ref(), cs, cout, ksize)
             ws = x.new_empty((n,))
             dwp = x.new_empty((cout, T, cs))

@@ -69,7 +69,7 @@ def test_step_gradients_match_reference(step_result):
                 # softmax is shift-invariant): both sides hold only rounding noise
                 assert mine[1] / p.numel() < 1e-6, (mk, name, mine[1])
                 continue
-            rt = 1e-3
+            rt = 1e-3 if mode == "fp32" else 3e-3  # bf16x3 operands carry 16 mantissa bits (hi + lo)
             if mode == "bf16x3" and mk in ("dis_P7_CON", "dis_P6_CON"):
                 # at 128x256 these levels are 1x2 / 2x4 pixels per image: GroupNorm over 16 / 64 elements
                 # amplifies the 1e-5 operand-split error (the same effect shows on the CPU when the convs are
@@ -82,7 +82,7 @@ def test_step_gradients_match_reference(step_result):
             # numerics bar is the sum / abs-sum above (single elements of deep gradients are sums of
             # thousands of cancelling terms)
             mean_abs = ref[1] / max(1, p.numel())
-            st = 5e-2 if rt == 1e-3 else 0.5
+            st = 5e-2 if rt <= 3e-3 else 0.5
             for a, b in zip(mine[2:], ref[2:]):
                 assert abs(a - b) <= st * abs(b) + st * mean_abs + 1e-7, (mk, name, a, b)
 

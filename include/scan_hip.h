@@ -157,10 +157,11 @@ int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, con
                         int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns,
                         int32_t relu, void* stream);
 /* weight gradient of the same conv, bf16x3 on the matrix cores, deterministic split-K through ws
- * (scan_conv3x3_wgrad_bf16x3_ws_floats floats).  dw [Cout][9][Cs]; accumulate != 0: dw += result. */
+ * (scan_conv3x3_wgrad_bf16x3_ws_floats floats).  dw [Cout][9][Cs]; db [Cout] or NULL = bias gradient (column
+ * sums of dy, fused); accumulate != 0: dw += result, db += result. */
 int64_t scan_conv3x3_wgrad_bf16x3_ws_floats(const scan_pyramid_t* d, int32_t Cs, int32_t Cout);
 int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const float* dy, int32_t Cout,
-                              int32_t Cout_s, float* dw, int32_t accumulate, float* ws, void* stream);
+                              int32_t Cout_s, float* dw, float* db, int32_t accumulate, float* ws, void* stream);
 /* w [Cout][T][Cin_s] -> wt [Cin_s][T][Cout_s] (zero padded) */
 int scan_weight_transpose(const float* w, int32_t Cout, int32_t T, int32_t Cin_s, float* wt, int32_t Cout_s,
                           void* stream);

@@ -53,7 +53,7 @@ SIGNATURES = {
     "scan_weight_split": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "scan_conv3x3_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "scan_conv3x3_wgrad_bf16x3_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
-    "scan_conv3x3_wgrad_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "scan_conv3x3_wgrad_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "scan_weight_transpose": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "scan_colsum_ws_floats": (c_i64, [c_i64, c_i32]),
     "scan_colsum": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),

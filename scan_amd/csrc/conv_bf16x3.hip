@@ -320,13 +320,20 @@ extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int3
 
 // ------------------------------------------------------------------------------------------------
 // weight gradient of the 3x3 / stride-1 conv on the bf16 matrix cores (same hi/lo split):
-//     dW[o][tap][c] = sum_m dY[m][o] * X[g(m, tap)][c]
+//     dW[o][ky][kx][c] = sum_m dY[m][o] * X[m + (ky-1, kx-1)][c]
 // GEMM with K = pixels.  Both operands live in memory pixel-major ([pixel][channel]), but an MFMA lane
 // needs 8 consecutive k (pixels) of one channel: the tiles are staged in LDS in their natural
 // [pixel][channel] layout and read with ds_read_b64_tr_b16, gfx950's transposing LDS read (each 16-lane
 // group fetches a 4-pixel x 16-channel block and receives it channel-major), so no transpose pass exists.
-// Block = 256 threads: 128 (o) x 128 (c) tile of one tap; K in chunks of 32 pixels; deterministic split-K
-// over gridDim.y into fp32 slabs (reduced in order by slab_reduce_kernel in conv_mfma.hip).
+//
+// The kernel is bound by operand traffic, not by the matrix cores (one tap per block re-reads every
+// dY / X element 18 times and saturates the fabric at ~8 TB/s), so a 512-thread workgroup computes the
+// 128 (o) x 128 (c) tile for the THREE kx taps of one ky from a single staged dY chunk and one staged X row
+// segment: K chunks are 32 consecutive pixels of one image row, the X segment carries one halo pixel each
+// side ([x0-1, x0+32], zero outside the row), and tap kx is just "LDS row + kx" for the transposed reads.
+// Deterministic split-K over chunk ranges into fp32 slabs; the splits of one tile group are placed on the
+// same XCD so the re-reads of a chunk hit that XCD's L2.  The bias gradient (column sums of dY) rides along
+// in the ky == 1, c-tile 0 workgroups, which already stream dY.
 // LDS rows are 320 B (256 B data + 64 B pad): the four pixel rows of a transposed read then fall on
 // disjoint 32-byte bank groups for both 16-lane groups of a half wave.
 // ------------------------------------------------------------------------------------------------
@@ -334,6 +341,12 @@ typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define WROW 160  // bf16 elements per LDS row
 #define WK 32     // pixels per K chunk
+#define WBUF ((WK + WK + 2) * 2 * WROW)  // bf16 elements per LDS buffer: dY hi/lo [32], X hi/lo [34]
+
+struct ChunkTab {
+  long long chunk_off[SCAN_MAX_LEVELS + 1];
+  int segs[SCAN_MAX_LEVELS];
+};
 
 __device__ __forceinline__ bf16x8 tr_read8(const __bf16* p0) {
   // p0: this lane's address for pixels k..k+3; pixels k+4..k+7 are 4 rows further
@@ -347,40 +360,54 @@ __device__ __forceinline__ bf16x8 tr_read8(const __bf16* p0) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(
+__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
-    float* __restrict__ slab, int o_tiles, int c_tiles, int chunks_per_split) {
-  __shared__ __align__(16) __bf16 sm[4 * WK * WROW];  // dY hi, dY lo, X hi, X lo : [32 px][160]
-  __bf16* Ah = sm;
-  __bf16* Al = sm + WK * WROW;
-  __bf16* Bh = sm + 2 * WK * WROW;
-  __bf16* Bl = sm + 3 * WK * WROW;
+    float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
+    int chunks_per_split, int splits) {
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  int bid = blockIdx.x;
-  const int c_tile = bid % c_tiles;
-  bid /= c_tiles;
-  const int tap = bid % 9;
-  const int o_tile = bid / 9;
+  // XCD-aware placement: ids b and b+8 share an XCD; all tiles of one split get the same b % 8
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  const int qq = L >> 3;
+  int tile = qq % n_tiles;
+  const int split = (qq / n_tiles) * 8 + xcd;
+  const int c_tile = tile % c_tiles;
+  tile /= c_tiles;
+  const int ky = tile % 3;
+  const int o_tile = tile / 3;
   const int o0 = o_tile * 128, c0 = c_tile * 128;
-  const int ky = tap / 3, kx = tap - 3 * ky;
-  const int64_t M = d.row_off[d.n_levels];
-  const int64_t total_chunks = (M + WK - 1) / WK;
-  const int64_t ch_begin = (int64_t)blockIdx.y * chunks_per_split;
-  int64_t ch_end = ch_begin + chunks_per_split;
+  const long long total_chunks = ct.chunk_off[d.n_levels];
+  const long long ch_begin = (long long)split * chunks_per_split;
+  long long ch_end = ch_begin + chunks_per_split;
   if (ch_end > total_chunks) ch_end = total_chunks;
+  const bool do_bias = (bias_slab != nullptr) && ky == 1 && c_tile == 0;
 
-  // staging: thread -> pixel rr + 8i (i < 4), channels 4*q4 .. +3
+  // staging roles: float4 column q4, pixel rows rr and rr + 16 (A); X rows rr, rr + 16, (rr + 32 for rr < 2)
   const int q4 = tid & 31, rr = tid >> 5;
-  float4 ra[4], rb[4];
-  auto load_chunk = [&](int64_t ch) {
+  float4 ra[2], rb[3];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_chunk = [&](long long ch) {
+    int lvl = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int64_t m = ch * WK + rr + 8 * i;
+    for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+      if (i < d.n_levels && ch >= ct.chunk_off[i]) lvl = i;
+    const int H = d.h[lvl], W = d.w[lvl];
+    const long long r = ch - ct.chunk_off[lvl];
+    const int seg = (int)(r % ct.segs[lvl]);
+    const long long row = r / ct.segs[lvl];  // n * H + y
+    const int y = (int)(row % H);
+    const int x0 = seg * WK;
+    const long long rowbase = d.row_off[lvl] + row * W;
+    const int o = o0 + 4 * q4, c = c0 + 4 * q4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int k = rr + 16 * i;
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (m < M) {
-        const int o = o0 + 4 * q4;
+      if (x0 + k < W) {
+        const long long m = rowbase + x0 + k;
         if ((Ns & 3) == 0 && o + 3 < Ns) {
           ra[i] = *reinterpret_cast<const float4*>(dy + m * Ns + o);
         } else {
@@ -389,129 +416,202 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_bf16x3_kernel(
             if (o + e < Ns) t[e] = dy[m * Ns + o + e];
           ra[i] = make_float4(t[0], t[1], t[2], t[3]);
         }
-        const int c = c0 + 4 * q4;
-        if (c < Cs) {
-          const RowCoord rc = decode_row(d, m);
-          const int yy = rc.y + ky - 1, xx = rc.x + kx - 1;
-          const int H = d.h[rc.lvl], W = d.w[rc.lvl];
-          if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-            const int64_t row = d.row_off[rc.lvl] + ((int64_t)rc.n * H + yy) * W + xx;
-            rb[i] = *reinterpret_cast<const float4*>(x + row * Cs + c);
-          }
-        }
       }
     }
-  };
-  auto store_chunk = [&]() {
+    const int yy = y + ky - 1;
+    const bool yok = yy >= 0 && yy < H && c < Cs;
+    const long long xrow = rowbase + (long long)(ky - 1) * W;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      bf16x4 hi, lo;
-      const int off = (rr + 8 * i) * WROW + 4 * q4;
+    for (int i = 0; i < 3; ++i) {
+      const int j = rr + 16 * i;
+      const int xx = x0 - 1 + j;
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < WK + 2 && yok && xx >= 0 && xx < W) rb[i] = *reinterpret_cast<const float4*>(x + (xrow + xx) * Cs + c);
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    __bf16* Ah = sm + buf * WBUF;
+    __bf16* Al = Ah + WK * WROW;
+    __bf16* Bh = Al + WK * WROW;
+    __bf16* Bl = Bh + (WK + 2) * WROW;
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int off = (rr + 16 * i) * WROW + 4 * q4;
       split4(ra[i], hi, lo);
       *reinterpret_cast<bf16x4*>(Ah + off) = hi;
       *reinterpret_cast<bf16x4*>(Al + off) = lo;
-      split4(rb[i], hi, lo);
-      *reinterpret_cast<bf16x4*>(Bh + off) = hi;
-      *reinterpret_cast<bf16x4*>(Bl + off) = lo;
+      if (do_bias) {
+        bsum.x += ra[i].x;
+        bsum.y += ra[i].y;
+        bsum.z += ra[i].z;
+        bsum.w += ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int j = rr + 16 * i;
+      if (j < WK + 2) {
+        const int off = j * WROW + 4 * q4;
+        split4(rb[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(Bh + off) = hi;
+        *reinterpret_cast<bf16x4*>(Bl + off) = lo;
+      }
     }
   };
 
-  const int wm = wid >> 1, wn = wid & 1;
+  // 8 waves: 2 (o) x 4 (c); each wave 64 o x 32 c = 2 x 1 MFMA tiles, for each of the 3 kx taps
+  const int wm = wid >> 2, wn = wid & 3;
   const int lr = lane & 31, lh = lane >> 5;
   // transposed-read lane address: pixel row 8h + (l&15)>>2, channel column 16*((l>>4)&1) + 4*(l&3)
   const int tr_off = (8 * lh + ((lane & 15) >> 2)) * WROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const int a_col = wm * 64, b_col = wn * 64;
+  const int a_col = wm * 64, b_col = wn * 32;
 
-  f32x16 acc[2][2];
+  f32x16 acc[3][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 3; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  if (ch_begin < ch_end) load_chunk(ch_begin);
-  for (int64_t ch = ch_begin; ch < ch_end; ++ch) {
-    __syncthreads();  // previous chunk fully consumed
-    store_chunk();
-    if (ch + 1 < ch_end) load_chunk(ch + 1);
-    __syncthreads();
+  if (ch_begin < ch_end) {
+    load_chunk(ch_begin);
+    store_chunk(0);
+  }
+  __syncthreads();
+  for (long long ch = ch_begin; ch < ch_end; ++ch) {
+    const int buf = (int)((ch - ch_begin) & 1);
+    const bool more = ch + 1 < ch_end;
+    if (more) load_chunk(ch + 1);
+    const __bf16* Ah = sm + buf * WBUF;
+    const __bf16* Al = Ah + WK * WROW;
+    const __bf16* Bh = Al + WK * WROW;
+    const __bf16* Bl = Bh + (WK + 2) * WROW;
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      bf16x8 ah[2], al[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int oa = tr_off + 16 * s * WROW + a_col + 32 * t;
-        const int ob = tr_off + 16 * s * WROW + b_col + 32 * t;
         ah[t] = tr_read8(Ah + oa);
         al[t] = tr_read8(Al + oa);
-        bh[t] = tr_read8(Bh + ob);
-        bl[t] = tr_read8(Bl + ob);
       }
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm)
+      for (int kx = 0; kx < 3; ++kx) {
+        const int ob = tr_off + (16 * s + kx) * WROW + b_col;
+        const bf16x8 bh = tr_read8(Bh + ob);
+        const bf16x8 bl = tr_read8(Bl + ob);
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+        for (int tm = 0; tm < 2; ++tm) {
+          acc[kx][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh, acc[kx][tm], 0, 0, 0);
+          acc[kx][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl, acc[kx][tm], 0, 0, 0);
+          acc[kx][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh, acc[kx][tm], 0, 0, 0);
         }
+      }
     }
+    if (more) store_chunk(buf ^ 1);
+    __syncthreads();
   }
 
-  float* out = slab + (int64_t)blockIdx.y * Nout * 9 * Cs;
+  float* out = slab + (long long)split * Nout * 9 * Cs;
+  const int c = c0 + b_col + lr;
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn) {
-    const int c = c0 + wn * 64 + tn * 32 + lr;
+  for (int kx = 0; kx < 3; ++kx)
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int o = o0 + wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (o < Nout && c < Cs) out[((int64_t)o * 9 + tap) * Cs + c] = acc[tm][tn][r];
+        const int o = o0 + a_col + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (o < Nout && c < Cs) out[((long long)o * 9 + ky * 3 + kx) * Cs + c] = acc[kx][tm][r];
       }
+
+  if (do_bias) {  // column sums of this split's dY rows: reduce the 16 pixel-row groups through LDS
+    float* red = reinterpret_cast<float*>(smem_raw);  // [16][128]
+    *reinterpret_cast<float4*>(red + rr * 128 + 4 * q4) = bsum;
+    __syncthreads();
+    if (tid < 128) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += red[g * 128 + tid];
+      if (o0 + tid < Nout) bias_slab[(long long)split * Nout + o0 + tid] = sum;
+    }
   }
+}
+
+__global__ void bias_slab_reduce_kernel(const float* __restrict__ bs, int splits, int n, float* __restrict__ db,
+                                        int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < splits; ++k) s += bs[(long long)k * n + i];
+  db[i] = accumulate ? db[i] + s : s;
 }
 
 extern "C" void scan_slab_reduce_launch(const float* slab, int splits, int64_t n, float* dw, int accumulate,
                                         hipStream_t st);
 
-static void wgrad3_plan(const scan_pyramid_t* d, int Cs, int Cout, int* o_tiles, int* c_tiles, int* splits, int* cps) {
-  const int64_t M = d->row_off[d->n_levels];
-  const int64_t chunks = (M + WK - 1) / WK;
-  *o_tiles = (Cout + 127) / 128;
+static void wgrad3_plan(const scan_pyramid_t* d, int Cs, int Cout, ChunkTab* ct, int* n_tiles, int* c_tiles,
+                        int* splits, int* cps) {
+  ct->chunk_off[0] = 0;
+  for (int l = 0; l < SCAN_MAX_LEVELS; ++l) {
+    if (l < d->n_levels) {
+      ct->segs[l] = (d->w[l] + WK - 1) / WK;
+      ct->chunk_off[l + 1] = ct->chunk_off[l] + (long long)d->n_images * d->h[l] * ct->segs[l];
+    } else {
+      ct->segs[l] = 1;
+      ct->chunk_off[l + 1] = ct->chunk_off[l];
+    }
+  }
+  const long long chunks = ct->chunk_off[d->n_levels];
   *c_tiles = (Cs + 127) / 128;
-  const int tiles = *o_tiles * *c_tiles * 9;
-  int64_t s = 2048 / tiles;
+  *n_tiles = ((Cout + 127) / 128) * 3 * *c_tiles;
+  long long s = 1024 / *n_tiles;
   if (s < 1) s = 1;
-  const int64_t smax = (chunks + 7) / 8;
+  const long long smax = (chunks + 7) / 8;
   if (s > smax) s = smax;
-  if (s < 1) s = 1;
+  s = (s + 7) / 8 * 8;  // groups of 8 splits, one per XCD
   *cps = (int)((chunks + s - 1) / s);
-  *splits = (int)((chunks + *cps - 1) / *cps);
+  if (*cps < 1) *cps = 1;
+  *splits = (int)s;
 }
 
 extern "C" int64_t scan_conv3x3_wgrad_bf16x3_ws_floats(const scan_pyramid_t* d, int32_t Cs, int32_t Cout) {
-  int ot, ct, sp, cps;
-  wgrad3_plan(d, Cs, Cout, &ot, &ct, &sp, &cps);
-  return (int64_t)sp * Cout * 9 * Cs;
+  ChunkTab ct;
+  int nt, ctl, sp, cps;
+  wgrad3_plan(d, Cs, Cout, &ct, &nt, &ctl, &sp, &cps);
+  return (int64_t)sp * Cout * 9 * Cs + (int64_t)sp * Cout;
 }
 
 extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const float* dy,
-                                         int32_t Cout, int32_t Cout_s, float* dw, int32_t accumulate, float* ws,
-                                         void* stream) {
+                                         int32_t Cout, int32_t Cout_s, float* dw, float* db, int32_t accumulate,
+                                         float* ws, void* stream) {
   SCAN_CHECK_ARG(d && d->n_levels >= 1 && d->n_levels <= SCAN_MAX_LEVELS && d->n_images >= 1,
                  "conv3x3_wgrad_bf16x3: bad pyramid");
   SCAN_CHECK_ARG(Cs > 0 && Cs % 4 == 0, "conv3x3_wgrad_bf16x3: Cs=%d must be a positive multiple of 4", Cs);
   SCAN_CHECK_ARG(Cout > 0 && Cout_s >= Cout, "conv3x3_wgrad_bf16x3: Cout=%d Cout_s=%d", Cout, Cout_s);
   SCAN_CHECK_ARG(x && dy && dw && ws, "conv3x3_wgrad_bf16x3: null pointer");
-  int ot, ct, sp, cps;
-  wgrad3_plan(d, Cs, Cout, &ot, &ct, &sp, &cps);
+  ChunkTab ct;
+  int nt, ctl, sp, cps;
+  wgrad3_plan(d, Cs, Cout, &ct, &nt, &ctl, &sp, &cps);
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(conv3x3_wgrad_bf16x3_kernel, dim3(ot * ct * 9, sp), dim3(256), 0, st, x, *d, Cs, dy, Cout, Cout_s,
-                     ws, ot, ct, cps);
+  const size_t sh = (size_t)2 * WBUF * sizeof(__bf16);
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16x3_kernel),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    done = true;
+  }
+  float* bias_slab = db ? ws + (int64_t)sp * Cout * 9 * Cs : nullptr;
+  hipLaunchKernelGGL(conv3x3_wgrad_bf16x3_kernel, dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout, Cout_s, ws,
+                     bias_slab, ct, nt, ctl, cps, sp);
   SCAN_LAUNCH_CHECK("conv3x3_wgrad_bf16x3");
   scan_slab_reduce_launch(ws, sp, (int64_t)Cout * 9 * Cs, dw, accumulate, st);
   SCAN_LAUNCH_CHECK("slab_reduce");
+  if (db) {
+    hipLaunchKernelGGL(bias_slab_reduce_kernel, dim3((Cout + 255) / 256), dim3(256), 0, st, bias_slab, sp, Cout, db,
+                       accumulate);
+    SCAN_LAUNCH_CHECK("bias_slab_reduce");
+  }
   return 0;
 }

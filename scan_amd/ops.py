@@ -245,8 +245,11 @@ class _Conv2d(torch.autograd.Function):
             ws = x.new_empty((query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),))
             dwp = x.new_empty((cout, T, cs))
             ev = kernel_timer.begin("conv3x3_bf16x3_wgrad", 2.0 * oshape.rows * cout * T * cin)
-            call("scan_conv3x3_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), cout, cout_s, _ptr(dwp), 0, _ptr(ws),
-                 st)
+            want_db = has_bias and ctx.needs_input_grad[2]
+            if want_db:
+                db = x.new_empty((cout,))
+            call("scan_conv3x3_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), cout, cout_s, _ptr(dwp),
+                 _ptr(db) if want_db else None, 0, _ptr(ws), st)
             kernel_timer.end(ev)
             dw = unpack_weight_grad(dwp, weight)
         elif ctx.needs_input_grad[1]:
@@ -258,7 +261,7 @@ class _Conv2d(torch.autograd.Function):
                  _ptr(dwp), 0, _ptr(ws), st)
             kernel_timer.end(ev)
             dw = unpack_weight_grad(dwp, weight)
-        if has_bias and ctx.needs_input_grad[2]:
+        if has_bias and ctx.needs_input_grad[2] and db is None:
             M = dy.shape[0]
             ws = x.new_empty((query("scan_colsum_ws_floats", M, cout),))
             db = x.new_empty((cout,))

@@ -26,11 +26,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-#define TH 8
 #define TW 16
-#define PH (TH + 2)
 #define PW (TW + 2)
-#define NPATCH (PH * PW)  // 180 halo pixels
 #define CK 32             // channels per K chunk
 #define LROW 40           // bf16 elements per LDS row (32 data + 8 pad = 80 B)
 
@@ -57,16 +54,21 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
   lo[3] = (__bf16)(v.w - (float)hi[3]);
 }
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
+// BN: output channels per workgroup; TH: tile height in pixels (tile = TH x 16); NT: threads (TH * 32)
+template <int BN, int TH, int NT>
+__global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
     const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
     float* __restrict__ dst, int Nout, int Ns, int relu, TileTab tt, int n_tiles) {
-  constexpr int WN_WAVES = BN / 64;        // 2 (BN=128) or 1 (BN=64)
-  constexpr int WM_WAVES = 4 / WN_WAVES;   // 2 or 4
-  constexpr int TM = 4 / WM_WAVES;         // 32-pixel MFMA tiles per wave: 2 or 1
-  constexpr int TN = 2;                    // 32-channel MFMA tiles per wave
-  constexpr int BSEG = BN * 4 * 2 / 256;   // 16-byte weight segments per thread per (chunk, tap): 4 or 2
+  constexpr int PH = TH + 2;
+  constexpr int NPATCH = PH * PW;                 // halo pixels: 180 (TH 8) or 324 (TH 16)
+  constexpr int WAVES = NT / 64;
+  constexpr int WN_WAVES = BN / 64;               // 2 (BN=128) or 1 (BN=64)
+  constexpr int WM_WAVES = WAVES / WN_WAVES;
+  constexpr int TM = (TH * TW / 32) / WM_WAVES;   // 32-pixel MFMA tiles per wave
+  constexpr int TN = 2;                           // 32-channel MFMA tiles per wave
+  constexpr int ASLOTS = (NPATCH * 8 + NT - 1) / NT;  // float4 of the halo patch per thread per chunk
+  constexpr int BSEG = BN * 4 * 2 / NT;           // 16-byte weight segments per thread per (chunk, tap)
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __bf16* Ah = reinterpret_cast<__bf16*>(smem_raw);  // [NPATCH][LROW]
@@ -92,12 +94,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
   const int nchunks = (Cs + CK - 1) / CK;
 
   // ---- A patch staging roles: 180 pixels x 8 float4 = 1440 slots, 6 per thread
-  float4 ra[6];
+  float4 ra[ASLOTS];
   auto load_a = [&](int cc) {
     const int c0 = cc * CK;
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int slot = tid + 256 * i;
+    for (int i = 0; i < ASLOTS; ++i) {
+      const int slot = tid + NT * i;
       const int q = slot >> 3, c = c0 + 4 * (slot & 7);
       const int py = q / PW, px = q - py * PW;
       const int y = ty0 - 1 + py, x = tx0 - 1 + px;
@@ -108,8 +110,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
   };
   auto store_a = [&]() {
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-      const int slot = tid + 256 * i;
+    for (int i = 0; i < ASLOTS; ++i) {
+      const int slot = tid + NT * i;
       if (slot < NPATCH * 8) {
         const int q = slot >> 3, c4 = slot & 7;
         bf16x4 hi, lo;
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
   auto load_b = [&](int cc, int tap) {
 #pragma unroll
     for (int i = 0; i < BSEG; ++i) {
-      const int slot = tid + 256 * i;
+      const int slot = tid + NT * i;
       const int plane = slot / (BN * 4);
       const int rem = slot - plane * BN * 4;
       const int row = rem >> 2, seg = rem & 3;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_bf16x3_kernel(
   auto store_b = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < BSEG; ++i) {
-      const int slot = tid + 256 * i;
+      const int slot = tid + NT * i;
       const int plane = slot / (BN * 4);
       const int rem = slot - plane * BN * 4;
       const int row = rem >> 2, seg = rem & 3;
@@ -254,7 +256,7 @@ __global__ void weight_split_kernel(const float* __restrict__ w, int O, int T, i
   }
 }
 
-static void make_tiles(const scan_pyramid_t* d, TileTab* tt) {
+static void make_tiles(const scan_pyramid_t* d, TileTab* tt, int TH) {
   tt->tile_off[0] = 0;
   for (int l = 0; l < SCAN_MAX_LEVELS; ++l) {
     if (l < d->n_levels) {
@@ -293,26 +295,31 @@ extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int3
   SCAN_CHECK_ARG(Nout > 0 && Ns >= Nout, "conv3x3_bf16x3: Nout=%d Ns=%d", Nout, Ns);
   SCAN_CHECK_ARG(x && wh && wl && y, "conv3x3_bf16x3: null pointer");
   TileTab tt;
-  make_tiles(d, &tt);
-  const int tiles = tt.tile_off[d->n_levels];
   hipStream_t st = as_stream(stream);
   const __bf16* h = reinterpret_cast<const __bf16*>(wh);
   const __bf16* l = reinterpret_cast<const __bf16*>(wl);
   if (Nout > 64) {
+    // 16 x 16 pixel tiles, 512 threads (8 waves = 4 x 2 of 64 px x 64 ch): one weight tile feeds 256 pixels.
+    // (A/B on one device, tower layer: 8x16/256 thr x2 per CU 305 TF, this 332 TF, a 3-deep software-pipelined
+    //  variant of it 330 TF -- not kept.)
+    make_tiles(d, &tt, 16);
+    const int tiles = tt.tile_off[d->n_levels];
     const int n_tiles = (Nout + 127) / 128;
-    const size_t sh = (size_t)(2 * NPATCH * LROW + 4 * 128 * LROW) * sizeof(__bf16);
+    const size_t sh = (size_t)(2 * 18 * PW * LROW + 4 * 128 * LROW) * sizeof(__bf16);
     static bool done = false;
     if (!done) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16x3_kernel<128>),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16x3_kernel<128, 16, 512>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
       done = true;
     }
-    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<128>), dim3(tiles * n_tiles), dim3(256), sh, st, x, *d, Cs, h, l, Csw, bias,
-                       mask, y, Nout, Ns, relu, tt, n_tiles);
+    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<128, 16, 512>), dim3(tiles * n_tiles), dim3(512), sh, st, x, *d, Cs, h, l,
+                       Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles);
   } else {
-    const size_t sh = (size_t)(2 * NPATCH * LROW + 4 * 64 * LROW) * sizeof(__bf16);
-    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<64>), dim3(tiles), dim3(256), sh, st, x, *d, Cs, h, l, Csw, bias, mask, y,
-                       Nout, Ns, relu, tt, 1);
+    make_tiles(d, &tt, 8);
+    const int tiles = tt.tile_off[d->n_levels];
+    const size_t sh = (size_t)(2 * 10 * PW * LROW + 4 * 64 * LROW) * sizeof(__bf16);
+    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<64, 8, 256>), dim3(tiles), dim3(256), sh, st, x, *d, Cs, h, l, Csw, bias,
+                       mask, y, Nout, Ns, relu, tt, 1);
   }
   SCAN_LAUNCH_CHECK("conv3x3_bf16x3");
   return 0;
@@ -566,7 +573,7 @@ static void wgrad3_plan(const scan_pyramid_t* d, int Cs, int Cout, ChunkTab* ct,
   const long long chunks = ct->chunk_off[d->n_levels];
   *c_tiles = (Cs + 127) / 128;
   *n_tiles = ((Cout + 127) / 128) * 3 * *c_tiles;
-  long long s = 1024 / *n_tiles;
+  long long s = 768 / *n_tiles;  // ~3 workgroups per CU in total: split-K slabs cost HBM traffic
   if (s < 1) s = 1;
   const long long smax = (chunks + 7) / 8;
   if (s > smax) s = smax;

@@ -107,6 +107,7 @@ class FlatGroup:
             view.copy_(p.data)
             p.data = view
             p.grad = self.flat_g[off:off + n].as_strided(p.shape, stride)
+            p._scan_flat = True  # ops.* backward kernels accumulate straight into p.grad (no autograd add)
             off += n
         self.lr, self.bias_lr_factor, self.wd, self.wd_bias, self.momentum = lr, bias_lr_factor, wd, wd_bias, momentum
         self.first = True

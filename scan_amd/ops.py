@@ -213,6 +213,13 @@ class _Conv2d(torch.autograd.Function):
             kernel_timer.end(ev)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.cfg = (shape, oshape, ksize, stride, relu, cout_s, bias is not None, fast)
+        # parameters re-homed into a flat gradient buffer (engine.FlatGroup): accumulate straight into it
+        ctx.wgrad_buf = ctx.bgrad_buf = None
+        if getattr(weight, "_scan_flat", False) and weight.grad is not None and weight.shape[1] == cs \
+                and weight.grad.permute(0, 2, 3, 1).is_contiguous():
+            ctx.wgrad_buf = weight.grad
+            if bias is not None and getattr(bias, "_scan_flat", False) and bias.grad is not None:
+                ctx.bgrad_buf = bias.grad
         return y
 
     @staticmethod
@@ -241,31 +248,41 @@ class _Conv2d(torch.autograd.Function):
             call("scan_conv2d_dgrad", _ptr(dy), oshape.ref(), cout_s, _ptr(wt), _ptr(dx), shape.ref(), cs, cs, ksize,
                  stride, None, st)
             kernel_timer.end(ev)
+        direct_w = ctx.wgrad_buf is not None
+        direct_b = direct_w and ctx.bgrad_buf is not None
+        db_done = False
         if ctx.needs_input_grad[1] and fast:
             ws = x.new_empty((query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),))
-            dwp = x.new_empty((cout, T, cs))
+            dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
             ev = kernel_timer.begin("conv3x3_bf16x3_wgrad", 2.0 * oshape.rows * cout * T * cin)
             want_db = has_bias and ctx.needs_input_grad[2]
             if want_db:
-                db = x.new_empty((cout,))
+                db = ctx.bgrad_buf if direct_b else x.new_empty((cout,))
+                db_done = True
             call("scan_conv3x3_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), cout, cout_s, _ptr(dwp),
-                 _ptr(db) if want_db else None, 0, _ptr(ws), st)
+                 _ptr(db) if want_db else None, int(direct_w), _ptr(ws), st)
             kernel_timer.end(ev)
-            dw = unpack_weight_grad(dwp, weight)
+            if want_db and direct_w and not direct_b:
+                raise RuntimeError("conv2d: flat weight gradient without a flat bias gradient")
+            dw = None if direct_w else unpack_weight_grad(dwp, weight)
+            if direct_b:
+                db = None
         elif ctx.needs_input_grad[1]:
             n = query("scan_conv2d_wgrad_ws_floats", oshape.ref(), cs, cout, ksize)
             ws = x.new_empty((n,))
-            dwp = x.new_empty((cout, T, cs))
+            dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
             ev = kernel_timer.begin("conv_wgrad", 2.0 * oshape.rows * cout * T * cin)
             call("scan_conv2d_wgrad", _ptr(x), shape.ref(), cs, _ptr(dy), oshape.ref(), cout, cout_s, ksize, stride,
-                 _ptr(dwp), 0, _ptr(ws), st)
+                 _ptr(dwp), int(direct_w), _ptr(ws), st)
             kernel_timer.end(ev)
-            dw = unpack_weight_grad(dwp, weight)
-        if has_bias and ctx.needs_input_grad[2] and db is None:
+            dw = None if direct_w else unpack_weight_grad(dwp, weight)
+        if has_bias and ctx.needs_input_grad[2] and not db_done:
             M = dy.shape[0]
             ws = x.new_empty((query("scan_colsum_ws_floats", M, cout),))
-            db = x.new_empty((cout,))
-            call("scan_colsum", _ptr(dy), M, cout, cout_s, _ptr(db), 0, _ptr(ws), st)
+            db = ctx.bgrad_buf if direct_b else x.new_empty((cout,))
+            call("scan_colsum", _ptr(dy), M, cout, cout_s, _ptr(db), int(direct_b), _ptr(ws), st)
+            if direct_b:
+                db = None
         return dx, dw, db, None, None, None, None, None
 
 
@@ -290,6 +307,10 @@ class _GroupNormReLU(torch.autograd.Function):
              _ptr(y), st)
         ctx.save_for_backward(x, y, gamma, stats)
         ctx.cfg = (shape, relu)
+        ctx.gbuf = ctx.bbuf = None
+        if getattr(gamma, "_scan_flat", False) and getattr(beta, "_scan_flat", False) and gamma.grad is not None \
+                and beta.grad is not None:
+            ctx.gbuf, ctx.bbuf = gamma.grad, beta.grad
         return y
 
     @staticmethod
@@ -301,10 +322,13 @@ class _GroupNormReLU(torch.autograd.Function):
         nws = query("scan_groupnorm_ws_floats", shape.ref(), C, 32)
         ws = torch.empty((nws // 2 + 1,), dtype=torch.float64, device=x.device)
         dx = torch.empty_like(x)
-        dg = x.new_empty((C,))
-        db = x.new_empty((C,))
+        direct = ctx.gbuf is not None
+        dg = ctx.gbuf if direct else x.new_empty((C,))
+        db = ctx.bbuf if direct else x.new_empty((C,))
         call("scan_groupnorm_relu_backward", _ptr(x), _ptr(y), _ptr(dy), shape.ref(), C, 32, _ptr(stats), _ptr(gamma),
-             int(relu), _ptr(dx), _ptr(dg), _ptr(db), 0, _ptr(ws), _stream())
+             int(relu), _ptr(dx), _ptr(dg), _ptr(db), int(direct), _ptr(ws), _stream())
+        if direct:
+            return dx, None, None, None, None, None
         return dx, dg, db, None, None, None
 
 

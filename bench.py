@@ -30,6 +30,20 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16X3_TFLOPS = 2500.0 / 3.0
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+    (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction).  None if not recorded."""
+    key = {"conv3x3_bf16x3_wgrad": "conv3x3_bf16x3_wgrad", "conv3x3_bf16x3_fwd": "conv3x3_bf16x3_fwd_dgrad_bn128",
+           "conv3x3_bf16x3_dgrad": "conv3x3_bf16x3_fwd_dgrad_bn128", "conv_igemm_fwd": "conv_igemm_fwd",
+           "conv_igemm_dgrad": "conv_igemm_dgrad", "conv_wgrad": "conv_wgrad"}.get(kernel_name)
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            rec = json.load(f).get(key)
+        return rec["hbm_bytes"] if rec else None
+    except Exception:
+        return None
+
+
 def peak_for(kernel_name):
     return PEAK_BF16X3_TFLOPS if "bf16x3" in kernel_name else PEAK_FP32_MFMA_TFLOPS
 
@@ -126,7 +140,8 @@ def main():
         if dom:
             name, r = dom
             roof = {"bound": "mfma", "kernel": name, "achieved": round(r["tflops"], 2), "peak": round(peak_for(name), 1),
-                    "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_for(name), 4), "traffic": None,
+                    "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_for(name), 4), "traffic": pmc_traffic(name),
+                    "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/r01_pmc_traffic.json)",
                     "peak_note": "algorithmic fp32-equivalent FLOPs; bf16x3 kernels spend 3 bf16 MFMAs per product, "
                                  "peak = 2.5 PFLOP/s dense bf16 / 3",
                     "launches": r["launches"], "avg_launch_ms": round(r["avg_ms"], 4),
@@ -135,12 +150,12 @@ def main():
                                          for k, v in ksum.items()}}
         cpu = None
         if not a.no_cpu_baseline:
-            sh, sw = H // 2, W // 2
+            sh, sw = H, W  # one full-size pair: ~10 s on 16 host threads
             cdt, cores = cpu_baseline(sh, sw)
             scale = (sh * sw) / float(H * W)
             cpu = {"value": round(scale / cdt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
-                   "sample": "1 (src,tgt) pair, one DA iteration + SGD at %dx%d (1/%d of the frame area), "
-                             "pairs/s scaled by the area ratio; %.1f s of CPU work" % (sh, sw, round(1 / scale), cdt)}
+                   "sample": "1 (src,tgt) pair of %dx%d frames, one full DA iteration + SGD (the GPU step does 2 pairs); "
+                             "%.1f s of CPU work" % (sh, sw, cdt)}
         line = {
             "metric": "train images/sec (whole node), VGG16 C2F 1024x2048", "value": round(value, 4),
             "unit": "image pairs/s (1 source + 1 target frame per pair)", "n_gpus": world, "steps": a.steps,

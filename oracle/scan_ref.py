@@ -291,6 +291,78 @@ def middle_head_source(p, state, feats, targets, K=9):
     return out, node_loss, act_loss, maps
 
 
+def dbscan_mask(act_fg, feat, eps=3, thr=0.05):
+    """PrototypeComputation.DBSCAN_batch_cpu (loss.py:397-423).  act_fg [N,CLS,H,W] (foreground act maps),
+    feat [N,C,H,W].  Points = feat * act[c] at entries with act > thr, in (n, cls, h, w) order; sklearn DBSCAN;
+    noise (-1) -> 1, cluster 0 -> 0; a pixel is selected if any class entry is non-zero."""
+    from sklearn import cluster
+    act_fg = act_fg.detach()
+    feat = feat.detach()
+    N, CLS, H, W = act_fg.shape
+    fn = torch.cat([(feat * act_fg[:, i].unsqueeze(1)).unsqueeze(0) for i in range(CLS)], 0)
+    fn = fn.permute(1, 0, 3, 4, 2).reshape(-1, feat.shape[1])
+    mask = (act_fg > thr).reshape(-1)
+    mask_float = mask.float()
+    pos = fn[mask]
+    if pos.bool().any():
+        Y = cluster.DBSCAN(eps=eps, n_jobs=-1).fit_predict(pos.numpy())
+        Y[Y < 0] = 1
+        mask_float[mask] = torch.from_numpy(Y.astype(np.float32))
+    Y = mask_float.reshape(N, CLS, H, W)
+    return Y.permute(0, 2, 3, 1).reshape(-1, CLS).sum(-1).bool()
+
+
+def sample_target_nodes(feats, maps, eps=3, thr=0.05):
+    """PrototypeComputation.__call__ target branch, 'dbscan' (loss.py:464-518)."""
+    pos_pts, pos_lab, neg_pts = [], [], []
+    for f, m in zip(feats, maps):
+        C, K = f.shape[1], m.shape[1]
+        conf = dbscan_mask(m[:, 1:], f, eps, thr)
+        if conf.any():
+            act = m.permute(0, 2, 3, 1).reshape(-1, K)
+            flat = f.permute(0, 2, 3, 1).reshape(-1, C)
+            pos_pts.append(flat[conf])
+            pos_lab.append(act[conf, 1:].argmax(dim=-1) + 1)
+            negs = flat[~conf]
+            idx = list(np.floor(np.linspace(0, int((~conf).sum()) - 2, int(conf.sum()))).astype(int))
+            neg_pts.append(negs[idx])
+    if not pos_pts:
+        return None, None
+    pos_pts, pos_lab, neg_pts = torch.cat(pos_pts, 0), torch.cat(pos_lab, 0), torch.cat(neg_pts, 0)
+    return torch.cat([neg_pts, pos_pts], 0), torch.cat([pos_lab.new_zeros(neg_pts.shape[0]), pos_lab])
+
+
+def sim_matrix(a, b, eps=1e-8):
+    """condgraph.py:35-43."""
+    a_n, b_n = a.norm(dim=1)[:, None], b.norm(dim=1)[:, None]
+    return torch.mm(a / torch.clamp(a_n, min=eps), (b / torch.clamp(b_n, min=eps)).transpose(0, 1))
+
+
+def transfer_loss(prototype, tg_prototype, tg_nodes, tg_labels):
+    """get_transfer_loss with TRANSFER_CFG ('NODES', 'ADJ') (condgraph.py:457-498)."""
+    sr = prototype.mean(dim=-1).detach()
+    # nn.KLDivLoss() default reduction 'mean' = mean over all elements
+    l_node = F.kl_div(tg_nodes.softmax(-1).log(), sr[tg_labels.long()].softmax(-1), reduction="mean")
+    indx = tg_prototype.sum(dim=-1).bool()
+    adj_sr = sim_matrix(sr[indx], sr[indx]).view(1, -1)
+    adj_tg = sim_matrix(tg_prototype[indx], tg_prototype[indx]).view(1, -1)
+    l_adj = F.cosine_embedding_loss(adj_sr, adj_tg, adj_sr.new_ones(1), margin=0.0)
+    return l_node + l_adj
+
+
+def middle_head_target(p, state, feats, K=9, eps=3, thr=0.05, lam3=1.0):
+    """GRAPHModule._forward_train_target (condgraph.py:500-534), GCN_SELF_TRAINING False."""
+    feats = [tower(p, "head_in.middle_tower", f, 2) for f in feats]
+    w = conded_weight(p, state.prototype)
+    _, maps = act_maps_from(feats, w)
+    pts, labs = sample_target_nodes(feats, maps, eps, thr)
+    out = [tower(p, "head_out.middle_tower", torch.cat([f, m], 1), 1, gn=False) for f, m in zip(feats, maps)]
+    if pts is None:
+        return out, None, maps
+    _, tg_proto = forward_gcns(p, pts, labs, K)
+    return out, lam3 * transfer_loss(state.prototype, tg_proto, pts, labs), maps
+
+
 def middle_head_plain(p, state, feats, K=9):
     """target pass with forward_target False / inference (condgraph.py:536-545):
     head_in -> act maps -> head_out, no losses."""
@@ -375,7 +447,8 @@ def discriminator_loss(p, feat, act, domain_label, K=9, grl_lambda=0.02):
 
 
 # ----------------------------------------------------------------------------- DA iteration
-def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, skip_dead_target_fcos=True):
+def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, skip_dead_target_fcos=True,
+                 forward_target=False):
     """Three-phase DA iteration (engine/trainer.py:266-385) with forward_target
     False: returns the loss dict (floats); gradients accumulate in P[...].grad.
     The target-pass FCOS head only yields the identically-zero 'zero' loss
@@ -395,8 +468,13 @@ def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, s
     sum(ds.values()).backward()
     out.update({k: float(v.detach()) for k, v in ds.items()})
     feats = vgg_fpn_forward(P["backbone"], images_t)
-    f_t, maps_t = middle_head_plain(P["middle_head"], state, feats, K)
     dt = {}
+    if forward_target:
+        f_t, cons, maps_t = middle_head_target(P["middle_head"], state, feats, K)
+        if cons is not None:
+            dt["consistency_loss_gt"] = cons
+    else:
+        f_t, maps_t = middle_head_plain(P["middle_head"], state, feats, K)
     if not skip_dead_target_fcos:
         lg, rg, ct = fcos_head(P["fcos"], f_t)
         dt["zero_gt"] = 0.0 * sum(0.0 * x.sum() for x in lg + rg + ct)

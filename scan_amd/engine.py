@@ -68,7 +68,7 @@ def forward_detector(model, images, targets=None, mode="source", forward_target=
                                                              forward_target=forward_target)
     if loss_graph is not None:
         node_loss, consistency_loss = loss_graph
-        if consistency_loss:
+        if consistency_loss is not None and not (isinstance(consistency_loss, (int, float)) and consistency_loss == 0):
             losses["consistency_loss"] = consistency_loss
         if node_loss is not None:
             losses["node_loss"] = node_loss

@@ -123,11 +123,65 @@ def sample_source_nodes(feats, labels, shape):
     return torch.cat([neg_pts, pos_pts], 0), torch.cat([pos_lab.new_zeros(neg_pts.shape[0]), pos_lab])
 
 
+def sim_matrix(a, b, eps=1e-8):
+    """reference condgraph.py:35-43."""
+    a_n, b_n = a.norm(dim=1)[:, None], b.norm(dim=1)[:, None]
+    return torch.mm(a / torch.clamp(a_n, min=eps), (b / torch.clamp(b_n, min=eps)).transpose(0, 1))
+
+
+def dbscan_positive_rows(feat_l, act_l, n_images, eps, thr):
+    """PrototypeComputation.DBSCAN_batch_cpu (reference loss.py:397-423) on one level, HOST tier (north star:
+    DBSCAN target-node sampling stays on the host; sklearn, all cores).  feat_l [N*HW, C], act_l [N*HW, K]
+    rows.  Points are feat * act[c] at the (image, class, pixel) entries with act > thr, in that order; noise
+    (-1) -> 1, cluster 0 -> 0; a pixel row is selected when any of its class entries is non-zero."""
+    from sklearn import cluster
+    K = act_l.shape[1]
+    hw = feat_l.shape[0] // n_images
+    act = act_l.detach().view(n_images, hw, K)[:, :, 1:].permute(0, 2, 1).contiguous()  # [N, CLS, HW]
+    mask = act > thr
+    idx = mask.nonzero()  # (n, cls, hw) lexicographic = the reference's (n, cls, h, w) order
+    sel = torch.zeros_like(act)
+    if idx.shape[0] > 0:
+        pts = feat_l.detach().view(n_images, hw, -1)[idx[:, 0], idx[:, 2]] * act[mask][:, None]
+        if bool(pts.bool().any()):
+            y = cluster.DBSCAN(eps=eps, n_jobs=-1).fit_predict(pts.cpu().numpy())
+            y[y < 0] = 1
+            sel[mask] = torch.from_numpy(y.astype(np.float32)).to(sel.device)
+        else:
+            sel[mask] = 1.0
+    return sel.sum(1).bool().reshape(-1)  # [N*HW] in row order
+
+
+def sample_target_nodes(feats, maps, shape, eps=3, thr=0.05):
+    """PrototypeComputation.__call__ target branch, TARGET_SAMPLING_CFG 'dbscan' (reference loss.py:464-518):
+    pseudo-label = argmax foreground act map; as many background rows as positives, linspace-subsampled."""
+    pos_pts, pos_lab, neg_pts = [], [], []
+    for l in range(shape.n_levels):
+        r0, r1 = shape.row_off[l], shape.row_off[l + 1]
+        f, m = feats[r0:r1], maps[r0:r1]
+        conf = dbscan_positive_rows(f, m, shape.n_images, eps, thr)
+        if bool(conf.any()):
+            pi = torch.nonzero(conf).squeeze(1)
+            ni = torch.nonzero(~conf).squeeze(1)
+            pos_pts.append(f[pi])
+            pos_lab.append(m[pi, 1:].argmax(dim=-1) + 1)
+            idx = np.floor(np.linspace(0, ni.numel() - 2, pi.numel())).astype(np.int64)
+            neg_pts.append(f[ni[torch.from_numpy(idx).to(ni.device)]])
+    if not pos_pts:
+        return None, None
+    pos_pts, pos_lab, neg_pts = torch.cat(pos_pts, 0), torch.cat(pos_lab, 0), torch.cat(neg_pts, 0)
+    return torch.cat([neg_pts, pos_pts], 0), torch.cat([pos_lab.new_zeros(neg_pts.shape[0]), pos_lab])
+
+
 class GRAPHModule(nn.Module):
     """model["middle_head"]."""
 
-    def __init__(self, in_channels=256, num_classes=9, proto_iter=3, attn_dropout=0.1):
+    def __init__(self, in_channels=256, num_classes=9, proto_iter=3, attn_dropout=0.1, transfer_cfg=("NODES", "ADJ"),
+                 dbscan_eps=3, dbscan_thr=0.05):
         super().__init__()
+        self.transfer_cfg = tuple(transfer_cfg)
+        self.dbscan_eps, self.dbscan_thr = dbscan_eps, dbscan_thr
+        self.lamda3 = self.lamda4 = 1.0
         self.num_classes_fg = num_classes - 1
         self.used_num_classes = num_classes  # PROTO_WITH_BG
         self.prototype_iter = proto_iter
@@ -200,6 +254,34 @@ class GRAPHModule(nn.Module):
         cat = torch.cat([feats, maps, feats.new_zeros(feats.shape[0], pad)], 1)
         return logits, maps, self.head_out(cat, shape)
 
+    def get_transfer_loss(self, tg_prototype, tg_nodes, tg_labels):
+        """Graph-guided semantic transfer (reference condgraph.py:457-498) for TRANSFER_CFG in {NODES, ADJ}."""
+        sr = self.prototype.mean(dim=-1).detach()
+        losses = []
+        if "NODES" in self.transfer_cfg or "NODE" in self.transfer_cfg:
+            # nn.KLDivLoss() default reduction: mean over all elements
+            losses.append(F.kl_div(tg_nodes.softmax(-1).log(), sr[tg_labels.long()].softmax(-1), reduction="mean"))
+        if "ADJ" in self.transfer_cfg:
+            indx = tg_prototype.sum(dim=-1).bool()
+            adj_sr = sim_matrix(sr[indx], sr[indx]).view(1, -1)
+            adj_tg = sim_matrix(tg_prototype[indx], tg_prototype[indx]).view(1, -1)
+            losses.append(F.cosine_embedding_loss(adj_sr, adj_tg, adj_sr.new_ones(1), margin=0.0))
+        return sum(losses) if losses else None
+
+    def _forward_train_target(self, feats, shape):
+        """reference condgraph.py:500-534 (GCN_SELF_TRAINING False): act maps with the conditioned kernels (HIP),
+        DBSCAN node sampling (host), graph aggregation + GST losses (torch tier)."""
+        kernels = self.get_conded_weight()
+        _, maps, out = self._act_and_out(feats, shape, kernels)
+        pts, labs = sample_target_nodes(feats, maps, shape, self.dbscan_eps, self.dbscan_thr)
+        if pts is not None and self.transfer_cfg and self.transfer_cfg[0] is not None:
+            _, tg_proto = self._forward_gcns(pts, labs)
+            tl = self.get_transfer_loss(tg_proto, pts, labs)
+            if tl is not None:
+                tl = self.lamda3 * tl
+            return out, (None, tl), None, maps
+        return out, None, None, maps
+
     def forward(self, rows, shape, targets=None, mode="source", forward_target=False):
         """-> feats [M,256], (node_loss, transfer_loss) or None, act_loss or None, act_maps [M,K]."""
         feats = self.head_in(rows, shape)
@@ -214,8 +296,7 @@ class GRAPHModule(nn.Module):
             act_loss = self.lamda2 * self.act_loss_func(logits, labels.long())
             return out, (node_loss, 0), act_loss, maps
         if self.training and mode == "target" and forward_target:
-            raise NotImplementedError("target-domain node sampling (DBSCAN + GST losses, reference "
-                                      "loss.py:397-518, condgraph.py:457-534) is a later SURVEY 8 row")
+            return self._forward_train_target(feats, shape)
         kernels = self.get_conded_weight()
         _, maps, out = self._act_and_out(feats, shape, kernels)
         return out, None, None, maps

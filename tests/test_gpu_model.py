@@ -139,3 +139,34 @@ def test_two_steps_run_and_update(device):
         assert all(torch.isfinite(v).item() for v in losses.values())
     assert not torch.equal(before, trainer.groups["fcos"].flat_p)
     assert trainer.groups["backbone"].flat_m.abs().sum().item() > 0
+
+
+def test_step_with_target_sampling_matches_reference(device, gold_dir):
+    """forward_target=True: DBSCAN target-node sampling (host) + GST consistency loss (reference loss.py:397-518,
+    condgraph.py:457-534) in the fp32-MFMA mode; golden captured at 2 x 256x512."""
+    from scan_amd import engine, ops, synth
+    gold = json.load(open(os.path.join(gold_dir, "step_ft_256x512.json")))
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    for mode in ("fp32", "bf16x3"):
+        ops.CONV_MODE = mode
+        try:
+            model = engine.build_model(9, device=device, attn_dropout=0.0)
+            engine.load_procedural_weights(model)
+            trainer = engine.Trainer(model)
+            for g in trainer.groups.values():
+                g.lr = 0.0
+            losses = trainer.step(synth.synth_images(N, H, W, gold["seeds"]["src"]).to(device),
+                                  synth.synth_targets(N, H, W, 8, 12, gold["seeds"]["boxes"]),
+                                  synth.synth_images(N, H, W, gold["seeds"]["tgt"]).to(device), forward_target=True)
+        finally:
+            ops.CONV_MODE = "bf16x3"
+        assert "consistency_loss_gt" in losses
+        for k, ref in gold["losses"].items():
+            v = float(losses[k])
+            if ref == 0.0:
+                assert v == 0.0
+            else:
+                assert abs(v - ref) <= LOSS_RTOL * abs(ref), (mode, k, v, ref)
+        ref = gold["grad_digest"]["middle_head"]["multihead_attn.linear_q.weight"]
+        mine = _digest(model["middle_head"].multihead_attn.linear_q.weight.grad)
+        assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1]

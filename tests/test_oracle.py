@@ -101,3 +101,18 @@ def test_inference_oracle_vs_reference(gold_dir):
         assert np.array_equal(l.numpy()[o1], rl[o2])
         np.testing.assert_allclose(s.numpy()[o1], rs[o2], atol=1e-5)
         np.testing.assert_allclose(b.numpy()[o1], rb[o2], atol=1e-3)
+
+
+def test_da_iteration_with_target_sampling_oracle_vs_reference(gold_dir):
+    """forward_target=True (DBSCAN sampling + GST losses) against the reference's loss dict."""
+    gold = json.load(open(os.path.join(gold_dir, "step_ft_256x512.json")))
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    sds, P = _params()
+    st = scan_ref.PrototypeState(sds["middle_head"]["prototype"])
+    out = scan_ref.da_iteration(P, st, synth.synth_images(N, H, W, 1234), synth.synth_targets(N, H, W, 8, 12, 4321),
+                                synth.synth_images(N, H, W, 2234), forward_target=True)
+    assert gold["forward_target"] and "consistency_loss_gt" in out
+    for k, ref in gold["losses"].items():
+        if k == "zero_gt":
+            continue
+        assert abs(out[k] - ref) <= 1e-5 * abs(ref), (k, out[k], ref)

@@ -347,8 +347,11 @@ extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int3
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define WROW 160  // bf16 elements per LDS row
-#define WK 32     // pixels per K chunk
-#define WBUF ((WK + WK + 2) * 2 * WROW)  // bf16 elements per LDS buffer: dY hi/lo [32], X hi/lo [34]
+#define WK 64     // pixels per K chunk (one image-row segment): ~2 us of MFMA work per chunk, enough to cover the
+                  // HBM latency of the next chunk's loads, which are prefetched into registers meanwhile
+#define WNA (WK / 16)             // dY float4 per thread per chunk
+#define WNB ((WK + 2 + 15) / 16)  // X float4 per thread per chunk (1-pixel halo each side)
+#define WBUF ((WK + WK + 2) * 2 * WROW)  // bf16 elements of the LDS stage: dY hi/lo [WK], X hi/lo [WK + 2]
 
 struct ChunkTab {
   long long chunk_off[SCAN_MAX_LEVELS + 1];
@@ -392,9 +395,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
   if (ch_end > total_chunks) ch_end = total_chunks;
   const bool do_bias = (bias_slab != nullptr) && ky == 1 && c_tile == 0;
 
-  // staging roles: float4 column q4, pixel rows rr and rr + 16 (A); X rows rr, rr + 16, (rr + 32 for rr < 2)
+  // staging roles: float4 column q4, pixel rows rr + 16 i
   const int q4 = tid & 31, rr = tid >> 5;
-  float4 ra[2], rb[3];
+  float4 ra[WNA], rb[WNB];
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_chunk = [&](long long ch) {
     int lvl = 0;
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     const long long rowbase = d.row_off[lvl] + row * W;
     const int o = o0 + 4 * q4, c = c0 + 4 * q4;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WNA; ++i) {
       const int k = rr + 16 * i;
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (x0 + k < W) {
@@ -429,21 +432,21 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     const bool yok = yy >= 0 && yy < H && c < Cs;
     const long long xrow = rowbase + (long long)(ky - 1) * W;
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < WNB; ++i) {
       const int j = rr + 16 * i;
       const int xx = x0 - 1 + j;
       rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j < WK + 2 && yok && xx >= 0 && xx < W) rb[i] = *reinterpret_cast<const float4*>(x + (xrow + xx) * Cs + c);
     }
   };
-  auto store_chunk = [&](int buf) {
-    __bf16* Ah = sm + buf * WBUF;
+  auto store_chunk = [&]() {
+    __bf16* Ah = sm;
     __bf16* Al = Ah + WK * WROW;
     __bf16* Bh = Al + WK * WROW;
     __bf16* Bl = Bh + (WK + 2) * WROW;
     bf16x4 hi, lo;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WNA; ++i) {
       const int off = (rr + 16 * i) * WROW + 4 * q4;
       split4(ra[i], hi, lo);
       *reinterpret_cast<bf16x4*>(Ah + off) = hi;
@@ -456,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
       }
     }
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < WNB; ++i) {
       const int j = rr + 16 * i;
       if (j < WK + 2) {
         const int off = j * WROW + 4 * q4;
@@ -482,21 +485,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  if (ch_begin < ch_end) {
-    load_chunk(ch_begin);
-    store_chunk(0);
-  }
-  __syncthreads();
+  // One LDS stage; the next chunk is prefetched into registers while this one computes and is converted /
+  // written after the barrier that retires the current chunk.
+  if (ch_begin < ch_end) load_chunk(ch_begin);
+  const __bf16* Ah = sm;
+  const __bf16* Al = Ah + WK * WROW;
+  const __bf16* Bh = Al + WK * WROW;
+  const __bf16* Bl = Bh + (WK + 2) * WROW;
   for (long long ch = ch_begin; ch < ch_end; ++ch) {
-    const int buf = (int)((ch - ch_begin) & 1);
-    const bool more = ch + 1 < ch_end;
-    if (more) load_chunk(ch + 1);
-    const __bf16* Ah = sm + buf * WBUF;
-    const __bf16* Al = Ah + WK * WROW;
-    const __bf16* Bh = Al + WK * WROW;
-    const __bf16* Bl = Bh + (WK + 2) * WROW;
+    store_chunk();
+    if (ch + 1 < ch_end) load_chunk(ch + 1);
+    __syncthreads();
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < WK / 16; ++s) {
       bf16x8 ah[2], al[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
@@ -517,8 +518,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
         }
       }
     }
-    if (more) store_chunk(buf ^ 1);
-    __syncthreads();
+    __syncthreads();  // every wave is done with this chunk's LDS image
   }
 
   float* out = slab + (long long)split * Nout * 9 * Cs;
@@ -602,7 +602,7 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
   int nt, ctl, sp, cps;
   wgrad3_plan(d, Cs, Cout, &ct, &nt, &ctl, &sp, &cps);
   hipStream_t st = as_stream(stream);
-  const size_t sh = (size_t)2 * WBUF * sizeof(__bf16);
+  const size_t sh = (size_t)WBUF * sizeof(__bf16);
   static bool done = false;
   if (!done) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16x3_kernel),

@@ -30,6 +30,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #define PW (TW + 2)
 #define CK 32             // channels per K chunk
 #define LROW 40           // bf16 elements per LDS row (32 data + 8 pad = 80 B)
+#define PPITCH 768        // bf16 elements per halo-patch ROW of 18 pixels: 1440 B of data padded to 1536 B, so a
+                          // fragment read that spans two tile rows (lanes 0-15 / 16-31) stays on 16 distinct
+                          // 16-byte slots (5 * pixel mod 16 is a bijection only if the row step is 0 mod 16 slots)
 
 struct TileTab {
   int tile_off[SCAN_MAX_LEVELS + 1];
@@ -71,9 +74,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
   constexpr int BSEG = BN * 4 * 2 / NT;           // 16-byte weight segments per thread per (chunk, tap)
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  __bf16* Ah = reinterpret_cast<__bf16*>(smem_raw);  // [NPATCH][LROW]
-  __bf16* Al = Ah + NPATCH * LROW;                   // [NPATCH][LROW]
-  __bf16* Bs = Al + NPATCH * LROW;                   // [2 buf][2 plane][BN][LROW]
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem_raw);  // [PH][PPITCH]
+  __bf16* Al = Ah + PH * PPITCH;                     // [PH][PPITCH]
+  __bf16* Bs = Al + PH * PPITCH;                     // [2 buf][2 plane][BN][LROW]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int bid = xcd_remap3(blockIdx.x, gridDim.x);
@@ -114,10 +117,11 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
       const int slot = tid + NT * i;
       if (slot < NPATCH * 8) {
         const int q = slot >> 3, c4 = slot & 7;
+        const int py = q / PW, px = q - py * PW;
         bf16x4 hi, lo;
         split4(ra[i], hi, lo);
-        *reinterpret_cast<bf16x4*>(Ah + q * LROW + 4 * c4) = hi;
-        *reinterpret_cast<bf16x4*>(Al + q * LROW + 4 * c4) = lo;
+        *reinterpret_cast<bf16x4*>(Ah + py * PPITCH + px * LROW + 4 * c4) = hi;
+        *reinterpret_cast<bf16x4*>(Al + py * PPITCH + px * LROW + 4 * c4) = lo;
       }
     }
   };
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
 #pragma unroll
   for (int tm = 0; tm < TM; ++tm) {
     const int p = (wm * TM + tm) * 32 + lr;  // pixel within the 8x16 tile
-    a_off[tm] = ((p >> 4) * PW + (p & 15)) * LROW + 8 * lh;
+    a_off[tm] = (p >> 4) * PPITCH + (p & 15) * LROW + 8 * lh;
   }
   const int b_off = (wn * 64 + lr) * LROW + 8 * lh;
 
@@ -182,7 +186,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
         load_b(cc + 1, 0);
       __syncthreads();
       const int ky = tap / 3, kx = tap - 3 * ky;
-      const int shift = (ky * PW + kx) * LROW;
+      const int shift = ky * PPITCH + kx * LROW;
       const __bf16* bh = Bs + (buf * 2 + 0) * BN * LROW + b_off;
       const __bf16* bl = Bs + (buf * 2 + 1) * BN * LROW + b_off;
 #pragma unroll
@@ -305,7 +309,7 @@ extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int3
     make_tiles(d, &tt, 16);
     const int tiles = tt.tile_off[d->n_levels];
     const int n_tiles = (Nout + 127) / 128;
-    const size_t sh = (size_t)(2 * 18 * PW * LROW + 4 * 128 * LROW) * sizeof(__bf16);
+    const size_t sh = (size_t)(2 * 18 * PPITCH + 4 * 128 * LROW) * sizeof(__bf16);
     static bool done = false;
     if (!done) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16x3_kernel<128, 16, 512>),
@@ -317,7 +321,7 @@ extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int3
   } else {
     make_tiles(d, &tt, 8);
     const int tiles = tt.tile_off[d->n_levels];
-    const size_t sh = (size_t)(2 * 10 * PW * LROW + 4 * 64 * LROW) * sizeof(__bf16);
+    const size_t sh = (size_t)(2 * 10 * PPITCH + 4 * 64 * LROW) * sizeof(__bf16);
     hipLaunchKernelGGL((conv3x3_bf16x3_kernel<64, 8, 256>), dim3(tiles), dim3(256), sh, st, x, *d, Cs, h, l, Csw, bias,
                        mask, y, Nout, Ns, relu, tt, 1);
   }

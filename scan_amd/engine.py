@@ -143,6 +143,11 @@ class Trainer:
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.comm_stream = torch.cuda.Stream() if self.distributed else None
         self._pending = []
+        # The five CKA discriminators are independent; P4..P7 have 16 K ... 256 pixel rows, far too few tiles to
+        # fill 256 CUs, so they run on side HIP streams next to P3 (autograd replays each backward on the stream
+        # of its forward, so the backward overlaps the same way).
+        self.dis_streams = {lvl: torch.cuda.Stream() for lvl in ("P4", "P5", "P6", "P7")} \
+            if next(iter(model.values())).parameters().__next__().is_cuda else {}
 
     def _allreduce_async(self, keys):
         """all-reduce the flat gradient buffers of sub-models whose gradients are final, on the side stream."""
@@ -155,6 +160,26 @@ class Trainer:
                 g = self.groups[k].flat_g
                 g.div_(ws)
                 self._pending.append(dist.all_reduce(g, async_op=True))
+
+    def _discriminators(self, feats, maps, shape, label, domain, tag):
+        """con_dis_lambda * dis_CON(feat[l], label, act_maps[l]) for the five levels (reference trainer.py:314-333,
+        373-376); the small levels run concurrently on side streams."""
+        main = torch.cuda.current_stream()
+        ld = {}
+        for lvl in DIS_ORDER:
+            i = LEVELS.index(lvl)
+            side = self.dis_streams.get(lvl)
+            if side is None:
+                ld["loss_adv_%s_CON_%s" % (lvl, tag)] = self.con_dis_lambda * self.model["dis_%s_CON" % lvl](
+                    feats[lvl], label, maps[lvl], domain=domain, shape=shape.level(i))
+                continue
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                ld["loss_adv_%s_CON_%s" % (lvl, tag)] = self.con_dis_lambda * self.model["dis_%s_CON" % lvl](
+                    feats[lvl], label, maps[lvl], domain=domain, shape=shape.level(i))
+        for side in self.dis_streams.values():
+            main.wait_stream(side)
+        return ld
 
     def step(self, images_s, targets_s, images_t, forward_target=False):
         """One DA iteration; returns the loss dict (0-dim GPU tensors, reference key names)."""
@@ -170,11 +195,7 @@ class Trainer:
         sum(loss_dict.values()).backward(retain_graph=True)
         out.update(loss_dict)
         # (2) discriminators on source (GRL pushes -lambda*grad into backbone / middle head)
-        ld = {}
-        for lvl in DIS_ORDER:
-            i = LEVELS.index(lvl)
-            ld["loss_adv_%s_CON_ds" % lvl] = lam * model["dis_%s_CON" % lvl](
-                feat_s[lvl], 1.0, maps_s[lvl], domain="source", shape=shape.level(i))
+        ld = self._discriminators(feat_s, maps_s, shape, 1.0, "source", "ds")
         sum(ld.values()).backward()
         out.update(ld)
         del loss_dict, feat_s, maps_s
@@ -183,10 +204,7 @@ class Trainer:
         loss_dict, feat_t, maps_t, shape = forward_detector(model, images_t, None, mode="target",
                                                             forward_target=forward_target)
         ld = {k + "_gt": v for k, v in loss_dict.items()}
-        for lvl in DIS_ORDER:
-            i = LEVELS.index(lvl)
-            ld["loss_adv_%s_CON_dt" % lvl] = lam * model["dis_%s_CON" % lvl](
-                feat_t[lvl], 0.0, maps_t[lvl], domain="target", shape=shape.level(i))
+        ld.update(self._discriminators(feat_t, maps_t, shape, 0.0, "target", "dt"))
         sum(v for k, v in ld.items() if k != "zero_gt").backward()
         out.update(ld)
         self._allreduce_async([k for k in self.groups if k != "fcos"])

@@ -146,8 +146,10 @@ class Trainer:
         # The five CKA discriminators are independent; P4..P7 have 16 K ... 256 pixel rows, far too few tiles to
         # fill 256 CUs, so they run on side HIP streams next to P3 (autograd replays each backward on the stream
         # of its forward, so the backward overlaps the same way).
-        self.dis_streams = {lvl: torch.cuda.Stream() for lvl in ("P4", "P5", "P6", "P7")} \
-            if next(iter(model.values())).parameters().__next__().is_cuda else {}
+        on_gpu = next(next(iter(model.values())).parameters()).is_cuda
+        self.dis_streams = {lvl: torch.cuda.Stream() for lvl in ("P4", "P5", "P6", "P7")} if on_gpu else {}
+        self.tgt_stream = torch.cuda.Stream() if on_gpu else None
+        self.overlap_target = True
 
     def _allreduce_async(self, keys):
         """all-reduce the flat gradient buffers of sub-models whose gradients are final, on the side stream."""
@@ -192,6 +194,15 @@ class Trainer:
         # (1) generator on source
         loss_dict, feat_s, maps_s, shape = forward_detector(model, images_s, targets_s, mode="source")
         loss_dict = {k + "_gs": v for k, v in loss_dict.items()}
+        # (3a) the target forward does not depend on the source backward passes (parameters are only updated
+        # at the end of the iteration, the paradigm buffer was updated by the source forward): issue it now on a
+        # side stream so it fills the tails of the source backward kernels
+        tgt = None
+        if self.overlap_target and self.tgt_stream is not None:
+            main = torch.cuda.current_stream()
+            self.tgt_stream.wait_stream(main)
+            with torch.cuda.stream(self.tgt_stream):
+                tgt = forward_detector(model, images_t, None, mode="target", forward_target=forward_target)
         sum(loss_dict.values()).backward(retain_graph=True)
         out.update(loss_dict)
         # (2) discriminators on source (GRL pushes -lambda*grad into backbone / middle head)
@@ -201,8 +212,11 @@ class Trainer:
         del loss_dict, feat_s, maps_s
         self._allreduce_async(["fcos"])  # the target pass adds nothing to the FCOS head
         # (3) target pass + discriminators on target
-        loss_dict, feat_t, maps_t, shape = forward_detector(model, images_t, None, mode="target",
-                                                            forward_target=forward_target)
+        if tgt is None:
+            tgt = forward_detector(model, images_t, None, mode="target", forward_target=forward_target)
+        else:
+            torch.cuda.current_stream().wait_stream(self.tgt_stream)
+        loss_dict, feat_t, maps_t, shape = tgt
         ld = {k + "_gt": v for k, v in loss_dict.items()}
         ld.update(self._discriminators(feat_t, maps_t, shape, 0.0, "target", "dt"))
         sum(v for k, v in ld.items() if k != "zero_gt").backward()

@@ -85,6 +85,9 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=2, help="source (= target) frames per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial-streams", action="store_true",
+                    help="run everything on one stream (no side-stream overlap): what the per-kernel roofline "
+                         "figures and the rocprof summaries under profiles/ are taken with")
     a = ap.parse_args()
 
     import torch
@@ -104,6 +107,17 @@ def main():
     model = engine.build_model(9, device=dev)
     engine.load_procedural_weights(model)
     trainer = engine.Trainer(model)
+
+    def set_serial(flag):
+        trainer.overlap_target = not flag
+        if flag:
+            trainer._saved_dis = trainer.dis_streams
+            trainer.dis_streams = {}
+        elif hasattr(trainer, "_saved_dis"):
+            trainer.dis_streams = trainer._saved_dis
+
+    if a.serial_streams:
+        set_serial(True)
     H, W, B = a.height, a.width, a.batch
     imgs_s = synth.synth_images(B, H, W, 1234 + 100 * rank).to(dev)
     imgs_t = synth.synth_images(B, H, W, 2234 + 100 * rank).to(dev)
@@ -117,13 +131,23 @@ def main():
     for _ in range(a.warmup):
         trainer.step(imgs_s, tg, imgs_t)
     barrier()
-    ops.kernel_timer.enabled = True
-    ops.kernel_timer.reset()
     t0 = time.time()
     for _ in range(a.steps):
         losses = trainer.step(imgs_s, tg, imgs_t)
     barrier()
     dt = time.time() - t0
+    # per-kernel roofline figures: HIP events around every conv launch on its stream.  With the side-stream overlap
+    # of the timed region an event pair also spans whatever co-runs on the other streams, so the kernels are timed
+    # in two extra steps with the overlap switched off (same kernels, same shapes; rocprof: profiles/*serial*).
+    set_serial(True)
+    ops.kernel_timer.enabled = True
+    ops.kernel_timer.reset()
+    roof_steps = 2
+    t0r = time.time()
+    for _ in range(roof_steps):
+        trainer.step(imgs_s, tg, imgs_t)
+    torch.cuda.synchronize()
+    dtr = time.time() - t0r
     ops.kernel_timer.enabled = False
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -145,8 +169,12 @@ def main():
                     "peak_note": "algorithmic fp32-equivalent FLOPs; bf16x3 kernels spend 3 bf16 MFMAs per product, "
                                  "peak = 2.5 PFLOP/s dense bf16 / 3",
                     "launches": r["launches"], "avg_launch_ms": round(r["avg_ms"], 4),
+                    "measured": "HIP events on the launch stream, %d steps with side-stream overlap off "
+                                "(%.1f ms/step serial vs %.1f ms/step overlapped)" % (roof_steps, dtr / roof_steps * 1e3,
+                                                                                     dt / a.steps * 1e3),
                     "all_conv_kernels": {k: {"tflops": round(v["tflops"], 2), "avg_ms": round(v["avg_ms"], 4),
-                                             "launches": v["launches"], "share_of_step": round(v["total_ms"] / (dt * 1e3), 3)}
+                                             "launches": v["launches"],
+                                             "share_of_serial_step": round(v["total_ms"] / (dtr * 1e3), 3)}
                                          for k, v in ksum.items()}}
         cpu = None
         if not a.no_cpu_baseline:

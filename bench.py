@@ -99,14 +99,17 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # started by torch.distributed.run
+    if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
     from scan_amd import engine, ops, synth
     model = engine.build_model(9, device=dev)
     engine.load_procedural_weights(model)
-    trainer = engine.Trainer(model)
+    # under torch.distributed.run the data-parallel path (flat-buffer all-reduce on the side stream, paradigm
+    # all-reduce) is exercised even with a single rank
+    trainer = engine.Trainer(model, distributed=True if dist.is_initialized() else None)
 
     def set_serial(flag):
         trainer.overlap_target = not flag
@@ -124,7 +127,7 @@ def main():
     tg = [(b.to(dev), l.to(dev)) for b, l in synth.synth_targets(B, H, W, 8, 12, 4321 + 100 * rank)]
 
     def barrier():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +199,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

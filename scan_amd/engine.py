@@ -183,6 +183,16 @@ class Trainer:
             main.wait_stream(side)
         return ld
 
+    def _join_streams(self):
+        """Backward kernels that accumulate straight into the flat gradient buffers run on the stream of their
+        forward op and bypass autograd's AccumulateGrad (and with it the engine's end-of-backward stream sync):
+        make the main stream wait for every side stream before gradients are reduced / consumed."""
+        main = torch.cuda.current_stream()
+        for s in self.dis_streams.values():
+            main.wait_stream(s)
+        if self.tgt_stream is not None:
+            main.wait_stream(self.tgt_stream)
+
     def step(self, images_s, targets_s, images_t, forward_target=False):
         """One DA iteration; returns the loss dict (0-dim GPU tensors, reference key names)."""
         model, lam = self.model, self.con_dis_lambda
@@ -208,6 +218,7 @@ class Trainer:
         # (2) discriminators on source (GRL pushes -lambda*grad into backbone / middle head)
         ld = self._discriminators(feat_s, maps_s, shape, 1.0, "source", "ds")
         sum(ld.values()).backward()
+        self._join_streams()
         out.update(ld)
         del loss_dict, feat_s, maps_s
         self._allreduce_async(["fcos"])  # the target pass adds nothing to the FCOS head
@@ -220,6 +231,7 @@ class Trainer:
         ld = {k + "_gt": v for k, v in loss_dict.items()}
         ld.update(self._discriminators(feat_t, maps_t, shape, 0.0, "target", "dt"))
         sum(v for k, v in ld.items() if k != "zero_gt").backward()
+        self._join_streams()
         out.update(ld)
         self._allreduce_async([k for k in self.groups if k != "fcos"])
         if self.distributed:

@@ -221,7 +221,7 @@ class GRAPHModule(nn.Module):
         """reference condgraph.py:586-606 with COSINE_UPDATE_ON."""
         it = self.counter_rnn()
         pb = proto_batch.detach()
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized():
             # data parallel (SURVEY.md 8e (ii)): average the per-rank class means over the ranks that saw
             # the class, so the paradigm buffer stays identical on every rank (9 x 257 floats)
             ex = pb.sum(-1).bool().to(pb.dtype)[:, None]

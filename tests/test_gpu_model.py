@@ -170,3 +170,27 @@ def test_step_with_target_sampling_matches_reference(device, gold_dir):
         ref = gold["grad_digest"]["middle_head"]["multihead_attn.linear_q.weight"]
         mine = _digest(model["middle_head"].multihead_attn.linear_q.weight.grad)
         assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1]
+
+
+def test_stream_overlap_is_race_free(device):
+    """the side-stream schedule (P4..P7 discriminators, target forward) must give the same parameters after two
+    full iterations as the single-stream schedule."""
+    from scan_amd import engine, synth
+    res = []
+    for overlap in (False, True):
+        model = engine.build_model(9, device=device, attn_dropout=0.0)
+        engine.load_procedural_weights(model)
+        trainer = engine.Trainer(model)
+        if not overlap:
+            trainer.dis_streams = {}
+            trainer.overlap_target = False
+        imgs_s = synth.synth_images(2, 256, 512, 11).to(device)
+        imgs_t = synth.synth_images(2, 256, 512, 12).to(device)
+        tg = synth.synth_targets(2, 256, 512, 8, 8, 13)
+        for _ in range(2):
+            trainer.step(imgs_s, tg, imgs_t)
+        torch.cuda.synchronize()
+        res.append({k: g.flat_p.clone() for k, g in trainer.groups.items()})
+    for k in res[0]:
+        a, b = res[0][k], res[1][k]
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (k, (a - b).abs().max().item())

@@ -250,6 +250,10 @@ def main():
         gen_pointwise(a.check)
     if "step" in todo:
         gen_step(a.check)
+    if "step_ragged" in todo:  # sizes that are multiples of 32 but not of the 8x16 / 16x16 kernel tiles
+        gen_step(a.check, H=160, W=224, N=1, name="step_ragged_160x224")
+    if "step_cfg1" in todo:  # BASELINE.json configs[0]: one 800x1600 frame
+        gen_step(a.check, H=800, W=1600, N=1, name="step_cfg1_800x1600")
     if "step_ft" in todo:
         gen_step(a.check, H=256, W=512, name="step_ft_256x512", forward_target=True)
     if "inference" in todo:

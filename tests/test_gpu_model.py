@@ -194,3 +194,38 @@ def test_stream_overlap_is_race_free(device):
     for k in res[0]:
         a, b = res[0][k], res[1][k]
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (k, (a - b).abs().max().item())
+
+
+@pytest.mark.parametrize("name", ["step_ragged_160x224", "step_cfg1_800x1600"])
+def test_step_other_sizes_match_reference(device, gold_dir, name):
+    """ragged level sizes (20x28 ... 2x2: partial kernel tiles everywhere) and BASELINE.json configs[0]
+    (one 800x1600 frame: 100x200, 50x100, 25x50, 13x25, 7x13), both conv modes, all losses within 1e-4."""
+    from scan_amd import engine, ops, synth
+    gold = json.load(open(os.path.join(gold_dir, name + ".json")))
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    for mode in ("fp32", "bf16x3"):
+        ops.CONV_MODE = mode
+        try:
+            model = engine.build_model(9, device=device, attn_dropout=0.0)
+            engine.load_procedural_weights(model)
+            trainer = engine.Trainer(model)
+            for g in trainer.groups.values():
+                g.lr = 0.0
+            losses = trainer.step(synth.synth_images(N, H, W, gold["seeds"]["src"]).to(device),
+                                  synth.synth_targets(N, H, W, 8, 12, gold["seeds"]["boxes"]),
+                                  synth.synth_images(N, H, W, gold["seeds"]["tgt"]).to(device))
+            torch.cuda.synchronize()
+        finally:
+            ops.CONV_MODE = "bf16x3"
+        for k, ref in gold["losses"].items():
+            v = float(losses[k])
+            if ref == 0.0:
+                assert v == 0.0
+            else:
+                assert abs(v - ref) <= LOSS_RTOL * abs(ref), (mode, k, v, ref)
+        for mk, name_ in (("backbone", "body.features.28.weight"), ("fcos", "head.cls_tower.0.weight"),
+                          ("middle_head", "head_out.middle_tower.0.weight"), ("dis_P3_CON", "dis_tower.0.weight")):
+            ref = gold["grad_digest"][mk][name_]
+            p = dict(model[mk].named_parameters())[name_]
+            mine = _digest(p.grad)
+            assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mode, mk, name_, mine[1], ref[1])

@@ -147,3 +147,31 @@ def test_prototype_update_matches_reference(gold_dir):
         k = mh.get_conded_weight()
         kr = scan_ref.conded_weight(scan_ref.params(sd, requires_grad=False), st.prototype)
     assert torch.allclose(k, kr, rtol=1e-4, atol=1e-6)
+
+
+def test_checkpoint_wire_format(tmp_path):
+    """reference DetectronCheckpointer layout: one .pth with model_backbone / model_fcos / middle_head /
+    model_dis_P*_CON state_dicts, a last_checkpoint tag file, suffix-matched loading (ImageNet VGG keys)."""
+    from scan_amd import checkpoint
+    model = engine.build_model(9, device="cpu")
+    engine.load_procedural_weights(model)
+    path = checkpoint.save(model, str(tmp_path), "model_final", iteration=123)
+    assert checkpoint.get_checkpoint_file(str(tmp_path)) == path
+    raw = torch.load(path)
+    assert set(raw) == {"model_backbone", "model_fcos", "middle_head", "iteration"} | {"model_dis_P%d_CON" % i for i in range(3, 8)}
+    assert "body.features.0.weight" in raw["model_backbone"] and "prototype" in raw["middle_head"]
+    fresh = engine.build_model(9, device="cpu")
+    rest = checkpoint.load(fresh, path, load_dis=False)
+    assert rest["iteration"] == 123
+    a, b = model["fcos"].state_dict(), fresh["fcos"].state_dict()
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert torch.equal(model["middle_head"].prototype, fresh["middle_head"].prototype)
+    assert not torch.equal(model["dis_P3_CON"].dis_tower[0].weight, fresh["dis_P3_CON"].dis_tower[0].weight)  # load_dis=False
+    assert fresh["backbone"].body.features[10].weight.permute(0, 2, 3, 1).is_contiguous()  # re-homed channels-last
+    # ImageNet-style VGG file: keys "features.N.*" fill "body.features.N.*"; DDP "module." prefix is stripped
+    vgg = {"module." + k[len("body."):]: v + 1 for k, v in synth.backbone_state_dict().items() if k.startswith("body.")}
+    vpath = os.path.join(str(tmp_path), "vgg16.pth")
+    torch.save(vgg, vpath)
+    checkpoint.load(fresh, vpath)
+    assert torch.equal(fresh["backbone"].body.features[0].weight, synth.backbone_state_dict()["body.features.0.weight"] + 1)
+    assert torch.equal(fresh["backbone"].fpn.fpn_inner3.weight, model["backbone"].fpn.fpn_inner3.weight)  # untouched

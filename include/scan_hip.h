@@ -186,6 +186,13 @@ int scan_groupnorm_relu_backward(const float* x, const float* y, const float* dy
                                  int32_t G, const float* stats, const float* gamma, int32_t relu, float* dx,
                                  float* dgamma, float* dbeta, int32_t accumulate, float* ws, void* stream);
 
+/* ---- 2x2 / stride-2 max pooling on NHWC rows (replaces nn.MaxPool2d(2, 2) of the VGG body,
+ *      backbone/mmdetection/vgg.py:33).  x [N,H,W,C], y [N,H/2,W/2,C]; H, W even, C % 4 == 0.
+ *      backward routes the gradient to the first maximum of each window (F.max_pool2d's rule). ---- */
+int scan_maxpool2x2_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream);
+int scan_maxpool2x2_backward(const float* x, const float* y, const float* dy, int32_t N, int32_t H, int32_t W,
+                             int32_t C, float* dx, void* stream);
+
 /* ---- fused SGD with momentum (replaces torch.optim.SGD as configured by solver/build.py:7-43) ----
  * g' = g + wd*p ; buf = momentum*buf + g' ; p -= lr*buf   (first_step != 0: buf = g') */
 int scan_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float wd, float momentum,

@@ -438,3 +438,90 @@ extern "C" int scan_sgd_momentum(float* p, const float* g, float* buf, int64_t n
   SCAN_LAUNCH_CHECK("sgd");
   return 0;
 }
+
+// ------------------------------------------------------------------ 2x2 / stride-2 max pooling on NHWC rows
+// (replaces nn.MaxPool2d(2, 2) of the VGG body, reference backbone/mmdetection/vgg.py:33).  HBM-bound:
+// forward reads 4 and writes 1 float4 per lane; backward re-derives the argmax (first maximum in window
+// order, like F.max_pool2d) from x and y instead of storing indices.
+__global__ __launch_bounds__(256) void maxpool2_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+                                                           float* __restrict__ y) {
+  const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const float4* b = reinterpret_cast<const float4*>(x + (((int64_t)n * H + 2 * yo) * W + 2 * xo) * C) + c4;
+    const float4 a0 = b[0], a1 = b[C4], a2 = b[(int64_t)W * C4], a3 = b[(int64_t)W * C4 + C4];
+    float4 m;
+    m.x = fmaxf(fmaxf(a0.x, a1.x), fmaxf(a2.x, a3.x));
+    m.y = fmaxf(fmaxf(a0.y, a1.y), fmaxf(a2.y, a3.y));
+    m.z = fmaxf(fmaxf(a0.z, a1.z), fmaxf(a2.z, a3.z));
+    m.w = fmaxf(fmaxf(a0.w, a1.w), fmaxf(a2.w, a3.w));
+    reinterpret_cast<float4*>(y)[i] = m;
+  }
+}
+
+__device__ __forceinline__ void pool_bwd1(float a0, float a1, float a2, float a3, float m, float g, float& d0,
+                                          float& d1, float& d2, float& d3) {
+  d0 = d1 = d2 = d3 = 0.f;
+  if (a0 == m) d0 = g;
+  else if (a1 == m) d1 = g;
+  else if (a2 == m) d2 = g;
+  else d3 = g;
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                           const float* __restrict__ dy, int N, int H, int W, int C,
+                                                           float* __restrict__ dx) {
+  const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const int64_t off = ((((int64_t)n * H + 2 * yo) * W + 2 * xo) * C) / 4 + c4;
+    const float4* b = reinterpret_cast<const float4*>(x) + off;
+    float4* o = reinterpret_cast<float4*>(dx) + off;
+    const int64_t s1 = C4, s2 = (int64_t)W * C4, s3 = s2 + C4;
+    const float4 a0 = b[0], a1 = b[s1], a2 = b[s2], a3 = b[s3];
+    const float4 m = reinterpret_cast<const float4*>(y)[i];
+    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    float4 d0, d1, d2, d3;
+    pool_bwd1(a0.x, a1.x, a2.x, a3.x, m.x, g.x, d0.x, d1.x, d2.x, d3.x);
+    pool_bwd1(a0.y, a1.y, a2.y, a3.y, m.y, g.y, d0.y, d1.y, d2.y, d3.y);
+    pool_bwd1(a0.z, a1.z, a2.z, a3.z, m.z, g.z, d0.z, d1.z, d2.z, d3.z);
+    pool_bwd1(a0.w, a1.w, a2.w, a3.w, m.w, g.w, d0.w, d1.w, d2.w, d3.w);
+    o[0] = d0;
+    o[s1] = d1;
+    o[s2] = d2;
+    o[s3] = d3;
+  }
+}
+
+extern "C" int scan_maxpool2x2_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y,
+                                       void* stream) {
+  SCAN_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_forward: bad arguments");
+  SCAN_CHECK_ARG((H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0, "maxpool2x2_forward: H, W must be even and C %% 4 == 0");
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, N, H, W, C, y);
+  SCAN_LAUNCH_CHECK("maxpool2_fwd");
+  return 0;
+}
+
+extern "C" int scan_maxpool2x2_backward(const float* x, const float* y, const float* dy, int32_t N, int32_t H,
+                                        int32_t W, int32_t C, float* dx, void* stream) {
+  SCAN_CHECK_ARG(x && y && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_backward: bad arguments");
+  SCAN_CHECK_ARG((H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0, "maxpool2x2_backward: H, W must be even and C %% 4 == 0");
+  const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, y, dy, N, H, W,
+                     C, dx);
+  SCAN_LAUNCH_CHECK("maxpool2_bwd");
+  return 0;
+}

@@ -26,12 +26,8 @@ def conv_holder(cin, cout, k, stride=1):
 
 
 def maxpool2x2(rows, shape):
-    """2x2/2 max-pool of a single-level pyramid (torch glue on the NHWC view)."""
-    (h, w), n = shape.sizes[0], shape.n_images
-    c = rows.shape[1]
-    x = rows.view(n, h // 2, 2, w // 2, 2, c)
-    y = x.amax(dim=(2, 4))
-    return y.reshape(n * (h // 2) * (w // 2), c), PyramidShape(n, [(h // 2, w // 2)])
+    """2x2/2 max-pool of a single-level pyramid (HIP kernel, scan_maxpool2x2_*)."""
+    return ops.maxpool2x2(rows, shape)
 
 
 def upsample2x(rows, shape):

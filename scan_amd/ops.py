@@ -291,6 +291,36 @@ def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None):
     return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s)
 
 
+# ----------------------------------------------------------------------------- 2x2 max pooling
+class _MaxPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, shape):
+        _chk(x)
+        (h, w), n = shape.sizes[0], shape.n_images
+        c = x.shape[1]
+        y = x.new_empty((n * (h // 2) * (w // 2), c))
+        call("scan_maxpool2x2_forward", _ptr(x), n, h, w, c, _ptr(y), _stream())
+        ctx.save_for_backward(x, y)
+        ctx.dims = (n, h, w, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        n, h, w, c = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        call("scan_maxpool2x2_backward", _ptr(x), _ptr(y), _ptr(dy), n, h, w, c, _ptr(dx), _stream())
+        return dx, None
+
+
+def maxpool2x2(x, shape):
+    """2x2/2 max-pool of a single-level pyramid; returns (rows, PyramidShape)."""
+    assert shape.n_levels == 1
+    (h, w) = shape.sizes[0]
+    return _MaxPool2x2.apply(x, shape), PyramidShape(shape.n_images, [(h // 2, w // 2)])
+
+
 # ----------------------------------------------------------------------------- GroupNorm + ReLU
 class _GroupNormReLU(torch.autograd.Function):
     @staticmethod

@@ -382,3 +382,21 @@ def test_sgd_kernel(device):
         opt.step()
         ops.sgd_momentum_(pd, (g * (it + 1)).to(device), buf, 0.01, 1e-4, 0.9, it == 0)
     np.testing.assert_allclose(pd.cpu().numpy(), pr.detach().numpy(), rtol=1e-6, atol=1e-7)
+
+
+def test_maxpool2x2(device):
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 64, 12, 20, generator=g)
+    x[0, :, 0, 0] = x[0, :, 0, 1]  # exact ties inside a window: gradient goes to the first maximum
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    rows, shape = _rows(x, device)
+    rows.requires_grad_(True)
+    y, oshape = ops.maxpool2x2(rows, shape)
+    assert oshape.sizes == [(6, 10)]
+    assert torch.equal(ops.rows_to_nchw(y.detach(), oshape).contiguous().cpu(), yr.detach())
+    y.backward(_rows(gy, device)[0])
+    assert torch.equal(ops.rows_to_nchw(rows.grad, shape).contiguous().cpu(), xr.grad)

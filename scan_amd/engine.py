@@ -150,6 +150,7 @@ class Trainer:
         self.dis_streams = {lvl: torch.cuda.Stream() for lvl in ("P4", "P5", "P6", "P7")} if on_gpu else {}
         self.tgt_stream = torch.cuda.Stream() if on_gpu else None
         self.overlap_target = True
+        self.merge_source_backward = True
 
     def _allreduce_async(self, keys):
         """all-reduce the flat gradient buffers of sub-models whose gradients are final, on the side stream."""
@@ -213,12 +214,18 @@ class Trainer:
             self.tgt_stream.wait_stream(main)
             with torch.cuda.stream(self.tgt_stream):
                 tgt = forward_detector(model, images_t, None, mode="target", forward_target=forward_target)
-        sum(loss_dict.values()).backward(retain_graph=True)
-        out.update(loss_dict)
-        # (2) discriminators on source (GRL pushes -lambda*grad into backbone / middle head)
+        # (2) discriminators on source (GRL pushes -lambda*grad into backbone / middle head).
+        # The reference calls backward twice on the source graph (losses_gs with retain_graph, then the adversarial
+        # losses; trainer.py:299,343).  Gradients are linear in the loss, so ONE backward of the sum leaves exactly
+        # the same accumulated .grad and walks the shared backbone / middle-head graph once instead of twice.
         ld = self._discriminators(feat_s, maps_s, shape, 1.0, "source", "ds")
-        sum(ld.values()).backward()
+        if self.merge_source_backward:
+            (sum(loss_dict.values()) + sum(ld.values())).backward()
+        else:
+            sum(loss_dict.values()).backward(retain_graph=True)
+            sum(ld.values()).backward()
         self._join_streams()
+        out.update(loss_dict)
         out.update(ld)
         del loss_dict, feat_s, maps_s
         self._allreduce_async(["fcos"])  # the target pass adds nothing to the FCOS head

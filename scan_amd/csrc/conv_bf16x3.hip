@@ -550,6 +550,41 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
   }
 }
 
+// weight-slab reduction (float4 columns, splits summed in order) + bias-slab reduction in the extra last block
+__global__ __launch_bounds__(256) void slab_bias_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n,
+                                                               float* __restrict__ dw, const float* __restrict__ bs,
+                                                               int nb, float* __restrict__ db, int accumulate) {
+  const int wblocks = gridDim.x - (db ? 1 : 0);
+  if ((int)blockIdx.x < wblocks) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)wblocks * blockDim.x) {
+      float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int k = 0; k < splits; ++k) {
+        const float4 v = reinterpret_cast<const float4*>(slab + (int64_t)k * n)[i];
+        s.x += v.x;
+        s.y += v.y;
+        s.z += v.z;
+        s.w += v.w;
+      }
+      float4* d = reinterpret_cast<float4*>(dw) + i;
+      if (accumulate) {
+        const float4 o = *d;
+        s.x += o.x;
+        s.y += o.y;
+        s.z += o.z;
+        s.w += o.w;
+      }
+      *d = s;
+    }
+  } else {
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+      float s = 0.f;
+      for (int k = 0; k < splits; ++k) s += bs[(int64_t)k * nb + i];
+      db[i] = accumulate ? db[i] + s : s;
+    }
+  }
+}
+
 __global__ void bias_slab_reduce_kernel(const float* __restrict__ bs, int splits, int n, float* __restrict__ db,
                                         int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -617,12 +652,10 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
   hipLaunchKernelGGL(conv3x3_wgrad_bf16x3_kernel, dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout, Cout_s, ws,
                      bias_slab, ct, nt, ctl, cps, sp);
   SCAN_LAUNCH_CHECK("conv3x3_wgrad_bf16x3");
-  scan_slab_reduce_launch(ws, sp, (int64_t)Cout * 9 * Cs, dw, accumulate, st);
-  SCAN_LAUNCH_CHECK("slab_reduce");
-  if (db) {
-    hipLaunchKernelGGL(bias_slab_reduce_kernel, dim3((Cout + 255) / 256), dim3(256), 0, st, bias_slab, sp, Cout, db,
-                       accumulate);
-    SCAN_LAUNCH_CHECK("bias_slab_reduce");
-  }
+  // one launch reduces the weight slabs and (last block) the bias slabs
+  const int64_t n = (int64_t)Cout * 9 * Cs;
+  hipLaunchKernelGGL(slab_bias_reduce_kernel, dim3(grid_for(n / 4, 256) + (db ? 1 : 0)), dim3(256), 0, st, ws, sp, n, dw,
+                     bias_slab, Cout, db, accumulate);
+  SCAN_LAUNCH_CHECK("slab_bias_reduce");
   return 0;
 }

@@ -197,6 +197,7 @@ class Trainer:
     def step(self, images_s, targets_s, images_t, forward_target=False):
         """One DA iteration; returns the loss dict (0-dim GPU tensors, reference key names)."""
         model, lam = self.model, self.con_dis_lambda
+        ops.SPLIT_EPOCH = (id(self), self.iteration)  # parameters change once per iteration: reuse their bf16 planes
         for m in model.values():
             m.train()
         for g in self.groups.values():

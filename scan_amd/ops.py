@@ -168,7 +168,13 @@ def _round8(c):
     return (c + 7) // 8 * 8
 
 
-def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops):
+# bf16 hi/lo planes of the parameters are valid for one optimizer step: engine.Trainer bumps SPLIT_EPOCH at the
+# start of every iteration and the planes of flat-buffer parameters are reused by the source / target passes.
+SPLIT_EPOCH = None
+_split_cache = {}
+
+
+def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None):
     """wp: packed fp32 weights [O][9][Cs_w].  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
     st = _stream()
     O, T, cs_w = wp.shape
@@ -176,9 +182,24 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
         rows, csw, nout = O, _round8(cs_w), O
     else:
         rows, csw, nout = cs_w, _round8(max(O, cs_src)), cs_w
-    wh = torch.empty((rows, T, csw), dtype=torch.bfloat16, device=x.device)
-    wl = torch.empty_like(wh)
-    call("scan_weight_split", _ptr(wp), O, T, cs_w, mode, _ptr(wh), _ptr(wl), csw, st)
+    hit = None
+    if cache_key is not None and SPLIT_EPOCH is not None:
+        key = (cache_key, mode, csw)
+        hit = _split_cache.get(key)
+        if hit is not None and hit[0] != SPLIT_EPOCH:
+            hit = None
+    if hit is not None:
+        wh, wl = hit[1], hit[2]
+        # planes written on another stream (e.g. the target pass on its side stream) must be complete
+        torch.cuda.current_stream().wait_event(hit[3])
+    else:
+        wh = torch.empty((rows, T, csw), dtype=torch.bfloat16, device=x.device)
+        wl = torch.empty_like(wh)
+        call("scan_weight_split", _ptr(wp), O, T, cs_w, mode, _ptr(wh), _ptr(wl), csw, st)
+        if cache_key is not None and SPLIT_EPOCH is not None:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
     y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
     ev = kernel_timer.begin(name, flops)
     call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), None, _ptr(y), nout,
@@ -203,8 +224,10 @@ class _Conv2d(torch.autograd.Function):
         oshape = shape.conv_out(ksize, stride)
         fast = CONV_MODE == "bf16x3" and ksize == 3 and stride == 1
         flops = 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1]
+        ckey = weight.data_ptr() if getattr(weight, "_scan_flat", False) else None
         if fast:
-            y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s, "conv3x3_bf16x3_fwd", flops)
+            y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s, "conv3x3_bf16x3_fwd", flops,
+                                cache_key=ckey)
         else:
             y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
             ev = kernel_timer.begin("conv_igemm_fwd", flops)
@@ -213,6 +236,7 @@ class _Conv2d(torch.autograd.Function):
             kernel_timer.end(ev)
         ctx.save_for_backward(x, weight, y if relu else None)
         ctx.cfg = (shape, oshape, ksize, stride, relu, cout_s, bias is not None, fast)
+        ctx.ckey = ckey
         # parameters re-homed into a flat gradient buffer (engine.FlatGroup): accumulate straight into it
         ctx.wgrad_buf = ctx.bgrad_buf = None
         if getattr(weight, "_scan_flat", False) and weight.grad is not None and weight.shape[1] == cs \
@@ -238,7 +262,7 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0] and fast:
             dx = _conv3x3_bf16x3(dy, shape, pack_weight(weight, cs), cout, x.shape[0], cout_s, 1, None, False, cs,
-                                 "conv3x3_bf16x3_dgrad", 2.0 * oshape.rows * cout * T * cin)
+                                 "conv3x3_bf16x3_dgrad", 2.0 * oshape.rows * cout * T * cin, cache_key=ctx.ckey)
         elif ctx.needs_input_grad[0]:
             wp = pack_weight(weight, cs)
             wt = x.new_empty((cs, T, cout_s))

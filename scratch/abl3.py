@@ -15,8 +15,8 @@ for name, shape in [('tower N2', ops.PyramidShape(2, [(128, 256), (64, 128), (32
     x = torch.randn(shape.rows, 256, device=dev)
     fl = 2.0 * shape.rows * 256 * 2304
     for rnd in range(3):
-        for cond in (1, 0):
-            if cond: os.environ['SCAN_FWD_COND_LOADS'] = '1'
-            else: os.environ.pop('SCAN_FWD_COND_LOADS', None)
+        for pre in (1, 0):
+            if pre: os.environ['SCAN_FWD_PRE'] = '1'
+            else: os.environ.pop('SCAN_FWD_PRE', None)
             ms = timeit(lambda: ops.conv2d(x, w, None, shape))
-            print(name, 'cond' if cond else 'unc ', '%.3f ms %.1f TF' % (ms, fl / ms / 1e9))
+            print(name, 'pre ' if pre else 'base', '%.3f ms %.1f TF' % (ms, fl / ms / 1e9))

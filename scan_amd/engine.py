@@ -78,8 +78,8 @@ def forward_detector(model, images, targets=None, mode="source", forward_target=
     proposals, proposal_losses = model["fcos"](sizes, feats, shape, targets=targets, act_maps=maps)
     if model["fcos"].training:
         losses.update(proposal_losses)
-        f = {n: feats[shape.row_off[i]:shape.row_off[i + 1]] for i, n in enumerate(LEVELS)}
-        a = {n: maps[shape.row_off[i]:shape.row_off[i + 1]] for i, n in enumerate(LEVELS)}
+        f = dict(zip(LEVELS, ops.split_levels(feats, shape)))
+        a = dict(zip(LEVELS, ops.split_levels(maps, shape)))
         return losses, f, a, shape
     return proposals
 

@@ -315,6 +315,30 @@ def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None):
     return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s)
 
 
+# ----------------------------------------------------------------------------- pyramid row split
+class _SplitLevels(torch.autograd.Function):
+    """rows [M, C] -> one view per level.  The backward concatenates the level gradients once instead of
+    autograd's per-slice zero-fill + add of full-size tensors."""
+
+    @staticmethod
+    def forward(ctx, rows, shape):
+        ctx.shape = shape
+        ctx.cols = rows.shape[1]
+        return tuple(rows[shape.row_off[l]:shape.row_off[l + 1]] for l in range(shape.n_levels))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape = ctx.shape
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else ref.new_zeros((shape.row_off[l + 1] - shape.row_off[l], ctx.cols))
+                 for l, g in enumerate(grads)]
+        return torch.cat(parts, 0), None
+
+
+def split_levels(rows, shape):
+    return _SplitLevels.apply(rows, shape)
+
+
 # ----------------------------------------------------------------------------- 2x2 max pooling
 class _MaxPool2x2(torch.autograd.Function):
     @staticmethod

@@ -19,6 +19,7 @@ from . import ops, synth
 from .modeling.backbone import build_backbone
 from .modeling.condgraph import build_condgraph
 from .modeling.discriminator import FCOSDiscriminator_con
+from .modeling import fcos as fcos_mod
 from .modeling.fcos import build_fcos
 
 LEVELS = ("P3", "P4", "P5", "P6", "P7")
@@ -59,10 +60,29 @@ def load_procedural_weights(model, num_classes=9):
 
 
 # ----------------------------------------------------------------------------- forward
+_plan_streams = {}
+
+
+def _plan_stream(device):
+    s = _plan_streams.get(device)
+    if s is None:
+        s = _plan_streams[device] = torch.cuda.Stream(device)
+    return s
+
+
 def forward_detector(model, images, targets=None, mode="source", forward_target=False):
     """reference engine/trainer.py:20-72.  images [N,3,H,W] on the GPU; targets list of (boxes, labels).
     Training: (losses, features{P3..P7: rows}, act_maps{P3..P7: rows}, shape).  Eval: detections."""
+    plan_here = bool(targets) and mode == "source" and model["middle_head"].training and images.is_cuda
+    if plan_here:
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(torch.cuda.current_stream())
     rows, shape = model["backbone"](images)
+    if plan_here:
+        # the backbone is queued (tens of ms of GPU work, ~1 ms of host time): derive everything that depends on
+        # the ground truth alone on a side stream now, so its host round trips hide behind the convolutions
+        fcos_mod.target_plan(shape, targets, images.device, side_stream=_plan_stream(images.device),
+                             after=inputs_ready)
     losses = {}
     feats, loss_graph, loss_act, maps = model["middle_head"](rows, shape, targets=targets, mode=mode,
                                                              forward_target=forward_target)
@@ -198,6 +218,7 @@ class Trainer:
         """One DA iteration; returns the loss dict (0-dim GPU tensors, reference key names)."""
         model, lam = self.model, self.con_dis_lambda
         ops.SPLIT_EPOCH = (id(self), self.iteration)  # parameters change once per iteration: reuse their bf16 planes
+        fcos_mod.reset_target_plan()
         for m in model.values():
             m.train()
         for g in self.groups.values():

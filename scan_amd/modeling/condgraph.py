@@ -20,7 +20,7 @@ from torch import nn
 from .. import ops
 from ..layers import FocalLoss, MultiHeadAttention
 from .backbone import conv_holder
-from .fcos import assign_targets, compute_locations, make_tower, run_tower
+from .fcos import make_tower, run_tower, source_node_index, target_plan
 
 
 class PROTOTYPECounter:
@@ -99,28 +99,10 @@ class _RNNParams(nn.Module):
 
 
 def sample_source_nodes(feats, labels, shape):
-    """PrototypeComputation.__call__ source branch (reference loss.py:428-463): per level, positives in
-    row order; negatives = floor(linspace(0, n_neg-2, n_pos)) of the background rows (all of them when
-    n_pos > n_neg); final order [all neg, all pos]."""
-    pos_pts, pos_lab, neg_pts = [], [], []
-    for l in range(shape.n_levels):
-        r0, r1 = shape.row_off[l], shape.row_off[l + 1]
-        lab = labels[r0:r1]
-        f = feats[r0:r1]
-        pi = torch.nonzero(lab > 0).squeeze(1)
-        ni = torch.nonzero(lab == 0).squeeze(1)
-        pos_pts.append(f[pi])
-        pos_lab.append(lab[pi])
-        n_pos, n_neg = pi.numel(), ni.numel()
-        if n_pos > n_neg:
-            neg_pts.append(f[ni])
-        else:
-            idx = np.floor(np.linspace(0, n_neg - 2, n_pos)).astype(np.int64)
-            neg_pts.append(f[ni[torch.from_numpy(idx).to(ni.device)]])
-    pos_pts = torch.cat(pos_pts, 0)
-    pos_lab = torch.cat(pos_lab, 0)
-    neg_pts = torch.cat(neg_pts, 0)
-    return torch.cat([neg_pts, pos_pts], 0), torch.cat([pos_lab.new_zeros(neg_pts.shape[0]), pos_lab])
+    """PrototypeComputation.__call__ source branch (reference loss.py:428-463): node features and labels, order
+    [all neg, all pos] (fcos.source_node_index picks the rows)."""
+    index, node_labels = source_node_index(labels, shape)
+    return feats[index], node_labels
 
 
 def sim_matrix(a, b, eps=1e-8):
@@ -286,9 +268,9 @@ class GRAPHModule(nn.Module):
         """-> feats [M,256], (node_loss, transfer_loss) or None, act_loss or None, act_maps [M,K]."""
         feats = self.head_in(rows, shape)
         if self.training and targets and mode == "source":
-            locs = compute_locations(shape, rows.device)
-            labels, _ = assign_targets(locs, targets)
-            pts, labs = sample_source_nodes(feats, labels, shape)
+            plan = target_plan(shape, targets, rows.device)
+            labels = plan.labels
+            pts, labs = feats[plan.node_index], plan.node_labels
             node_loss, proto_batch = self._forward_gcns(pts, labs)
             self.update_prototype_nx1_rnn(proto_batch)
             kernels = self.get_conded_weight()

@@ -50,6 +50,85 @@ def compute_locations(shape, device, strides=FPN_STRIDES):
     return locs
 
 
+class TargetPlan:
+    """Everything the source pass derives from the ground truth alone (no network output involved): the FCOS
+    assignment (reference loss.py:40-126, and its copy at :262-343 used by the middle head), the positive rows
+    with their regression / centerness targets (loss.py:128-133,197-222) and the graph-node sampling index
+    (loss.py:428-463).  It is built once per batch -- by engine.forward_detector on a side stream while the
+    backbone convolutions are queued on the main one, so its host round trips (nonzero) cost no GPU idle time."""
+    __slots__ = ("key", "targets", "labels", "labels_i32", "reg_targets", "pos_inds", "n_pos", "reg_pos", "ctr_pos",
+                 "node_index", "node_labels", "ready")
+
+
+_plan = [None]
+
+
+def reset_target_plan():
+    """engine.Trainer calls this at the top of every iteration: a plan never outlives its batch."""
+    _plan[0] = None
+
+
+def source_node_index(labels, shape):
+    """Row indices and labels of the graph nodes the source branch samples (reference loss.py:428-463): per level,
+    positives in row order; negatives = floor(linspace(0, n_neg-2, n_pos)) of the background rows (all of them
+    when n_pos > n_neg); final order [all neg, all pos]."""
+    import numpy as np
+    pos, neg = [], []
+    for l in range(shape.n_levels):
+        r0, r1 = shape.row_off[l], shape.row_off[l + 1]
+        lab = labels[r0:r1]
+        pi = torch.nonzero(lab > 0).squeeze(1)
+        ni = torch.nonzero(lab == 0).squeeze(1)
+        n_pos, n_neg = pi.numel(), ni.numel()
+        if n_pos <= n_neg:
+            idx = np.floor(np.linspace(0, n_neg - 2, n_pos)).astype(np.int64)
+            ni = ni[torch.from_numpy(idx).to(ni.device)]
+        pos.append(pi + r0)
+        neg.append(ni + r0)
+    pos, neg = torch.cat(pos, 0), torch.cat(neg, 0)
+    return torch.cat([neg, pos], 0), torch.cat([labels.new_zeros(neg.numel()), labels[pos]], 0)
+
+
+def target_plan(shape, targets, device, side_stream=None, after=None):
+    """The TargetPlan of (shape, targets); cached for the current batch.  With ``side_stream`` the plan is built
+    there (after event ``after``) and the calling stream is made to wait for it."""
+    key = (id(targets), tuple(shape.sizes), shape.n_images, str(device))
+    p = _plan[0]
+    if p is not None and p.key == key and p.targets is targets:
+        return p
+    cur = torch.cuda.current_stream() if device.type == "cuda" else None
+    if side_stream is not None and cur is not None:
+        if after is not None:
+            side_stream.wait_event(after)
+        with torch.cuda.stream(side_stream):
+            p = _build_plan(shape, targets, device)
+            p.ready = torch.cuda.Event()
+            p.ready.record(side_stream)
+        cur.wait_event(p.ready)
+        for name in TargetPlan.__slots__:
+            t = getattr(p, name, None)
+            if isinstance(t, torch.Tensor):
+                t.record_stream(cur)
+    else:
+        p = _build_plan(shape, targets, device)
+    p.key, p.targets = key, targets
+    _plan[0] = p
+    return p
+
+
+def _build_plan(shape, targets, device):
+    p = TargetPlan()
+    p.ready = None
+    p.labels, p.reg_targets = assign_targets(compute_locations(shape, device), targets)
+    p.labels_i32 = p.labels.int()
+    p.node_index, p.node_labels = source_node_index(p.labels, shape)
+    p.pos_inds = torch.nonzero(p.labels > 0).squeeze(1)
+    p.n_pos = p.pos_inds.numel()
+    p.reg_pos = p.reg_targets[p.pos_inds]
+    p.ctr_pos = centerness_targets(p.reg_pos) if p.n_pos > 0 else None
+    return p
+
+
 def assign_targets(locations, targets):
     """FCOS location -> GT assignment (reference loss.py:40-126; PrototypeComputation has an identical
     copy at :262-343).  targets: list of (boxes [G,4] xyxy, labels [G] int64) per image.
@@ -140,15 +219,12 @@ class FCOSLossComputation:
 
     def __call__(self, shape, box_cls, box_regression, centerness, targets):
         N = shape.n_images
-        locs = compute_locations(shape, box_cls.device)
-        labels, reg_targets = assign_targets(locs, targets)
-        pos_inds = torch.nonzero(labels > 0).squeeze(1)
-        cls_loss = self.cls_loss_func(box_cls.contiguous(), labels.int()) / (pos_inds.numel() + N)
+        plan = target_plan(shape, targets, box_cls.device)
+        pos_inds, reg_targets, ctr_t = plan.pos_inds, plan.reg_pos, plan.ctr_pos
+        cls_loss = self.cls_loss_func(box_cls.contiguous(), plan.labels_i32) / (plan.n_pos + N)
         box_regression = box_regression[pos_inds]
-        reg_targets = reg_targets[pos_inds]
         centerness = centerness[pos_inds]
-        if pos_inds.numel() > 0:
-            ctr_t = centerness_targets(reg_targets)
+        if plan.n_pos > 0:
             reg_loss = self.box_reg_loss_func(box_regression, reg_targets, ctr_t)
             ctr_loss = ops.bce_with_logits_mean(centerness, ctr_t)
         else:

@@ -136,15 +136,17 @@ def _grad_digest(named):
     return out
 
 
-def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False):
-    """Full DA iteration, procedural weights/inputs."""
-    cfg = rh.make_cfg()
+def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False, K=9,
+             yaml_name="scan_vgg16_cityscapace_to_foggy.yaml"):
+    """Full DA iteration, procedural weights/inputs.  K = MODEL.FCOS.NUM_CLASSES of the yaml (9 C2F, 2 S2C)."""
+    cfg = rh.make_cfg(yaml_name=yaml_name)
+    assert cfg.MODEL.FCOS.NUM_CLASSES == K
     model = rh.build_models(cfg, dropout=0.0)
-    sds = synth.all_state_dicts(9)
+    sds = synth.all_state_dicts(K)
     _load(model, sds)
     imgs_s = synth.synth_images(N, H, W, 1234)
     imgs_t = synth.synth_images(N, H, W, 2234)
-    tg = synth.synth_targets(N, H, W, 8, 12, 4321)
+    tg = synth.synth_targets(N, H, W, K - 1, 12, 4321)
     targets = rh.make_targets([b for b, _ in tg], [l for _, l in tg], (H, W))
     losses = rh.da_iteration(cfg, model, imgs_s, targets, imgs_t, forward_target=forward_target)
     grads = {}
@@ -166,13 +168,15 @@ def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False
         **{"label_map_%d" % l: lm.numpy() for l, lm in enumerate(label_maps)})
     with open(os.path.join(GOLD, name + ".json"), "w") as f:
         json.dump({"H": H, "W": W, "N": N, "seeds": {"src": 1234, "tgt": 2234, "boxes": 4321},
-                   "forward_target": forward_target, "losses": losses, "grad_digest": grads}, f)
+                   "forward_target": forward_target, "num_classes": K,
+                   "transfer_cfg": [t for t in cfg.MODEL.MIDDLE_HEAD.TRANSFER_CFG], "losses": losses, "grad_digest": grads}, f)
     print(name, {k: round(v, 6) for k, v in losses.items()})
     if check:
         P = {k: scan_ref.params(v, frozen_prefixes=("body.features.0.", "body.features.2.", "body.features.5.", "body.features.7."))
              for k, v in sds.items()}
         st = scan_ref.PrototypeState(sds["middle_head"]["prototype"])
-        mine = scan_ref.da_iteration(P, st, imgs_s, tg, imgs_t, forward_target=forward_target)
+        mine = scan_ref.da_iteration(P, st, imgs_s, tg, imgs_t, K=K, forward_target=forward_target,
+                                     transfer=cfg.MODEL.MIDDLE_HEAD.TRANSFER_CFG[0] is not None)
         worst = 0.0
         for k, v in mine.items():
             worst = max(worst, rel(v, losses[k]))
@@ -188,13 +192,13 @@ def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False
         assert worst < 1e-4 and gw < 3e-3
 
 
-def gen_inference(check, H=128, W=256, N=2):
-    cfg = rh.make_cfg()
+def gen_inference(check, H=128, W=256, N=2, K=9, yaml_name="scan_vgg16_cityscapace_to_foggy.yaml",
+                  name="inference_128x256"):
     out = {}
-    sds = synth.all_state_dicts(9)
+    sds = synth.all_state_dicts(K)
     imgs = synth.synth_images(N, H, W, 3234)
     for mode in ("common", "precision"):
-        c = rh.make_cfg(["TEST.MODE", mode])
+        c = rh.make_cfg(["TEST.MODE", mode], yaml_name=yaml_name)
         model = rh.build_models(c)
         _load(model, sds)
         for m in model.values():
@@ -223,7 +227,7 @@ def gen_inference(check, H=128, W=256, N=2):
             P = {k: scan_ref.params(v, requires_grad=False) for k, v in sds.items()}
             st = scan_ref.PrototypeState(sds["middle_head"]["prototype"])
             nms_fn = lambda b, s, t: torch.from_numpy(coracle.nms(b.numpy(), s.numpy(), t)) if len(b) else torch.empty(0, dtype=torch.int64)
-            mine = scan_ref.inference(P, st, imgs, nms_fn, mode=mode)
+            mine = scan_ref.inference(P, st, imgs, nms_fn, mode=mode, K=K)
             for i, (b, s, l) in enumerate(mine):
                 rb = out["%s_boxes_%d" % (mode, i)]
                 assert len(b) == len(rb), (len(b), len(rb))
@@ -233,7 +237,7 @@ def gen_inference(check, H=128, W=256, N=2):
                 print("  img %d: max box diff %.3e score diff %.3e" % (
                     i, np.abs(b.numpy()[o1] - rb[o2]).max() if len(b) else 0,
                     np.abs(s.numpy()[o1] - out["%s_scores_%d" % (mode, i)][o2]).max() if len(b) else 0))
-    np.savez_compressed(os.path.join(GOLD, "inference_128x256.npz"), **out)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
 
 
 def main():
@@ -256,8 +260,15 @@ def main():
         gen_step(a.check, H=800, W=1600, N=1, name="step_cfg1_800x1600")
     if "step_ft" in todo:
         gen_step(a.check, H=256, W=512, name="step_ft_256x512", forward_target=True)
+    if "step_s2c" in todo:  # BASELINE.json configs[2]: Sim10k->Cityscapes, NUM_CLASSES 2, TRANSFER_CFG (None,)
+        gen_step(a.check, name="step_s2c_128x256", K=2, yaml_name="scan_vgg16_sim10k_to_cityscapes.yaml")
+    if "step_s2c_ft" in todo:
+        gen_step(a.check, H=256, W=512, name="step_s2c_ft_256x512", K=2, forward_target=True,
+                 yaml_name="scan_vgg16_sim10k_to_cityscapes.yaml")
     if "inference" in todo:
         gen_inference(a.check)
+    if "inference_s2c" in todo:
+        gen_inference(a.check, K=2, yaml_name="scan_vgg16_sim10k_to_cityscapes.yaml", name="inference_s2c_128x256")
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@ arithmetic on the path.
 """
 import ast
 import os
+import re
 import sys
 import types
 
@@ -185,11 +186,21 @@ def setup():
     _READY = True
 
 
-def make_cfg(extra=()):
+def make_cfg(extra=(), yaml_name="scan_vgg16_cityscapace_to_foggy.yaml"):
     setup()
     from fcos_core.config import cfg as _cfg
     cfg = _cfg.clone()
-    cfg.merge_from_file(os.path.join(REF, "configs/scan/scan_vgg16_cityscapace_to_foggy.yaml"))
+    path = os.path.join(REF, "configs/scan", yaml_name)
+    text = open(path).read()
+    # scan_vgg16_sim10k_to_cityscapes.yaml:5 carries a stray extra space before WEIGHT (not valid YAML as shipped):
+    # parse an in-memory copy with that one line re-indented
+    fixed = re.sub(r"(?m)^   WEIGHT:", "  WEIGHT:", text)
+    if fixed != text:
+        import tempfile
+        with tempfile.NamedTemporaryFile("w", suffix=".yaml", delete=False) as f:
+            f.write(fixed)
+            path = f.name
+    cfg.merge_from_file(path)
     cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.WEIGHT", ""] + list(extra))
     return cfg
 

@@ -350,14 +350,14 @@ def transfer_loss(prototype, tg_prototype, tg_nodes, tg_labels):
     return l_node + l_adj
 
 
-def middle_head_target(p, state, feats, K=9, eps=3, thr=0.05, lam3=1.0):
+def middle_head_target(p, state, feats, K=9, eps=3, thr=0.05, lam3=1.0, transfer=True):
     """GRAPHModule._forward_train_target (condgraph.py:500-534), GCN_SELF_TRAINING False."""
     feats = [tower(p, "head_in.middle_tower", f, 2) for f in feats]
     w = conded_weight(p, state.prototype)
     _, maps = act_maps_from(feats, w)
     pts, labs = sample_target_nodes(feats, maps, eps, thr)
     out = [tower(p, "head_out.middle_tower", torch.cat([f, m], 1), 1, gn=False) for f, m in zip(feats, maps)]
-    if pts is None:
+    if pts is None or not transfer:  # TRANSFER_CFG (None,): condgraph.py:521 skips the GST branch
         return out, None, maps
     _, tg_proto = forward_gcns(p, pts, labs, K)
     return out, lam3 * transfer_loss(state.prototype, tg_proto, pts, labs), maps
@@ -448,7 +448,7 @@ def discriminator_loss(p, feat, act, domain_label, K=9, grl_lambda=0.02):
 
 # ----------------------------------------------------------------------------- DA iteration
 def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, skip_dead_target_fcos=True,
-                 forward_target=False):
+                 forward_target=False, transfer=True):
     """Three-phase DA iteration (engine/trainer.py:266-385) with forward_target
     False: returns the loss dict (floats); gradients accumulate in P[...].grad.
     The target-pass FCOS head only yields the identically-zero 'zero' loss
@@ -470,7 +470,7 @@ def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, s
     feats = vgg_fpn_forward(P["backbone"], images_t)
     dt = {}
     if forward_target:
-        f_t, cons, maps_t = middle_head_target(P["middle_head"], state, feats, K)
+        f_t, cons, maps_t = middle_head_target(P["middle_head"], state, feats, K, transfer=transfer)
         if cons is not None:
             dt["consistency_loss_gt"] = cons
     else:

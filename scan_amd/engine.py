@@ -26,11 +26,19 @@ LEVELS = ("P3", "P4", "P5", "P6", "P7")
 DIS_ORDER = ("P7", "P6", "P5", "P4", "P3")  # order the reference builds / iterates them
 
 
-def build_model(num_classes=9, test_mode="precision", device="cuda", attn_dropout=0.1):
+# the shipped yamls (reference configs/scan/*.yaml): what differs between them on this path
+CONFIGS = {
+    "c2f": dict(num_classes=9, test_mode="precision", transfer_cfg=("NODES", "ADJ")),  # Cityscapes -> Foggy
+    "s2c": dict(num_classes=2, test_mode="common", transfer_cfg=(None,)),  # Sim10k -> Cityscapes
+    "k2c": dict(num_classes=2, test_mode="common", transfer_cfg=(None,)),  # KITTI -> Cityscapes
+}
+
+
+def build_model(num_classes=9, test_mode="precision", device="cuda", attn_dropout=0.1, transfer_cfg=("NODES", "ADJ")):
     """dict MODEL{backbone, middle_head, fcos, dis_P*_CON} like tools/train_net_da.py:43-48,223-274."""
     model = {
         "backbone": build_backbone(),
-        "middle_head": build_condgraph(None, 256, num_classes),
+        "middle_head": build_condgraph(None, 256, num_classes, transfer_cfg),
         "fcos": build_fcos(None, num_classes, test_mode),
     }
     model["middle_head"].multihead_attn.dropout.p = attn_dropout

@@ -284,5 +284,7 @@ class GRAPHModule(nn.Module):
         return out, None, None, maps
 
 
-def build_condgraph(cfg=None, in_channels=256, num_classes=9):
-    return GRAPHModule(in_channels, num_classes)
+def build_condgraph(cfg=None, in_channels=256, num_classes=9, transfer_cfg=("NODES", "ADJ")):
+    """transfer_cfg = MODEL.MIDDLE_HEAD.TRANSFER_CFG: ('NODES', 'ADJ') in the C2F yaml, the default (None,)
+    (reference config/defaults.py:694) in the Sim10k / KITTI yamls."""
+    return GRAPHModule(in_channels, num_classes, transfer_cfg=transfer_cfg)

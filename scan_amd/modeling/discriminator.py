@@ -25,8 +25,8 @@ class FCOSDiscriminator_con(nn.Module):
     def __init__(self, with_GA=False, fusion_cfg="concat", num_convs=4, in_channels=256, num_classes=9,
                  grad_reverse_lambda=0.02, grl_applied_domain="both", patch_stride=None, cfg=None):
         super().__init__()
-        assert fusion_cfg == "concat" and grl_applied_domain == "both" and patch_stride is None and num_classes > 2, \
-            "only the configuration the SCAN C2F yaml uses is built"
+        assert fusion_cfg == "concat" and grl_applied_domain == "both" and patch_stride is None and num_classes >= 2, \
+            "only the configuration the SCAN yamls use is built"
         self.num_convs = num_convs
         self.in_channels = in_channels
         self.num_classes = num_classes - 1  # use_bg False
@@ -69,4 +69,8 @@ class FCOSDiscriminator_con(nn.Module):
             xcat = torch.nn.functional.pad(xcat, (0, pad))
         h = ops.conv2d(xcat, w1, b1, shape, 3, 1, relu=True)
         logits = ops.conv2d(h, w2, b2, shape, 3, 1)[:, :Cf]
+        if Cf == 1:
+            # single foreground class (Sim10k / KITTI): plain mean BCE, no act-map weight (reference :122-123)
+            logits = logits.reshape(-1)
+            return ops.bce_with_logits_mean(logits, torch.full_like(logits, float(target)))
         return ops.cka_bce(logits, act_maps.detach(), float(target), Cf)

@@ -1,0 +1,39 @@
+import sys, torch, collections
+sys.path.insert(0, '/root/repo')
+from scan_amd import engine, synth, ops
+dev = torch.device('cuda')
+model = engine.build_model(9, device=dev); engine.load_procedural_weights(model)
+tr = engine.Trainer(model)
+tr.overlap_target = False; tr.dis_streams = {}
+H, W, B = 1024, 2048, 2
+s = synth.synth_images(B, H, W, 1).to(dev); t = synth.synth_images(B, H, W, 2).to(dev)
+tg = [(b.to(dev), l.to(dev)) for b, l in synth.synth_targets(B, H, W, 8, 12, 3)]
+for _ in range(2): tr.step(s, tg, t)
+torch.cuda.synchronize()
+# tag every timed launch with its shape
+orig_conv = ops._Conv2d.forward
+cur = {}
+kt = ops.kernel_timer
+orig_begin = kt.begin
+def begin(name, flops):
+    return orig_begin(name + " " + cur.get("tag", ""), flops)
+kt.begin = begin
+def fwd(ctx, x, weight, bias, shape, *a, **k):
+    cur["tag"] = "cin%d cout%d rows%d" % (weight.shape[1], weight.shape[0], x.shape[0])
+    ctx._tag = cur["tag"]
+    return orig_conv(ctx, x, weight, bias, shape, *a, **k)
+ops._Conv2d.forward = staticmethod(fwd)
+orig_bwd = ops._Conv2d.backward
+def bwd(ctx, *g):
+    cur["tag"] = ctx._tag
+    return orig_bwd(ctx, *g)
+ops._Conv2d.backward = staticmethod(bwd)
+kt.enabled = True
+import time
+torch.cuda.synchronize(); t0 = time.time()
+tr.step(s, tg, t)
+torch.cuda.synchronize(); dt = time.time() - t0
+sm = kt.summary()
+print("serial step %.1f ms; timed conv total %.1f ms" % (dt * 1e3, sum(v["total_ms"] for v in sm.values())))
+for k, v in sorted(sm.items(), key=lambda kv: -kv[1]["total_ms"])[:45]:
+    print("%7.2f ms %3d x %7.1f us %7.1f TF  %s" % (v["total_ms"], v["launches"], v["avg_ms"] * 1e3, v["tflops"], k))

@@ -99,13 +99,14 @@ def test_prototype_and_kernels_match_reference(step_result, gold_dir):
         np.testing.assert_allclose(mh.get_conded_weight().cpu().numpy(), g["kernels"], rtol=1e-3, atol=a)
 
 
-def test_inference_matches_reference(device, gold_dir):
+@pytest.mark.parametrize("K,fixture", [(9, "inference_128x256"), (2, "inference_s2c_128x256")])
+def test_inference_matches_reference(device, gold_dir, K, fixture):
     from scan_amd import engine, synth
-    g = np.load(os.path.join(gold_dir, "inference_128x256.npz"))
+    g = np.load(os.path.join(gold_dir, fixture + ".npz"))
     imgs = synth.synth_images(2, 128, 256, 3234).to(device)
     for mode in ("common", "precision"):
-        model = engine.build_model(9, test_mode=mode, device=device)
-        engine.load_procedural_weights(model)
+        model = engine.build_model(K, test_mode=mode, device=device)
+        engine.load_procedural_weights(model, K)
         res = engine.inference(model, imgs)
         for i, (b, s, l) in enumerate(res):
             rb, rs, rl = g["%s_boxes_%d" % (mode, i)], g["%s_scores_%d" % (mode, i)], g["%s_labels_%d" % (mode, i)]
@@ -229,3 +230,46 @@ def test_step_other_sizes_match_reference(device, gold_dir, name):
             p = dict(model[mk].named_parameters())[name_]
             mine = _digest(p.grad)
             assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mode, mk, name_, mine[1], ref[1])
+
+
+@pytest.mark.parametrize("name,ft", [("step_s2c_128x256", False), ("step_s2c_ft_256x512", True)])
+def test_step_s2c_matches_reference(device, gold_dir, name, ft):
+    """BASELINE.json configs[2] model (Sim10k->Cityscapes yaml: NUM_CLASSES 2, TRANSFER_CFG (None,)): one foreground
+    class -> K=2 dynamic conv / act maps, 1-channel cls_logits, plain mean-BCE discriminators
+    (fcos_head_discriminator_con.py:122-123), and no GST loss even with forward_target."""
+    from scan_amd import engine, ops, synth
+    gold = json.load(open(os.path.join(gold_dir, name + ".json")))
+    assert gold["num_classes"] == 2 and gold["transfer_cfg"] == [None]
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    cfg = engine.CONFIGS["s2c"]
+    for mode in ("fp32", "bf16x3"):
+        ops.CONV_MODE = mode
+        try:
+            model = engine.build_model(cfg["num_classes"], cfg["test_mode"], device=device, attn_dropout=0.0,
+                                       transfer_cfg=cfg["transfer_cfg"])
+            engine.load_procedural_weights(model, 2)
+            trainer = engine.Trainer(model)
+            for g in trainer.groups.values():
+                g.lr = 0.0
+            losses = trainer.step(synth.synth_images(N, H, W, gold["seeds"]["src"]).to(device),
+                                  synth.synth_targets(N, H, W, 1, 12, gold["seeds"]["boxes"]),
+                                  synth.synth_images(N, H, W, gold["seeds"]["tgt"]).to(device), forward_target=ft)
+            torch.cuda.synchronize()
+        finally:
+            ops.CONV_MODE = "bf16x3"
+        assert "consistency_loss_gt" not in losses
+        for k, ref in gold["losses"].items():
+            v = float(losses[k])
+            if ref == 0.0:
+                assert v == 0.0
+            else:
+                assert abs(v - ref) <= LOSS_RTOL * abs(ref), (mode, k, v, ref)
+        for mk, name_ in (("backbone", "body.features.28.weight"), ("fcos", "head.cls_logits.weight"),
+                          ("middle_head", "head_out.middle_tower.0.weight"), ("dis_P3_CON", "classifier_cls_0.0.weight"),
+                          ("dis_P4_CON", "dis_tower.0.weight")):
+            ref = gold["grad_digest"][mk][name_]
+            p = dict(model[mk].named_parameters())[name_]
+            mine = _digest(p.grad)
+            assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mode, mk, name_, mine[1], ref[1])
+    g = np.load(os.path.join(gold_dir, name + ".npz"))
+    np.testing.assert_allclose(model["middle_head"].prototype.cpu().numpy(), g["prototype_after"], rtol=1e-4, atol=1e-4)

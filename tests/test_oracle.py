@@ -116,3 +116,24 @@ def test_da_iteration_with_target_sampling_oracle_vs_reference(gold_dir):
         if k == "zero_gt":
             continue
         assert abs(out[k] - ref) <= 1e-5 * abs(ref), (k, out[k], ref)
+
+
+def test_da_iteration_s2c_oracle_vs_reference(gold_dir):
+    """Sim10k->Cityscapes yaml (NUM_CLASSES 2, TRANSFER_CFG (None,)): K=2 restatement against the reference."""
+    gold = json.load(open(os.path.join(gold_dir, "step_s2c_128x256.json")))
+    g = np.load(os.path.join(gold_dir, "step_s2c_128x256.npz"))
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    sds = synth.all_state_dicts(2)
+    frozen = ("body.features.0.", "body.features.2.", "body.features.5.", "body.features.7.")
+    P = {k: scan_ref.params(v, frozen_prefixes=frozen) for k, v in sds.items()}
+    st = scan_ref.PrototypeState(sds["middle_head"]["prototype"])
+    out = scan_ref.da_iteration(P, st, synth.synth_images(N, H, W, 1234), synth.synth_targets(N, H, W, 1, 12, 4321),
+                                synth.synth_images(N, H, W, 2234), K=2, transfer=False)
+    for k, ref in gold["losses"].items():
+        if k == "zero_gt":
+            continue
+        assert abs(out[k] - ref) <= 1e-5 * abs(ref), (k, out[k], ref)
+    np.testing.assert_allclose(st.prototype.numpy(), g["prototype_after"], rtol=1e-5, atol=1e-6)
+    gr = P["dis_P3_CON"]["classifier_cls_0.0.weight"].grad.double()
+    ref = gold["grad_digest"]["dis_P3_CON"]["classifier_cls_0.0.weight"]
+    assert abs(gr.abs().sum().item() - ref[1]) <= 1e-3 * ref[1]

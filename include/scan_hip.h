@@ -188,10 +188,12 @@ int scan_groupnorm_relu_backward(const float* x, const float* y, const float* dy
 
 /* ---- 2x2 / stride-2 max pooling on NHWC rows (replaces nn.MaxPool2d(2, 2) of the VGG body,
  *      backbone/mmdetection/vgg.py:33).  x [N,H,W,C], y [N,H/2,W/2,C]; H, W even, C % 4 == 0.
- *      backward routes the gradient to the first maximum of each window (F.max_pool2d's rule). ---- */
+ *      backward routes the gradient to the first maximum of each window (F.max_pool2d's rule);
+ *      relu_mask != 0 additionally zeroes it where that maximum is <= 0 (x is a ReLU output whose own
+ *      backward was left to its consumers, see scan_conv3x3_bf16x3's mask). ---- */
 int scan_maxpool2x2_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream);
 int scan_maxpool2x2_backward(const float* x, const float* y, const float* dy, int32_t N, int32_t H, int32_t W,
-                             int32_t C, float* dx, void* stream);
+                             int32_t C, float* dx, int32_t relu_mask, void* stream);
 
 /* ---- fused SGD with momentum (replaces torch.optim.SGD as configured by solver/build.py:7-43) ----
  * g' = g + wd*p ; buf = momentum*buf + g' ; p -= lr*buf   (first_step != 0: buf = g') */

@@ -137,18 +137,30 @@ def _grad_digest(named):
 
 
 def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False, K=9,
-             yaml_name="scan_vgg16_cityscapace_to_foggy.yaml"):
+             yaml_name="scan_vgg16_cityscapace_to_foggy.yaml", sizes=None):
     """Full DA iteration, procedural weights/inputs.  K = MODEL.FCOS.NUM_CLASSES of the yaml (9 C2F, 2 S2C)."""
     cfg = rh.make_cfg(yaml_name=yaml_name)
     assert cfg.MODEL.FCOS.NUM_CLASSES == K
     model = rh.build_models(cfg, dropout=0.0)
     sds = synth.all_state_dicts(K)
     _load(model, sds)
-    imgs_s = synth.synth_images(N, H, W, 1234)
-    imgs_t = synth.synth_images(N, H, W, 2234)
-    tg = synth.synth_targets(N, H, W, K - 1, 12, 4321)
+    if sizes is None:
+        imgs_s = synth.synth_images(N, H, W, 1234)
+        imgs_t = synth.synth_images(N, H, W, 2234)
+        ref_s, ref_t = imgs_s, imgs_t
+        tg = synth.synth_targets(N, H, W, K - 1, 12, 4321)
+    else:
+        # ragged batch through the reference's own collation (data/collate_batch.py:5-20: to_image_list(.., 32));
+        # boxes are drawn inside the smallest image so they are valid for every frame
+        from fcos_core.structures.image_list import to_image_list
+        N = len(sizes)
+        H, W = min(s[0] for s in sizes), min(s[1] for s in sizes)
+        imgs_s = synth.synth_image_list(sizes, 1234)
+        imgs_t = synth.synth_image_list(sizes, 2234)
+        ref_s, ref_t = to_image_list(imgs_s, 32), to_image_list(imgs_t, 32)
+        tg = synth.synth_targets(N, H, W, K - 1, 12, 4321)
     targets = rh.make_targets([b for b, _ in tg], [l for _, l in tg], (H, W))
-    losses = rh.da_iteration(cfg, model, imgs_s, targets, imgs_t, forward_target=forward_target)
+    losses = rh.da_iteration(cfg, model, ref_s, targets, ref_t, forward_target=forward_target)
     grads = {}
     for mk, m in model.items():
         grads[mk] = _grad_digest((k, p.grad) for k, p in m.named_parameters())
@@ -158,7 +170,7 @@ def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False
     from fcos_core.structures.image_list import to_image_list
     with torch.no_grad():
         mh = model["middle_head"]
-        feats = mh.head_in(model["backbone"](imgs_s))
+        feats = mh.head_in(model["backbone"](ref_s if sizes is None else ref_s.tensors))
         locs = mh.compute_locations(feats)
         pts, labs, label_maps = mh.prototype_evaluator(locs, feats, targets)
     np.savez_compressed(
@@ -167,7 +179,7 @@ def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False
         node_labels=labs.numpy(), node_sum=pts.double().sum(1).numpy(),
         **{"label_map_%d" % l: lm.numpy() for l, lm in enumerate(label_maps)})
     with open(os.path.join(GOLD, name + ".json"), "w") as f:
-        json.dump({"H": H, "W": W, "N": N, "seeds": {"src": 1234, "tgt": 2234, "boxes": 4321},
+        json.dump({"H": H, "W": W, "N": N, "sizes": sizes, "seeds": {"src": 1234, "tgt": 2234, "boxes": 4321},
                    "forward_target": forward_target, "num_classes": K,
                    "transfer_cfg": [t for t in cfg.MODEL.MIDDLE_HEAD.TRANSFER_CFG], "losses": losses, "grad_digest": grads}, f)
     print(name, {k: round(v, 6) for k, v in losses.items()})
@@ -260,6 +272,10 @@ def main():
         gen_step(a.check, H=800, W=1600, N=1, name="step_cfg1_800x1600")
     if "step_ft" in todo:
         gen_step(a.check, H=256, W=512, name="step_ft_256x512", forward_target=True)
+    if "step_pad" in todo:  # ragged batch, zero-padded to 352x512 by to_image_list(.., 32)
+        gen_step(a.check, name="step_pad_333x500", sizes=[(333, 500), (320, 480)])
+    if "step_cfg5" in todo:  # BASELINE.json configs[4] frame: 1333x2666 padded to 1344x2688
+        gen_step(a.check, name="step_cfg5_1333x2666", sizes=[(1333, 2666)])
     if "step_s2c" in todo:  # BASELINE.json configs[2]: Sim10k->Cityscapes, NUM_CLASSES 2, TRANSFER_CFG (None,)
         gen_step(a.check, name="step_s2c_128x256", K=2, yaml_name="scan_vgg16_sim10k_to_cityscapes.yaml")
     if "step_s2c_ft" in todo:

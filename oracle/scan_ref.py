@@ -446,6 +446,21 @@ def discriminator_loss(p, feat, act, domain_label, K=9, grl_lambda=0.02):
     return loss
 
 
+def pad_images(images, size_divisible=32):
+    """to_image_list(list, size_divisible) (structures/image_list.py:29-72): zero-pad bottom/right to the common
+    size rounded up to a multiple of size_divisible; returns (batch [N,3,H,W], true sizes)."""
+    if isinstance(images, torch.Tensor):
+        return images, [tuple(images.shape[-2:])] * images.shape[0]
+    h = max(i.shape[1] for i in images)
+    w = max(i.shape[2] for i in images)
+    h = -(-h // size_divisible) * size_divisible
+    w = -(-w // size_divisible) * size_divisible
+    out = torch.zeros(len(images), images[0].shape[0], h, w)
+    for o, i in zip(out, images):
+        o[:, :i.shape[1], :i.shape[2]] = i
+    return out, [tuple(i.shape[-2:]) for i in images]
+
+
 # ----------------------------------------------------------------------------- DA iteration
 def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, skip_dead_target_fcos=True,
                  forward_target=False, transfer=True):
@@ -454,6 +469,8 @@ def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, s
     The target-pass FCOS head only yields the identically-zero 'zero' loss
     (fcos.py:215-220); it is skipped unless skip_dead_target_fcos=False."""
     out = {}
+    images_s, _ = pad_images(images_s)
+    images_t, _ = pad_images(images_t)
     feats = vgg_fpn_forward(P["backbone"], images_s)
     f_s, node_loss, act_loss, maps_s = middle_head_source(P["middle_head"], state, feats, targets_s, K)
     lg, rg, ct = fcos_head(P["fcos"], f_s)
@@ -565,6 +582,7 @@ def inference(P, state, images, nms_fn, mode="precision", K=9):
     """eval path: backbone -> _forward_inference (condgraph.py:536-545) -> FCOS
     head -> score fusion (fcos.py:162-169) -> post-processor."""
     with torch.no_grad():
+        images, sizes = pad_images(images)
         feats = vgg_fpn_forward(P["backbone"], images)
         f, maps = middle_head_plain(P["middle_head"], state, feats, K)
         lg, rg, ct = fcos_head(P["fcos"], f)
@@ -573,5 +591,4 @@ def inference(P, state, images, nms_fn, mode="precision", K=9):
         elif mode == "precision":
             lg = [0.5 * l.sigmoid() + 0.5 * m[:, 1:] for l, m in zip(lg, maps)]
         locs = compute_locations(f)
-        sizes = [tuple(images.shape[-2:])] * images.shape[0]
         return postprocess(locs, lg, rg, ct, sizes, nms_fn, mode=mode, num_classes=K)

@@ -476,7 +476,7 @@ __device__ __forceinline__ void pool_bwd1(float a0, float a1, float a2, float a3
 
 __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                                            const float* __restrict__ dy, int N, int H, int W, int C,
-                                                           float* __restrict__ dx) {
+                                                           float* __restrict__ dx, int relu_mask) {
   const int Ho = H >> 1, Wo = W >> 1, C4 = C >> 2;
   const int64_t total = (int64_t)N * Ho * Wo * C4;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -492,7 +492,13 @@ __global__ __launch_bounds__(256) void maxpool2_bwd_kernel(const float* __restri
     const int64_t s1 = C4, s2 = (int64_t)W * C4, s3 = s2 + C4;
     const float4 a0 = b[0], a1 = b[s1], a2 = b[s2], a3 = b[s3];
     const float4 m = reinterpret_cast<const float4*>(y)[i];
-    const float4 g = reinterpret_cast<const float4*>(dy)[i];
+    float4 g = reinterpret_cast<const float4*>(dy)[i];
+    if (relu_mask) {  // x is a ReLU output whose own backward was deferred to its consumers: dx *= (x > 0)
+      g.x = m.x > 0.f ? g.x : 0.f;
+      g.y = m.y > 0.f ? g.y : 0.f;
+      g.z = m.z > 0.f ? g.z : 0.f;
+      g.w = m.w > 0.f ? g.w : 0.f;
+    }
     float4 d0, d1, d2, d3;
     pool_bwd1(a0.x, a1.x, a2.x, a3.x, m.x, g.x, d0.x, d1.x, d2.x, d3.x);
     pool_bwd1(a0.y, a1.y, a2.y, a3.y, m.y, g.y, d0.y, d1.y, d2.y, d3.y);
@@ -516,12 +522,12 @@ extern "C" int scan_maxpool2x2_forward(const float* x, int32_t N, int32_t H, int
 }
 
 extern "C" int scan_maxpool2x2_backward(const float* x, const float* y, const float* dy, int32_t N, int32_t H,
-                                        int32_t W, int32_t C, float* dx, void* stream) {
+                                        int32_t W, int32_t C, float* dx, int32_t relu_mask, void* stream) {
   SCAN_CHECK_ARG(x && y && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, "maxpool2x2_backward: bad arguments");
   SCAN_CHECK_ARG((H & 1) == 0 && (W & 1) == 0 && (C & 3) == 0, "maxpool2x2_backward: H, W must be even and C %% 4 == 0");
   const int64_t total = (int64_t)N * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, y, dy, N, H, W,
-                     C, dx);
+                     C, dx, relu_mask);
   SCAN_LAUNCH_CHECK("maxpool2_bwd");
   return 0;
 }

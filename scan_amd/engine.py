@@ -16,6 +16,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops, synth
+from .structures import ImageList, to_image_list  # noqa: F401
 from .modeling.backbone import build_backbone
 from .modeling.condgraph import build_condgraph
 from .modeling.discriminator import FCOSDiscriminator_con
@@ -79,8 +80,12 @@ def _plan_stream(device):
 
 
 def forward_detector(model, images, targets=None, mode="source", forward_target=False):
-    """reference engine/trainer.py:20-72.  images [N,3,H,W] on the GPU; targets list of (boxes, labels).
-    Training: (losses, features{P3..P7: rows}, act_maps{P3..P7: rows}, shape).  Eval: detections."""
+    """reference engine/trainer.py:20-72.  images: [N,3,H,W] on the GPU or an ImageList (structures.to_image_list:
+    ragged images zero-padded to a common /32 size, true sizes kept for the box clipping of inference); targets
+    list of (boxes, labels).  Training: (losses, features{P3..P7: rows}, act_maps{P3..P7: rows}, shape).
+    Eval: detections."""
+    il = to_image_list(images)
+    images = il.tensors
     plan_here = bool(targets) and mode == "source" and model["middle_head"].training and images.is_cuda
     if plan_here:
         inputs_ready = torch.cuda.Event()
@@ -102,7 +107,7 @@ def forward_detector(model, images, targets=None, mode="source", forward_target=
             losses["node_loss"] = node_loss
     if loss_act is not None:
         losses["act_loss"] = loss_act
-    sizes = [tuple(images.shape[-2:])] * images.shape[0]
+    sizes = il.image_sizes
     proposals, proposal_losses = model["fcos"](sizes, feats, shape, targets=targets, act_maps=maps)
     if model["fcos"].training:
         losses.update(proposal_losses)

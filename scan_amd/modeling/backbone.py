@@ -25,9 +25,9 @@ def conv_holder(cin, cout, k, stride=1):
     return m
 
 
-def maxpool2x2(rows, shape):
+def maxpool2x2(rows, shape, relu_input=False):
     """2x2/2 max-pool of a single-level pyramid (HIP kernel, scan_maxpool2x2_*)."""
-    return ops.maxpool2x2(rows, shape)
+    return ops.maxpool2x2(rows, shape, relu_input)
 
 
 def upsample2x(rows, shape):
@@ -56,12 +56,14 @@ class VGGBody(nn.Module):
                     p.requires_grad = False
 
     def forward(self, rows, shape):
+        # every conv output here has exactly one consumer (the next conv or the stage's max-pool), so the ReLU
+        # backward is folded into that consumer's dgrad / pool-backward epilogue instead of a pass of its own
         outs = []
         for stage in VGG_STAGES:
-            for idx in stage:
+            for j, idx in enumerate(stage):
                 m = self.features[idx]
-                rows = ops.conv2d(rows, m.weight, m.bias, shape, 3, 1, relu=True)
-            rows, shape = maxpool2x2(rows, shape)
+                rows = ops.conv2d(rows, m.weight, m.bias, shape, 3, 1, relu="deferred", mask_dx=j > 0)
+            rows, shape = maxpool2x2(rows, shape, relu_input=True)
             outs.append((rows, shape))
         return outs
 
@@ -102,7 +104,7 @@ class FPN(nn.Module):
 
 
 class VGG16FPN(nn.Module):
-    """model["backbone"]: images [N,3,H,W] (H, W multiples of 128) -> (rows [M,256], PyramidShape of P3..P7)."""
+    """model["backbone"]: images [N,3,H,W] (H, W multiples of 32: structures.to_image_list pads) -> (rows [M,256], PyramidShape of P3..P7)."""
     out_channels = 256
 
     def __init__(self):

@@ -67,8 +67,8 @@ class FCOSDiscriminator_con(nn.Module):
         pad = ops.pad4(xcat.shape[1]) - xcat.shape[1]
         if pad:
             xcat = torch.nn.functional.pad(xcat, (0, pad))
-        h = ops.conv2d(xcat, w1, b1, shape, 3, 1, relu=True)
-        logits = ops.conv2d(h, w2, b2, shape, 3, 1)[:, :Cf]
+        h = ops.conv2d(xcat, w1, b1, shape, 3, 1, relu="deferred")  # its only consumer masks dx by (h > 0)
+        logits = ops.conv2d(h, w2, b2, shape, 3, 1, mask_dx=True)[:, :Cf]
         if Cf == 1:
             # single foreground class (Sim10k / KITTI): plain mean BCE, no act-map weight (reference :122-123)
             logits = logits.reshape(-1)

@@ -174,7 +174,8 @@ SPLIT_EPOCH = None
 _split_cache = {}
 
 
-def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None):
+def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None,
+                    mask=None):
     """wp: packed fp32 weights [O][9][Cs_w].  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
     st = _stream()
     O, T, cs_w = wp.shape
@@ -202,17 +203,21 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
             _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
     y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
     ev = kernel_timer.begin(name, flops)
-    call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), None, _ptr(y), nout,
-         ns, int(relu), st)
+    call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask), _ptr(y),
+         nout, ns, int(bool(relu)), st)
     kernel_timer.end(ev)
     return y
 
 
 class _Conv2d(torch.autograd.Function):
-    """conv (k in {1,3}, stride in {1,2}, pad k//2) + bias (+ ReLU) on a pyramid."""
+    """conv (k in {1,3}, stride in {1,2}, pad k//2) + bias (+ ReLU) on a pyramid.
+
+    relu = "deferred": the forward applies the ReLU, the backward does NOT mask dy -- the contract is that every
+    consumer of y multiplies its dx by (y > 0) itself (mask_dx=True on a conv, relu_input=True on the max-pool),
+    which those kernels do for free in their epilogue; it removes the separate relu-backward pass over dy."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, shape, ksize, stride, relu, cout_s):
+    def forward(ctx, x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx=False):
         _chk(x, bias)
         if not weight.is_cuda:
             raise RuntimeError("scan_amd ops run only on the GPU (HIP); no CPU fallback")
@@ -232,10 +237,11 @@ class _Conv2d(torch.autograd.Function):
             y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
             ev = kernel_timer.begin("conv_igemm_fwd", flops)
             call("scan_conv2d_forward", _ptr(x), shape.ref(), cs, _ptr(wp), _ptr(bias), _ptr(y), oshape.ref(), cout,
-                 cout_s, ksize, stride, int(relu), _stream())
+                 cout_s, ksize, stride, int(bool(relu)), _stream())
             kernel_timer.end(ev)
-        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.save_for_backward(x, weight, y if relu is True else None)
         ctx.cfg = (shape, oshape, ksize, stride, relu, cout_s, bias is not None, fast)
+        ctx.mask_dx = mask_dx
         ctx.ckey = ckey
         # parameters re-homed into a flat gradient buffer (engine.FlatGroup): accumulate straight into it
         ctx.wgrad_buf = ctx.bgrad_buf = None
@@ -255,14 +261,16 @@ class _Conv2d(torch.autograd.Function):
         T = ksize * ksize
         st = _stream()
         dy = dy.contiguous()
-        if relu:
+        if relu is True:
             g = torch.empty_like(dy)
             call("scan_relu_backward", _ptr(dy), _ptr(y), _ptr(g), dy.numel(), st)
             dy = g
         dx = dw = db = None
+        mask = x if ctx.mask_dx else None  # x is a deferred-ReLU output: dx *= (x > 0) in the dgrad epilogue
         if ctx.needs_input_grad[0] and fast:
             dx = _conv3x3_bf16x3(dy, shape, pack_weight(weight, cs), cout, x.shape[0], cout_s, 1, None, False, cs,
-                                 "conv3x3_bf16x3_dgrad", 2.0 * oshape.rows * cout * T * cin, cache_key=ctx.ckey)
+                                 "conv3x3_bf16x3_dgrad", 2.0 * oshape.rows * cout * T * cin, cache_key=ctx.ckey,
+                                 mask=mask)
         elif ctx.needs_input_grad[0]:
             wp = pack_weight(weight, cs)
             wt = x.new_empty((cs, T, cout_s))
@@ -270,7 +278,7 @@ class _Conv2d(torch.autograd.Function):
             dx = torch.empty_like(x)
             ev = kernel_timer.begin("conv_igemm_dgrad", 2.0 * oshape.rows * cout * T * cin)
             call("scan_conv2d_dgrad", _ptr(dy), oshape.ref(), cout_s, _ptr(wt), _ptr(dx), shape.ref(), cs, cs, ksize,
-                 stride, None, st)
+                 stride, _ptr(mask), st)
             kernel_timer.end(ev)
         direct_w = ctx.wgrad_buf is not None
         direct_b = direct_w and ctx.bgrad_buf is not None
@@ -307,12 +315,14 @@ class _Conv2d(torch.autograd.Function):
             call("scan_colsum", _ptr(dy), M, cout, cout_s, _ptr(db), int(direct_b), _ptr(ws), st)
             if direct_b:
                 db = None
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None):
-    """Returns rows [M_out, Cout_s]; the output PyramidShape is shape.conv_out(ksize, stride)."""
-    return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s)
+def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None, mask_dx=False):
+    """Returns rows [M_out, Cout_s]; the output PyramidShape is shape.conv_out(ksize, stride).
+    relu: False | True | "deferred" (see _Conv2d); mask_dx: x is a deferred-ReLU output."""
+    assert relu in (False, True, "deferred")
+    return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx)
 
 
 # ----------------------------------------------------------------------------- pyramid row split
@@ -342,31 +352,32 @@ def split_levels(rows, shape):
 # ----------------------------------------------------------------------------- 2x2 max pooling
 class _MaxPool2x2(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, shape):
+    def forward(ctx, x, shape, relu_input=False):
         _chk(x)
         (h, w), n = shape.sizes[0], shape.n_images
         c = x.shape[1]
         y = x.new_empty((n * (h // 2) * (w // 2), c))
         call("scan_maxpool2x2_forward", _ptr(x), n, h, w, c, _ptr(y), _stream())
         ctx.save_for_backward(x, y)
-        ctx.dims = (n, h, w, c)
+        ctx.dims = (n, h, w, c, int(relu_input))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, y = ctx.saved_tensors
-        n, h, w, c = ctx.dims
+        n, h, w, c, relu_input = ctx.dims
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        call("scan_maxpool2x2_backward", _ptr(x), _ptr(y), _ptr(dy), n, h, w, c, _ptr(dx), _stream())
-        return dx, None
+        call("scan_maxpool2x2_backward", _ptr(x), _ptr(y), _ptr(dy), n, h, w, c, _ptr(dx), relu_input, _stream())
+        return dx, None, None
 
 
-def maxpool2x2(x, shape):
-    """2x2/2 max-pool of a single-level pyramid; returns (rows, PyramidShape)."""
+def maxpool2x2(x, shape, relu_input=False):
+    """2x2/2 max-pool of a single-level pyramid; returns (rows, PyramidShape).  relu_input: x is a deferred-ReLU
+    conv output (ops.conv2d relu="deferred"): the backward also applies that ReLU's mask."""
     assert shape.n_levels == 1
     (h, w) = shape.sizes[0]
-    return _MaxPool2x2.apply(x, shape), PyramidShape(shape.n_images, [(h // 2, w // 2)])
+    return _MaxPool2x2.apply(x, shape, relu_input), PyramidShape(shape.n_images, [(h // 2, w // 2)])
 
 
 # ----------------------------------------------------------------------------- GroupNorm + ReLU

@@ -149,6 +149,11 @@ def synth_images(n, h, w, seed0=1234):
     return torch.stack(imgs, 0)
 
 
+def synth_image_list(sizes, seed0=1234):
+    """ragged batch: list of [3,h_i,w_i] images (same per-image generator as synth_images)."""
+    return [synth_images(1, h, w, seed0 + i)[0] for i, (h, w) in enumerate(sizes)]
+
+
 def synth_targets(n, h, w, num_fg=8, boxes_per_img=12, seed0=4321):
     """Per image: (boxes [G,4] xyxy fp32, labels [G] int64 in 1..num_fg)."""
     out = []

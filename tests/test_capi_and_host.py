@@ -175,3 +175,20 @@ def test_checkpoint_wire_format(tmp_path):
     checkpoint.load(fresh, vpath)
     assert torch.equal(fresh["backbone"].body.features[0].weight, synth.backbone_state_dict()["body.features.0.weight"] + 1)
     assert torch.equal(fresh["backbone"].fpn.fpn_inner3.weight, model["backbone"].fpn.fpn_inner3.weight)  # untouched
+
+
+def test_to_image_list_padding():
+    """structures/image_list.py:29-72: zero pad bottom/right to the common size rounded up to /32, keep true sizes."""
+    from scan_amd.structures import ImageList, to_image_list
+    a, b = torch.ones(3, 33, 50), 2 * torch.ones(3, 20, 70)
+    il = to_image_list([a, b], 32)
+    assert isinstance(il, ImageList) and tuple(il.tensors.shape) == (2, 3, 64, 96)
+    assert il.image_sizes == [(33, 50), (20, 70)]
+    assert float(il.tensors[0, :, :33, :50].min()) == 1.0 and float(il.tensors[0].sum()) == 3 * 33 * 50
+    assert float(il.tensors[1].sum()) == 2 * 3 * 20 * 70
+    assert to_image_list(il) is il
+    t = torch.zeros(2, 3, 64, 64)
+    assert to_image_list(t).image_sizes == [(64, 64)] * 2 and to_image_list(t).tensors is t
+    assert tuple(to_image_list(torch.zeros(3, 40, 40), 32).tensors.shape) == (1, 3, 64, 64)
+    with pytest.raises(TypeError):
+        to_image_list(np.zeros((3, 4, 4)))

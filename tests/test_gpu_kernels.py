@@ -400,3 +400,41 @@ def test_maxpool2x2(device):
     assert torch.equal(ops.rows_to_nchw(y.detach(), oshape).contiguous().cpu(), yr.detach())
     y.backward(_rows(gy, device)[0])
     assert torch.equal(ops.rows_to_nchw(rows.grad, shape).contiguous().cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+def test_deferred_relu_backward_chain(device, monkeypatch, mode):
+    """conv+ReLU -> conv+ReLU -> maxpool -> conv with the ReLU backward folded into the consumers' epilogues
+    (ops.conv2d relu="deferred" / mask_dx, ops.maxpool2x2 relu_input) against the plain torch chain."""
+    from scan_amd import ops
+    monkeypatch.setattr(ops, "CONV_MODE", mode)
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 8, 24, 40, generator=g)
+    ws = [torch.randn(16, 8, 3, 3, generator=g) * 0.2, torch.randn(16, 16, 3, 3, generator=g) * 0.15,
+          torch.randn(12, 16, 3, 3, generator=g) * 0.15]
+    bs = [torch.randn(16, generator=g) * 0.1, torch.randn(16, generator=g) * 0.1, torch.randn(12, generator=g) * 0.1]
+    xr = x.clone().requires_grad_(True)
+    wr = [w.clone().requires_grad_(True) for w in ws]
+    br = [b.clone().requires_grad_(True) for b in bs]
+    h1 = F.relu(F.conv2d(xr, wr[0], br[0], padding=1))
+    h2 = F.relu(F.conv2d(h1, wr[1], br[1], padding=1))
+    # keep pre-activations away from 0 so rounding cannot flip a mask bit between the two implementations
+    out_r = F.conv2d(F.max_pool2d(h2, 2, 2), wr[2], br[2], padding=1)
+    gy = torch.randn(out_r.shape, generator=g)
+    out_r.backward(gy)
+    rows, shape = _rows(x, device)
+    rows.requires_grad_(True)
+    wd = [w.to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True) for w in ws]
+    bd = [b.to(device).requires_grad_(True) for b in bs]
+    a1 = ops.conv2d(rows, wd[0], bd[0], shape, 3, 1, relu="deferred")
+    a2 = ops.conv2d(a1, wd[1], bd[1], shape, 3, 1, relu="deferred", mask_dx=True)
+    p, pshape = ops.maxpool2x2(a2, shape, relu_input=True)
+    out = ops.conv2d(p, wd[2], bd[2], pshape, 3, 1)
+    np.testing.assert_allclose(ops.rows_to_nchw(out.detach(), pshape, 0, 12).cpu().numpy(), out_r.detach().numpy(),
+                               rtol=2e-4, atol=2e-4)
+    out.backward(_rows(gy, device, out.shape[1])[0])
+    tol = dict(rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(ops.rows_to_nchw(rows.grad, shape, 0, 8).cpu().numpy(), xr.grad.numpy(), **tol)
+    for i in range(3):
+        np.testing.assert_allclose(wd[i].grad.cpu().numpy(), wr[i].grad.numpy(), **tol)
+        np.testing.assert_allclose(bd[i].grad.cpu().numpy(), br[i].grad.numpy(), **tol)

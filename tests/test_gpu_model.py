@@ -273,3 +273,38 @@ def test_step_s2c_matches_reference(device, gold_dir, name, ft):
             assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mode, mk, name_, mine[1], ref[1])
     g = np.load(os.path.join(gold_dir, name + ".npz"))
     np.testing.assert_allclose(model["middle_head"].prototype.cpu().numpy(), g["prototype_after"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["step_pad_333x500", "step_cfg5_1333x2666"])
+def test_step_padded_batches_match_reference(device, gold_dir, name):
+    """structures.to_image_list: a ragged batch (333x500 + 320x480 -> 352x512) and the BASELINE.json configs[4]
+    frame (1333x2666 -> 1344x2688: levels 168x336 ... 11x21) zero-padded to /32 exactly like the reference's
+    collator (data/collate_batch.py:5-20, structures/image_list.py:29-72); losses within 1e-4."""
+    from scan_amd import engine, synth
+    path = os.path.join(gold_dir, name + ".json")
+    if not os.path.exists(path):
+        pytest.skip("fixture not generated")
+    gold = json.load(open(path))
+    sizes = [tuple(s) for s in gold["sizes"]]
+    model = engine.build_model(9, device=device, attn_dropout=0.0)
+    engine.load_procedural_weights(model)
+    trainer = engine.Trainer(model)
+    for g in trainer.groups.values():
+        g.lr = 0.0
+    il_s = engine.to_image_list([t.to(device) for t in synth.synth_image_list(sizes, gold["seeds"]["src"])], 32)
+    il_t = engine.to_image_list([t.to(device) for t in synth.synth_image_list(sizes, gold["seeds"]["tgt"])], 32)
+    assert il_s.tensors.shape[-2] % 32 == 0 and il_s.tensors.shape[-1] % 32 == 0 and il_s.image_sizes == sizes
+    tg = synth.synth_targets(len(sizes), gold["H"], gold["W"], 8, 12, gold["seeds"]["boxes"])
+    losses = trainer.step(il_s, tg, il_t)
+    torch.cuda.synchronize()
+    for k, ref in gold["losses"].items():
+        v = float(losses[k])
+        if ref == 0.0:
+            assert v == 0.0
+        else:
+            assert abs(v - ref) <= LOSS_RTOL * abs(ref), (k, v, ref)
+    for mk, name_ in (("backbone", "body.features.28.weight"), ("fcos", "head.cls_tower.0.weight"),
+                      ("dis_P3_CON", "dis_tower.0.weight")):
+        ref = gold["grad_digest"][mk][name_]
+        mine = _digest(dict(model[mk].named_parameters())[name_].grad)
+        assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mk, name_, mine[1], ref[1])

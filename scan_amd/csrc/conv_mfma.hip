@@ -428,7 +428,10 @@ static int launch_igemm(const float* src, const scan_pyramid_t* sd, int Cs, cons
                         int stride, int relu, hipStream_t st) {
   const int64_t M = dd->row_off[dd->n_levels];
   const int m_tiles = (int)((M + BM - 1) / BM);
-  if (Nout > 32) {
+  // few-row problems (the stride-2 P6 / P7 convs: 8 and 2 row tiles) are latency bound on the serial K loop of a
+  // handful of workgroups: the 128 x 32 tile gives 4x the workgroups for the same K depth
+  const bool small = (int64_t)m_tiles * ((Nout + 127) / 128) < 256;
+  if (Nout > 32 && !small) {
     const int n_tiles = (Nout + 127) / 128;
     const size_t sh = (size_t)(2 * BM * LDA + 2 * 128 * LDA) * sizeof(float);
     static bool attr_done = false;
@@ -440,7 +443,7 @@ static int launch_igemm(const float* src, const scan_pyramid_t* sd, int Cs, cons
     hipLaunchKernelGGL((conv_igemm_kernel<MODE, 4>), dim3(m_tiles * n_tiles), dim3(256), sh, st, src, *sd, Cs, w, bias,
                        mask, dst, *dd, Nout, Ns, ksize, stride, relu, m_tiles, n_tiles);
   } else {
-    const int n_tiles = 1;
+    const int n_tiles = (Nout + 31) / 32;
     const size_t sh = (size_t)(2 * BM * LDA + 2 * 32 * LDA) * sizeof(float);
     hipLaunchKernelGGL((conv_igemm_kernel<MODE, 1>), dim3(m_tiles * n_tiles), dim3(256), sh, st, src, *sd, Cs, w, bias,
                        mask, dst, *dd, Nout, Ns, ksize, stride, relu, m_tiles, n_tiles);

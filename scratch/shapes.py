@@ -19,7 +19,7 @@ def begin(name, flops):
     return orig_begin(name + " " + cur.get("tag", ""), flops)
 kt.begin = begin
 def fwd(ctx, x, weight, bias, shape, *a, **k):
-    cur["tag"] = "cin%d cout%d rows%d" % (weight.shape[1], weight.shape[0], x.shape[0])
+    cur["tag"] = "k%d s%d cin%d cout%d rows%d" % (a[0], a[1], weight.shape[1], weight.shape[0], x.shape[0])
     ctx._tag = cur["tag"]
     return orig_conv(ctx, x, weight, bias, shape, *a, **k)
 ops._Conv2d.forward = staticmethod(fwd)
@@ -35,5 +35,5 @@ tr.step(s, tg, t)
 torch.cuda.synchronize(); dt = time.time() - t0
 sm = kt.summary()
 print("serial step %.1f ms; timed conv total %.1f ms" % (dt * 1e3, sum(v["total_ms"] for v in sm.values())))
-for k, v in sorted(sm.items(), key=lambda kv: -kv[1]["total_ms"])[:45]:
+for k, v in sorted(sm.items(), key=lambda kv: -kv[1]["total_ms"])[:200]:
     print("%7.2f ms %3d x %7.1f us %7.1f TF  %s" % (v["total_ms"], v["launches"], v["avg_ms"] * 1e3, v["tflops"], k))

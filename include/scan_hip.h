@@ -181,8 +181,10 @@ int scan_groupnorm_stats(const float* x, const scan_pyramid_t* d, int32_t C, int
 int scan_groupnorm_relu_forward(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G, const float* stats,
                                 const float* gamma, const float* beta, int32_t relu, float* y, void* stream);
 int64_t scan_groupnorm_ws_floats(const scan_pyramid_t* d, int32_t C, int32_t G);
-/* dx, dgamma[C] (+)=, dbeta[C] (+)=; y is the forward output (for the ReLU mask); ws: scan_groupnorm_ws_floats */
-int scan_groupnorm_relu_backward(const float* x, const float* y, const float* dy, const scan_pyramid_t* d, int32_t C,
+/* dx, dgamma[C] (+)=, dbeta[C] (+)=; beta [C] is the forward's shift: the ReLU mask is recomputed from x with the
+ * forward's exact operation order instead of reading y back (may be NULL when relu == 0);
+ * ws: scan_groupnorm_ws_floats */
+int scan_groupnorm_relu_backward(const float* x, const float* beta, const float* dy, const scan_pyramid_t* d, int32_t C,
                                  int32_t G, const float* stats, const float* gamma, int32_t relu, float* dx,
                                  float* dgamma, float* dbeta, int32_t accumulate, float* ws, void* stream);
 

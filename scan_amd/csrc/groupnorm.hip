@@ -60,6 +60,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
   }
 }
 
+// y before the ReLU.  One fixed operation order (explicit fma) shared by the forward and by the backward kernels,
+// which recompute it from x to get the ReLU mask instead of reading y back from HBM.
+__device__ __forceinline__ float gn_affine(float v, float mean, float rstd, float ga, float be) {
+  return __fmaf_rn((v - mean) * rstd, ga, be);
+}
+
 __global__ void gn_stats_final_kernel(const double* __restrict__ ws, scan_pyramid_t d, int G, float eps,
                                       float* __restrict__ stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,10 +95,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     const int64_t off = (b.row0 + r) * GN_C + 4 * lane;
     const float4 v = *reinterpret_cast<const float4*>(x + off);
     float4 o;
-    o.x = (v.x - mean) * rstd * ga.x + be.x;
-    o.y = (v.y - mean) * rstd * ga.y + be.y;
-    o.z = (v.z - mean) * rstd * ga.z + be.z;
-    o.w = (v.w - mean) * rstd * ga.w + be.w;
+    o.x = gn_affine(v.x, mean, rstd, ga.x, be.x);
+    o.y = gn_affine(v.y, mean, rstd, ga.y, be.y);
+    o.z = gn_affine(v.z, mean, rstd, ga.z, be.z);
+    o.w = gn_affine(v.w, mean, rstd, ga.w, be.w);
     if (relu) {
       o.x = fmaxf(o.x, 0.f);
       o.y = fmaxf(o.y, 0.f);
@@ -104,7 +110,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 }
 
 // backward pass 1: group sums S1 = sum dyh*gamma, S2 = sum dyh*gamma*xhat; channel sums dgamma, dbeta
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ beta,
                                                             const float* __restrict__ dy, scan_pyramid_t d, int G,
                                                             const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, int relu,
@@ -116,6 +122,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   const int g = lane >> 1;
   const float mean = stats[((int64_t)b.il * G + g) * 2], rstd = stats[((int64_t)b.il * G + g) * 2 + 1];
   const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+  const float4 be = relu ? *reinterpret_cast<const float4*>(beta + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
   double s1 = 0, s2 = 0;
   float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
   for (int r = wid; r < b.rows; r += 4) {
@@ -123,11 +130,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
     const float4 xv = *reinterpret_cast<const float4*>(x + off);
     float4 gv = *reinterpret_cast<const float4*>(dy + off);
     if (relu) {
-      const float4 yv = *reinterpret_cast<const float4*>(y + off);
-      gv.x = yv.x > 0.f ? gv.x : 0.f;
-      gv.y = yv.y > 0.f ? gv.y : 0.f;
-      gv.z = yv.z > 0.f ? gv.z : 0.f;
-      gv.w = yv.w > 0.f ? gv.w : 0.f;
+      gv.x = gn_affine(xv.x, mean, rstd, ga.x, be.x) > 0.f ? gv.x : 0.f;
+      gv.y = gn_affine(xv.y, mean, rstd, ga.y, be.y) > 0.f ? gv.y : 0.f;
+      gv.z = gn_affine(xv.z, mean, rstd, ga.z, be.z) > 0.f ? gv.z : 0.f;
+      gv.w = gn_affine(xv.w, mean, rstd, ga.w, be.w) > 0.f ? gv.w : 0.f;
     }
     const float h0 = (xv.x - mean) * rstd, h1 = (xv.y - mean) * rstd, h2 = (xv.z - mean) * rstd,
                 h3 = (xv.w - mean) * rstd;
@@ -167,7 +173,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ beta,
                                                            const float* __restrict__ dy, scan_pyramid_t d, int G,
                                                            const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, int relu,
@@ -180,16 +186,16 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   const float S1 = (float)ws_g[((int64_t)b.il * G + g) * 2] * inv_cnt;
   const float S2 = (float)ws_g[((int64_t)b.il * G + g) * 2 + 1] * inv_cnt;
   const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * lane);
+  const float4 be = relu ? *reinterpret_cast<const float4*>(beta + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
   for (int r = wid; r < b.rows; r += 4) {
     const int64_t off = (b.row0 + r) * GN_C + 4 * lane;
     const float4 xv = *reinterpret_cast<const float4*>(x + off);
     float4 gv = *reinterpret_cast<const float4*>(dy + off);
     if (relu) {
-      const float4 yv = *reinterpret_cast<const float4*>(y + off);
-      gv.x = yv.x > 0.f ? gv.x : 0.f;
-      gv.y = yv.y > 0.f ? gv.y : 0.f;
-      gv.z = yv.z > 0.f ? gv.z : 0.f;
-      gv.w = yv.w > 0.f ? gv.w : 0.f;
+      gv.x = gn_affine(xv.x, mean, rstd, ga.x, be.x) > 0.f ? gv.x : 0.f;
+      gv.y = gn_affine(xv.y, mean, rstd, ga.y, be.y) > 0.f ? gv.y : 0.f;
+      gv.z = gn_affine(xv.z, mean, rstd, ga.z, be.z) > 0.f ? gv.z : 0.f;
+      gv.w = gn_affine(xv.w, mean, rstd, ga.w, be.w) > 0.f ? gv.w : 0.f;
     }
     float4 o;
     o.x = rstd * (gv.x * ga.x - (S1 + (xv.x - mean) * rstd * S2));
@@ -252,12 +258,12 @@ extern "C" int scan_groupnorm_relu_forward(const float* x, const scan_pyramid_t*
   return 0;
 }
 
-extern "C" int scan_groupnorm_relu_backward(const float* x, const float* y, const float* dy, const scan_pyramid_t* d,
+extern "C" int scan_groupnorm_relu_backward(const float* x, const float* beta, const float* dy, const scan_pyramid_t* d,
                                             int32_t C, int32_t G, const float* stats, const float* gamma, int32_t relu,
                                             float* dx, float* dgamma, float* dbeta, int32_t accumulate, float* ws,
                                             void* stream) {
   if (gn_check(d, C, G, "groupnorm_relu_backward")) return -1;
-  SCAN_CHECK_ARG(x && dy && stats && gamma && dx && dgamma && dbeta && ws && (y || !relu),
+  SCAN_CHECK_ARG(x && dy && stats && gamma && dx && dgamma && dbeta && ws && (beta || !relu),
                  "groupnorm_relu_backward: null pointer");
   hipStream_t st = as_stream(stream);
   double* ws_g = reinterpret_cast<double*>(ws);
@@ -267,9 +273,9 @@ extern "C" int scan_groupnorm_relu_backward(const float* x, const float* y, cons
     scan_set_error("groupnorm_relu_backward: memset failed");
     return -2;
   }
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, gn_grid(d), dim3(256), 0, st, x, y, dy, *d, G, stats, gamma, relu, ws_g, ws_c);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, gn_grid(d), dim3(256), 0, st, x, beta, dy, *d, G, stats, gamma, relu, ws_g, ws_c);
   SCAN_LAUNCH_CHECK("gn_bwd_reduce");
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, gn_grid(d), dim3(256), 0, st, x, y, dy, *d, G, stats, gamma, relu, ws_g, dx);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, gn_grid(d), dim3(256), 0, st, x, beta, dy, *d, G, stats, gamma, relu, ws_g, dx);
   SCAN_LAUNCH_CHECK("gn_bwd_apply");
   hipLaunchKernelGGL(gn_bwd_param_final_kernel, dim3(1), dim3(GN_C), 0, st, ws_c, dgamma, dbeta, accumulate);
   SCAN_LAUNCH_CHECK("gn_bwd_param_final");

@@ -394,7 +394,7 @@ class _GroupNormReLU(torch.autograd.Function):
         y = torch.empty_like(x)
         call("scan_groupnorm_relu_forward", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta), int(relu),
              _ptr(y), st)
-        ctx.save_for_backward(x, y, gamma, stats)
+        ctx.save_for_backward(x, beta, gamma, stats)  # the backward recomputes the ReLU mask from x: y is not kept
         ctx.cfg = (shape, relu)
         ctx.gbuf = ctx.bbuf = None
         if getattr(gamma, "_scan_flat", False) and getattr(beta, "_scan_flat", False) and gamma.grad is not None \
@@ -404,7 +404,7 @@ class _GroupNormReLU(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, stats = ctx.saved_tensors
+        x, beta, gamma, stats = ctx.saved_tensors
         shape, relu = ctx.cfg
         C = x.shape[1]
         dy = dy.contiguous()
@@ -414,7 +414,7 @@ class _GroupNormReLU(torch.autograd.Function):
         direct = ctx.gbuf is not None
         dg = ctx.gbuf if direct else x.new_empty((C,))
         db = ctx.bbuf if direct else x.new_empty((C,))
-        call("scan_groupnorm_relu_backward", _ptr(x), _ptr(y), _ptr(dy), shape.ref(), C, 32, _ptr(stats), _ptr(gamma),
+        call("scan_groupnorm_relu_backward", _ptr(x), _ptr(beta), _ptr(dy), shape.ref(), C, 32, _ptr(stats), _ptr(gamma),
              int(relu), _ptr(dx), _ptr(dg), _ptr(db), int(direct), _ptr(ws), _stream())
         if direct:
             return dx, None, None, None, None, None

@@ -33,15 +33,40 @@ PEAK_BF16X3_TFLOPS = 2500.0 / 3.0
 def pmc_traffic(kernel_name):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
     (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction).  None if not recorded."""
-    key = {"conv3x3_bf16x3_wgrad": "conv3x3_bf16x3_wgrad", "conv3x3_bf16x3_fwd": "conv3x3_bf16x3_fwd_dgrad_bn128",
-           "conv3x3_bf16x3_dgrad": "conv3x3_bf16x3_fwd_dgrad_bn128", "conv_igemm_fwd": "conv_igemm_fwd",
-           "conv_igemm_dgrad": "conv_igemm_dgrad", "conv_wgrad": "conv_wgrad"}.get(kernel_name)
+    key = {"conv3x3_wgrad_bf16x3_kernel": "conv3x3_bf16x3_wgrad",
+           "conv3x3_bf16x3_kernel<128,16,512>": "conv3x3_bf16x3_fwd_dgrad_bn128",
+           "conv3x3_bf16x3_kernel<64,8,256>": "conv3x3_bf16x3_fwd_bn64", "conv_igemm_kernel<0,4>": "conv_igemm_fwd",
+           "conv_igemm_kernel<1,4>": "conv_igemm_dgrad", "conv_wgrad_kernel": "conv_wgrad_fp32"}.get(kernel_name)
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             rec = json.load(f).get(key)
         return rec["hbm_bytes"] if rec else None
     except Exception:
         return None
+
+
+# timer record name (scan_amd/ops.py) -> kernel symbol as rocprofv3 lists it: forward and data-gradient launches of
+# a conv are the SAME kernel (dgrad = forward on dY with flipped/transposed weights)
+SYMBOL = {"conv3x3_bf16x3_fwd_bn128": "conv3x3_bf16x3_kernel<128,16,512>",
+          "conv3x3_bf16x3_dgrad_bn128": "conv3x3_bf16x3_kernel<128,16,512>",
+          "conv3x3_bf16x3_fwd_bn64": "conv3x3_bf16x3_kernel<64,8,256>",
+          "conv3x3_bf16x3_dgrad_bn64": "conv3x3_bf16x3_kernel<64,8,256>",
+          "conv3x3_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel",
+          "conv_igemm_fwd": "conv_igemm_kernel<0,4>", "conv_igemm_dgrad": "conv_igemm_kernel<1,4>",
+          "conv_wgrad": "conv_wgrad_kernel"}
+
+
+def by_symbol(ksum):
+    out = {}
+    for name, r in ksum.items():
+        g = out.setdefault(SYMBOL.get(name, name), {"launches": 0, "total_ms": 0.0, "flops": 0.0})
+        g["launches"] += r["launches"]
+        g["total_ms"] += r["total_ms"]
+        g["flops"] += r["flops"]
+    for g in out.values():
+        g["avg_ms"] = g["total_ms"] / g["launches"]
+        g["tflops"] = g["flops"] / (g["total_ms"] * 1e-3) / 1e12 if g["total_ms"] > 0 else 0.0
+    return out
 
 
 def peak_for(kernel_name):
@@ -162,7 +187,7 @@ def main():
     if rank == 0:
         pairs = B * world * a.steps
         value = pairs / dt
-        dom = max(ksum.items(), key=lambda kv: kv[1]["total_ms"]) if ksum else None
+        dom = max(by_symbol(ksum).items(), key=lambda kv: kv[1]["total_ms"]) if ksum else None
         roof = None
         if dom:
             name, r = dom

@@ -374,6 +374,35 @@ __device__ __forceinline__ bf16x8 tr_read8(const __bf16* p0) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// MFMA work of one staged chunk for one wave: TMN = number of live 32-row o tiles (2, or 1 when the second lies
+// beyond Nout)
+template <int TMN>
+__device__ __forceinline__ void wgrad_mma(const __bf16* Ah, const __bf16* Al, const __bf16* Bh, const __bf16* Bl,
+                                          int tr_off, int a_col, int b_col, f32x16 (&acc)[3][2]) {
+#pragma unroll
+  for (int s = 0; s < WK / 16; ++s) {
+    bf16x8 ah[TMN], al[TMN];
+#pragma unroll
+    for (int t = 0; t < TMN; ++t) {
+      const int oa = tr_off + 16 * s * WROW + a_col + 32 * t;
+      ah[t] = tr_read8(Ah + oa);
+      al[t] = tr_read8(Al + oa);
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int ob = tr_off + (16 * s + kx) * WROW + b_col;
+      const bf16x8 bh = tr_read8(Bh + ob);
+      const bf16x8 bl = tr_read8(Bl + ob);
+#pragma unroll
+      for (int tm = 0; tm < TMN; ++tm) {
+        acc[kx][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh, acc[kx][tm], 0, 0, 0);
+        acc[kx][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl, acc[kx][tm], 0, 0, 0);
+        acc[kx][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh, acc[kx][tm], 0, 0, 0);
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
     float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
@@ -474,12 +503,15 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     }
   };
 
-  // 8 waves: 2 (o) x 4 (c); each wave 64 o x 32 c = 2 x 1 MFMA tiles, for each of the 3 kx taps
-  const int wm = wid >> 2, wn = wid & 3;
+  // 8 waves: 2 (o) x 4 (c); each wave 64 o x 32 c = 2 x 1 MFMA tiles, for each of the 3 kx taps.  Waves that share
+  // a c column group sit on different SIMDs (wid % 4), so a tile with one live column group keeps two SIMDs busy
+  const int wm = wid & 1, wn = wid >> 1;
   const int lr = lane & 31, lh = lane >> 5;
   // transposed-read lane address: pixel row 8h + (l&15)>>2, channel column 16*((l>>4)&1) + 4*(l&3)
   const int tr_off = (8 * lh + ((lane & 15) >> 2)) * WROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
   const int a_col = wm * 64, b_col = wn * 32;
+  const bool c_act = c0 + b_col < Cs;
+  const bool o_act0 = o0 + a_col < Nout, o_act1 = o0 + a_col + 32 < Nout;
 
   f32x16 acc[3][2];
 #pragma unroll
@@ -500,28 +532,12 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     store_chunk();
     if (ch + 1 < ch_end) load_chunk(ch + 1);
     __syncthreads();
-#pragma unroll
-    for (int s = 0; s < WK / 16; ++s) {
-      bf16x8 ah[2], al[2];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int oa = tr_off + 16 * s * WROW + a_col + 32 * t;
-        ah[t] = tr_read8(Ah + oa);
-        al[t] = tr_read8(Al + oa);
-      }
-#pragma unroll
-      for (int kx = 0; kx < 3; ++kx) {
-        const int ob = tr_off + (16 * s + kx) * WROW + b_col;
-        const bf16x8 bh = tr_read8(Bh + ob);
-        const bf16x8 bl = tr_read8(Bl + ob);
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-          acc[kx][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh, acc[kx][tm], 0, 0, 0);
-          acc[kx][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl, acc[kx][tm], 0, 0, 0);
-          acc[kx][tm] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh, acc[kx][tm], 0, 0, 0);
-        }
-      }
-    }
+    // wave-uniform skips: a wave whose 32 c columns lie beyond Cs (third c tile of Cin = 264 / 265) or whose o rows
+    // lie beyond Nout (Cout = 8 / 5 / 1 heads) has nothing to contribute; it still stages and synchronises
+    if (c_act && o_act1)
+      wgrad_mma<2>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
+    else if (c_act && o_act0)
+      wgrad_mma<1>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
     __syncthreads();  // every wave is done with this chunk's LDS image
   }
 

@@ -202,7 +202,7 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
             ev.record(torch.cuda.current_stream())
             _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
     y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
-    ev = kernel_timer.begin(name, flops)
+    ev = kernel_timer.begin(name + ("_bn128" if nout > 64 else "_bn64"), flops)  # the two template instances
     call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask), _ptr(y),
          nout, ns, int(bool(relu)), st)
     kernel_timer.end(ev)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs, --output-format csv).
+
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/pmcF -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/pmcW -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline
+    python tools/pmc_summarize.py <fetch counter_collection.csv[.gz]> <write ...csv[.gz]> > profiles/rNN_pmc_traffic.json
+
+Counter unit is KiB.  Per /opt/skills/guides/MI355X_MICROARCH.md FETCH_SIZE under-reports wide coalesced reads by
+2x on gfx950, so hbm_read_bytes = 2 * FETCH_SIZE * 1024 (checked on the dynamic-conv forward: 89.6 MB counted vs
+89.4 MB algorithmic).  Values are averages per launch over all launches of the kernel group in the run."""
+import collections
+import csv
+import gzip
+import json
+import sys
+
+GROUPS = [  # (substring of the kernel name, group key)
+    ("conv3x3_bf16x3_kernelILi128", "conv3x3_bf16x3_fwd_dgrad_bn128"),
+    ("conv3x3_bf16x3_kernelILi64", "conv3x3_bf16x3_fwd_bn64"),
+    ("conv3x3_wgrad_bf16x3_kernel", "conv3x3_bf16x3_wgrad"),
+    ("slab_bias_reduce_kernel", "slab_bias_reduce"),
+    ("conv_igemm_kernel<0", "conv_igemm_fwd"), ("conv_igemm_kernel<1", "conv_igemm_dgrad"),
+    ("conv_wgrad_kernel", "conv_wgrad_fp32"),
+    ("gn_stats_kernel", "gn_stats"), ("gn_apply_kernel", "gn_apply"), ("gn_bwd_reduce_kernel", "gn_bwd_reduce"),
+    ("gn_bwd_apply_kernel", "gn_bwd_apply"), ("relu_bwd_kernel", "relu_bwd"),
+    ("maxpool2_fwd_kernel", "maxpool2_fwd"), ("maxpool2_bwd_kernel", "maxpool2_bwd"),
+    ("dynconv_fwd_kernel", "dynconv_fwd"), ("dynconv_bwd_kernel", "dynconv_bwd"),
+    ("sigmoid_focal_fwd", "sigmoid_focal_fwd"), ("sfl_fwd", "softmax_focal_fwd"), ("sfl_bwd", "softmax_focal_bwd"),
+    ("cka_fwd_kernel", "cka_bce_fwd"), ("cka_bwd_kernel", "cka_bce_bwd"), ("scale_kernel", "grl_scale"),
+    ("sgd_kernel", "sgd_momentum"), ("weight_split_kernel", "weight_split"),
+]
+
+
+def read(path, counter):
+    op = gzip.open if path.endswith(".gz") else open
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    with op(path, "rt") as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            name = r["Kernel_Name"]
+            for sub, key in GROUPS:
+                if sub in name:
+                    acc[key][0] += 1
+                    acc[key][1] += float(r["Counter_Value"])
+                    break
+    return acc
+
+
+def main():
+    fe, wr = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
+    out = {"_note": __doc__.split("\n\n")[-1].replace("\n", " ")}
+    for _, key in GROUPS:
+        if key not in fe or key not in wr or key in out:
+            continue
+        n = fe[key][0]
+        f_kib, w_kib = fe[key][1] / n, wr[key][1] / max(1, wr[key][0])
+        rd, wb = int(2 * f_kib * 1024), int(w_kib * 1024)
+        out[key] = {"launches": n, "FETCH_SIZE_KiB_raw": round(f_kib, 1), "WRITE_SIZE_KiB": round(w_kib, 1),
+                    "hbm_read_bytes": rd, "hbm_write_bytes": wb, "hbm_bytes": rd + wb}
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()

@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=2, help="source (= target) frames per GPU per step")
+    ap.add_argument("--model", choices=("c2f", "s2c", "k2c"), default="c2f",
+                    help="which shipped yaml's model (engine.CONFIGS); the headline metric is c2f")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run everything on one stream (no side-stream overlap): what the per-kernel roofline "
@@ -130,8 +132,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from scan_amd import engine, ops, synth
-    model = engine.build_model(9, device=dev)
-    engine.load_procedural_weights(model)
+    mcfg = engine.CONFIGS[a.model]
+    model = engine.build_model(mcfg["num_classes"], mcfg["test_mode"], device=dev, transfer_cfg=mcfg["transfer_cfg"])
+    engine.load_procedural_weights(model, mcfg["num_classes"])
     # under torch.distributed.run the data-parallel path (flat-buffer all-reduce on the side stream, paradigm
     # all-reduce) is exercised even with a single rank
     trainer = engine.Trainer(model, distributed=True if dist.is_initialized() else None)
@@ -147,9 +150,11 @@ def main():
     if a.serial_streams:
         set_serial(True)
     H, W, B = a.height, a.width, a.batch
-    imgs_s = synth.synth_images(B, H, W, 1234 + 100 * rank).to(dev)
-    imgs_t = synth.synth_images(B, H, W, 2234 + 100 * rank).to(dev)
-    tg = [(b.to(dev), l.to(dev)) for b, l in synth.synth_targets(B, H, W, 8, 12, 4321 + 100 * rank)]
+    # frames go through the collator's zero padding to /32 (structures.to_image_list), e.g. 1333x2666 -> 1344x2688
+    imgs_s = engine.to_image_list([t.to(dev) for t in synth.synth_image_list([(H, W)] * B, 1234 + 100 * rank)], 32)
+    imgs_t = engine.to_image_list([t.to(dev) for t in synth.synth_image_list([(H, W)] * B, 2234 + 100 * rank)], 32)
+    tg = [(b.to(dev), l.to(dev))
+          for b, l in synth.synth_targets(B, H, W, mcfg["num_classes"] - 1, 12, 4321 + 100 * rank)]
 
     def barrier():
         if dist.is_initialized():
@@ -205,7 +210,7 @@ def main():
                                              "share_of_serial_step": round(v["total_ms"] / (dtr * 1e3), 3)}
                                          for k, v in ksum.items()}}
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and a.model == "c2f":
             sh, sw = H, W  # one full-size pair: ~10 s on 16 host threads
             cdt, cores = cpu_baseline(sh, sw)
             scale = (sh * sw) / float(H * W)
@@ -216,9 +221,11 @@ def main():
             "metric": "train images/sec (whole node), VGG16 C2F 1024x2048", "value": round(value, 4),
             "unit": "image pairs/s (1 source + 1 target frame per pair)", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32 (3x3 convs: fp32 operands split hi+lo into 2xbf16, 3 bf16 MFMAs, fp32 accumulate)", "data": "synthetic",
-            "config": {"workload": "SCAN C2F VGG16-FPN DA iteration, %d src + %d tgt frames/GPU at %dx%d, "
-                                   "forward_target=False, procedural weights" % (B, B, H, W),
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "SCAN %s VGG16-FPN DA iteration, %d src + %d tgt frames/GPU at %dx%d, "
+                                   "forward_target=False, procedural weights" % (a.model.upper(), B, B, H, W),
+                       "arithmetic": "fp32 storage and accumulation; 3x3 convs split each fp32 operand hi+lo into "
+                                     "2 x bf16 and issue 3 bf16 MFMAs per product (1.7e-6 rel on the losses vs fp32)",
                        "global_batch_pairs": B * world, "frames_per_s": round(2 * value, 4), "parallelism": "dp%d" % world,
                        "losses_finite": finite},
             "roofline": roof, "cpu_baseline": cpu,

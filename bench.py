@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--batch", type=int, default=2, help="source (= target) frames per GPU per step")
-    ap.add_argument("--model", choices=("c2f", "s2c", "k2c"), default="c2f",
+    ap.add_argument("--model", choices=("c2f", "s2c", "k2c", "k2c_r50"), default="c2f",
                     help="which shipped yaml's model (engine.CONFIGS); the headline metric is c2f")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--serial-streams", action="store_true",
@@ -133,8 +133,10 @@ def main():
 
     from scan_amd import engine, ops, synth
     mcfg = engine.CONFIGS[a.model]
-    model = engine.build_model(mcfg["num_classes"], mcfg["test_mode"], device=dev, transfer_cfg=mcfg["transfer_cfg"])
-    engine.load_procedural_weights(model, mcfg["num_classes"])
+    body = mcfg.get("conv_body", "VGG-16-FPN-RETINANET")
+    model = engine.build_model(mcfg["num_classes"], mcfg["test_mode"], device=dev, transfer_cfg=mcfg["transfer_cfg"],
+                               conv_body=body)
+    engine.load_procedural_weights(model, mcfg["num_classes"], body)
     # under torch.distributed.run the data-parallel path (flat-buffer all-reduce on the side stream, paradigm
     # all-reduce) is exercised even with a single rank
     trainer = engine.Trainer(model, distributed=True if dist.is_initialized() else None)
@@ -222,8 +224,8 @@ def main():
             "unit": "image pairs/s (1 source + 1 target frame per pair)", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "SCAN %s VGG16-FPN DA iteration, %d src + %d tgt frames/GPU at %dx%d, "
-                                   "forward_target=False, procedural weights" % (a.model.upper(), B, B, H, W),
+            "config": {"workload": "SCAN %s %s DA iteration, %d src + %d tgt frames/GPU at %dx%d, "
+                                   "forward_target=False, procedural weights" % (a.model.upper(), body, B, B, H, W),
                        "arithmetic": "fp32 storage and accumulation; 3x3 convs split each fp32 operand hi+lo into "
                                      "2 x bf16 and issue 3 bf16 MFMAs per product (1.7e-6 rel on the losses vs fp32)",
                        "global_batch_pairs": B * world, "frames_per_s": round(2 * value, 4), "parallelism": "dp%d" % world,

@@ -128,7 +128,7 @@ int scan_nms(const float* dets, const float* scores, const float* labels, int64_
  * x: pyramid [Mi, Cin_s] (row stride Cin_s floats, Cin_s % 4 == 0, channels >= Cin are zero padding)
  * w: [Cout][k*k][Cin_s] fp32 ("OHWI", what a channels_last torch weight is physically)
  * y: pyramid [Mo, Cout_s]; bias [Cout] or NULL; relu != 0 fuses max(0,.).
- * ksize in {1,3}; stride in {1,2}; pad = ksize/2. */
+ * ksize in {1,3,5,7}; stride in {1,2}; pad = ksize/2. */
 int scan_conv2d_forward(const float* x, const scan_pyramid_t* xd, int32_t Cin_s, const float* w, const float* bias,
                         float* y, const scan_pyramid_t* yd, int32_t Cout, int32_t Cout_s, int32_t ksize,
                         int32_t stride, int32_t relu, void* stream);
@@ -196,6 +196,14 @@ int scan_groupnorm_relu_backward(const float* x, const float* beta, const float*
 int scan_maxpool2x2_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream);
 int scan_maxpool2x2_backward(const float* x, const float* y, const float* dy, int32_t N, int32_t H, int32_t W,
                              int32_t C, float* dx, int32_t relu_mask, void* stream);
+
+/* ---- ResNet body pieces (reference backbone/resnet.py): stem pooling F.max_pool2d(x, 3, 2, 1) on NHWC rows
+ *      (:335; forward only -- the stem is frozen for FREEZE_CONV_BODY_AT >= 1), y [N,(H-1)/2+1,(W-1)/2+1,C], C % 4 == 0;
+ *      and the residual join y = max(a + b, 0) (:312-313; backward = scan_relu_backward(dy, y) to both branches).
+ *      FrozenBatchNorm2d (layers/batch_norm.py:5-24) is an affine per channel and is folded into the conv weights /
+ *      bias by the host side. ---- */
+int scan_maxpool3x3s2_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream);
+int scan_add_relu(const float* a, const float* b, float* y, int64_t n, void* stream);
 
 /* ---- fused SGD with momentum (replaces torch.optim.SGD as configured by solver/build.py:7-43) ----
  * g' = g + wd*p ; buf = momentum*buf + g' ; p -= lr*buf   (first_step != 0: buf = g') */

@@ -136,13 +136,19 @@ def _grad_digest(named):
     return out
 
 
+VGG_FROZEN = ("body.features.0.", "body.features.2.", "body.features.5.", "body.features.7.")
+RESNET_FROZEN = ("body.stem.", "body.layer1.")
+R50_CFG = ["MODEL.BACKBONE.CONV_BODY", "R-50-FPN-RETINANET", "MODEL.RESNETS.BACKBONE_OUT_CHANNELS", 256]
+
+
 def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False, K=9,
-             yaml_name="scan_vgg16_cityscapace_to_foggy.yaml", sizes=None):
+             yaml_name="scan_vgg16_cityscapace_to_foggy.yaml", sizes=None, extra_cfg=(),
+             conv_body="VGG-16-FPN-RETINANET"):
     """Full DA iteration, procedural weights/inputs.  K = MODEL.FCOS.NUM_CLASSES of the yaml (9 C2F, 2 S2C)."""
-    cfg = rh.make_cfg(yaml_name=yaml_name)
-    assert cfg.MODEL.FCOS.NUM_CLASSES == K
+    cfg = rh.make_cfg(list(extra_cfg), yaml_name=yaml_name)
+    assert cfg.MODEL.FCOS.NUM_CLASSES == K and cfg.MODEL.BACKBONE.CONV_BODY == conv_body
     model = rh.build_models(cfg, dropout=0.0)
-    sds = synth.all_state_dicts(K)
+    sds = synth.all_state_dicts(K, conv_body)
     _load(model, sds)
     if sizes is None:
         imgs_s = synth.synth_images(N, H, W, 1234)
@@ -180,11 +186,11 @@ def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False
         **{"label_map_%d" % l: lm.numpy() for l, lm in enumerate(label_maps)})
     with open(os.path.join(GOLD, name + ".json"), "w") as f:
         json.dump({"H": H, "W": W, "N": N, "sizes": sizes, "seeds": {"src": 1234, "tgt": 2234, "boxes": 4321},
-                   "forward_target": forward_target, "num_classes": K,
+                   "forward_target": forward_target, "num_classes": K, "conv_body": conv_body,
                    "transfer_cfg": [t for t in cfg.MODEL.MIDDLE_HEAD.TRANSFER_CFG], "losses": losses, "grad_digest": grads}, f)
     print(name, {k: round(v, 6) for k, v in losses.items()})
     if check:
-        P = {k: scan_ref.params(v, frozen_prefixes=("body.features.0.", "body.features.2.", "body.features.5.", "body.features.7."))
+        P = {k: scan_ref.params(v, frozen_prefixes=VGG_FROZEN if conv_body.startswith("VGG") else RESNET_FROZEN)
              for k, v in sds.items()}
         st = scan_ref.PrototypeState(sds["middle_head"]["prototype"])
         mine = scan_ref.da_iteration(P, st, imgs_s, tg, imgs_t, K=K, forward_target=forward_target,
@@ -281,6 +287,9 @@ def main():
     if "step_s2c_ft" in todo:
         gen_step(a.check, H=256, W=512, name="step_s2c_ft_256x512", K=2, forward_target=True,
                  yaml_name="scan_vgg16_sim10k_to_cityscapes.yaml")
+    if "step_r50" in todo:  # BASELINE.json configs[3]: K2C yaml with the R-50-FPN-RETINANET body
+        gen_step(a.check, name="step_k2c_r50_128x256", K=2, yaml_name="scan_vgg16_kitti_to_cityscapes.yaml",
+                 extra_cfg=R50_CFG, conv_body="R-50-FPN-RETINANET")
     if "inference" in todo:
         gen_inference(a.check)
     if "inference_s2c" in todo:

@@ -28,7 +28,9 @@ def params(sd, requires_grad=True, frozen_prefixes=()):
     out = {}
     for k, v in sd.items():
         t = v.detach().clone().float()
-        if requires_grad and t.is_floating_point() and k != "prototype" and not k.startswith(tuple(frozen_prefixes)):
+        bn_buffer = ".bn" in k or ".downsample.1." in k  # FrozenBatchNorm2d holds buffers, not parameters
+        if requires_grad and t.is_floating_point() and k != "prototype" and not bn_buffer \
+                and not k.startswith(tuple(frozen_prefixes)):
             t.requires_grad_(True)
         out[k] = t
     return out
@@ -58,6 +60,54 @@ def vgg_fpn_forward(p, x):
     p6 = conv("fpn.top_blocks.p6", p5, stride=2, pad=1)
     p7 = conv("fpn.top_blocks.p7", F.relu(p6), stride=2, pad=1)
     return [p3, p4, p5, p6, p7]
+
+
+def _frozen_bn(p, name, x):
+    """FrozenBatchNorm2d.forward (layers/batch_norm.py:17-24): no eps."""
+    scale = p[name + ".weight"] * p[name + ".running_var"].rsqrt()
+    bias = p[name + ".bias"] - p[name + ".running_mean"] * scale
+    return x * scale.reshape(1, -1, 1, 1) + bias.reshape(1, -1, 1, 1)
+
+
+def resnet_fpn_forward(p, x):
+    """R-50/101-FPN-RETINANET (backbone/backbone.py:94-117): StemWithFixedBatchNorm (resnet.py:316-336),
+    BottleneckWithFixedBatchNorm blocks with the stride in the first 1x1 (resnet.py:228-314), FPN on C3..C5
+    (in_channels_list [0, 512, 1024, 2048] -> fpn_inner/layer 2..4) + LastLevelP6P7 on P5.  Returns [P3..P7]."""
+    x = F.relu(_frozen_bn(p, "body.stem.bn1", F.conv2d(x, p["body.stem.conv1.weight"], stride=2, padding=3)))
+    x = F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+    outs = []
+    for i in range(1, 5):
+        b = 0
+        while "body.layer%d.%d.conv1.weight" % (i, b) in p:
+            q = "body.layer%d.%d" % (i, b)
+            stride = 2 if (i > 1 and b == 0) else 1
+            out = F.relu(_frozen_bn(p, q + ".bn1", F.conv2d(x, p[q + ".conv1.weight"], stride=stride)))
+            out = F.relu(_frozen_bn(p, q + ".bn2", F.conv2d(out, p[q + ".conv2.weight"], padding=1)))
+            out = _frozen_bn(p, q + ".bn3", F.conv2d(out, p[q + ".conv3.weight"]))
+            idt = x
+            if q + ".downsample.0.weight" in p:
+                idt = _frozen_bn(p, q + ".downsample.1", F.conv2d(x, p[q + ".downsample.0.weight"], stride=stride))
+            x = F.relu(out + idt)
+            b += 1
+        outs.append(x)
+    c3, c4, c5 = outs[1], outs[2], outs[3]
+
+    def conv(name, t, stride=1, pad=0):
+        return F.conv2d(t, p[name + ".weight"], p[name + ".bias"], stride=stride, padding=pad)
+
+    inner5 = conv("fpn.fpn_inner4", c5)
+    p5 = conv("fpn.fpn_layer4", inner5, pad=1)
+    inner4 = conv("fpn.fpn_inner3", c4) + F.interpolate(inner5, scale_factor=2, mode="nearest")
+    p4 = conv("fpn.fpn_layer3", inner4, pad=1)
+    inner3 = conv("fpn.fpn_inner2", c3) + F.interpolate(inner4, scale_factor=2, mode="nearest")
+    p3 = conv("fpn.fpn_layer2", inner3, pad=1)
+    p6 = conv("fpn.top_blocks.p6", p5, stride=2, pad=1)
+    p7 = conv("fpn.top_blocks.p7", F.relu(p6), stride=2, pad=1)
+    return [p3, p4, p5, p6, p7]
+
+
+def backbone_forward(p, x):
+    return resnet_fpn_forward(p, x) if "body.stem.conv1.weight" in p else vgg_fpn_forward(p, x)
 
 
 def tower(p, prefix, x, n, gn=True):
@@ -471,7 +521,7 @@ def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, s
     out = {}
     images_s, _ = pad_images(images_s)
     images_t, _ = pad_images(images_t)
-    feats = vgg_fpn_forward(P["backbone"], images_s)
+    feats = backbone_forward(P["backbone"], images_s)
     f_s, node_loss, act_loss, maps_s = middle_head_source(P["middle_head"], state, feats, targets_s, K)
     lg, rg, ct = fcos_head(P["fcos"], f_s)
     lc, lr, lctr = fcos_loss(lg, rg, ct, targets_s)
@@ -484,7 +534,7 @@ def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, s
         ds["loss_adv_%s_CON_ds" % lvl] = con_lambda * discriminator_loss(P["dis_%s_CON" % lvl], f_s[i], maps_s[i], 1.0, K)
     sum(ds.values()).backward()
     out.update({k: float(v.detach()) for k, v in ds.items()})
-    feats = vgg_fpn_forward(P["backbone"], images_t)
+    feats = backbone_forward(P["backbone"], images_t)
     dt = {}
     if forward_target:
         f_t, cons, maps_t = middle_head_target(P["middle_head"], state, feats, K, transfer=transfer)
@@ -583,7 +633,7 @@ def inference(P, state, images, nms_fn, mode="precision", K=9):
     head -> score fusion (fcos.py:162-169) -> post-processor."""
     with torch.no_grad():
         images, sizes = pad_images(images)
-        feats = vgg_fpn_forward(P["backbone"], images)
+        feats = backbone_forward(P["backbone"], images)
         f, maps = middle_head_plain(P["middle_head"], state, feats, K)
         lg, rg, ct = fcos_head(P["fcos"], f)
         if mode == "light":

@@ -453,7 +453,7 @@ static int launch_igemm(const float* src, const scan_pyramid_t* sd, int Cs, cons
 }
 
 static int check_geometry(const scan_pyramid_t* xd, const scan_pyramid_t* yd, int ksize, int stride, const char* who) {
-  SCAN_CHECK_ARG(ksize == 1 || ksize == 3, "%s: ksize must be 1 or 3, got %d", who, ksize);
+  SCAN_CHECK_ARG(ksize == 1 || ksize == 3 || ksize == 5 || ksize == 7, "%s: ksize must be 1, 3, 5 or 7, got %d", who, ksize);
   SCAN_CHECK_ARG(stride == 1 || stride == 2, "%s: stride must be 1 or 2, got %d", who, stride);
   SCAN_CHECK_ARG(xd->n_levels == yd->n_levels && xd->n_images == yd->n_images, "%s: pyramid mismatch", who);
   const int pad = ksize / 2;

@@ -531,3 +531,75 @@ extern "C" int scan_maxpool2x2_backward(const float* x, const float* y, const fl
   SCAN_LAUNCH_CHECK("maxpool2_bwd");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// ResNet stem pooling: 3x3 / stride 2 / pad 1 max-pool on NHWC rows (F.max_pool2d(x, 3, 2, 1) in BaseStem.forward,
+// reference backbone/resnet.py:335).  Forward only: the stem is frozen whenever FREEZE_CONV_BODY_AT >= 1 (default 2).
+__global__ __launch_bounds__(256) void maxpool3s2_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C,
+                                                             int Ho, int Wo, float* __restrict__ y) {
+  const int C4 = C >> 2;
+  const int64_t total = (int64_t)N * Ho * Wo * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    int64_t p = i / C4;
+    const int xo = (int)(p % Wo);
+    p /= Wo;
+    const int yo = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      const int yy = 2 * yo - 1 + dy;
+      if (yy < 0 || yy >= H) continue;
+#pragma unroll
+      for (int dx = 0; dx < 3; ++dx) {
+        const int xx = 2 * xo - 1 + dx;
+        if (xx < 0 || xx >= W) continue;
+        const float4 v = reinterpret_cast<const float4*>(x + (((int64_t)n * H + yy) * W + xx) * C)[c4];
+        m.x = fmaxf(m.x, v.x);
+        m.y = fmaxf(m.y, v.y);
+        m.z = fmaxf(m.z, v.z);
+        m.w = fmaxf(m.w, v.w);
+      }
+    }
+    reinterpret_cast<float4*>(y)[i] = m;
+  }
+}
+
+extern "C" int scan_maxpool3x3s2_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y,
+                                         void* stream) {
+  SCAN_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && C > 0 && (C & 3) == 0,
+                 "maxpool3x3s2_forward: bad arguments (C %% 4 == 0 required)");
+  const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+  const int64_t total = (int64_t)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(maxpool3s2_fwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, N, H, W, C,
+                     Ho, Wo, y);
+  SCAN_LAUNCH_CHECK("maxpool3s2_fwd");
+  return 0;
+}
+
+// residual join of a bottleneck block: y = max(a + b, 0)  (out += identity; F.relu_(out), resnet.py:312-313).
+// The backward is scan_relu_backward(dy, y) handed to both branches.
+__global__ __launch_bounds__(256) void add_relu_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       float* __restrict__ y, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    const float4 u = reinterpret_cast<const float4*>(a)[i], v = reinterpret_cast<const float4*>(b)[i];
+    float4 o;
+    o.x = fmaxf(u.x + v.x, 0.f);
+    o.y = fmaxf(u.y + v.y, 0.f);
+    o.z = fmaxf(u.z + v.z, 0.f);
+    o.w = fmaxf(u.w + v.w, 0.f);
+    reinterpret_cast<float4*>(y)[i] = o;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (int64_t i = n4 << 2; i < n; ++i) y[i] = fmaxf(a[i] + b[i], 0.f);
+}
+
+extern "C" int scan_add_relu(const float* a, const float* b, float* y, int64_t n, void* stream) {
+  SCAN_CHECK_ARG(a && b && y && n >= 0, "add_relu: bad arguments");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(add_relu_kernel, dim3(grid_for(n / 4 + 1, 256)), dim3(256), 0, as_stream(stream), a, b, y, n);
+  SCAN_LAUNCH_CHECK("add_relu");
+  return 0;
+}

@@ -22,6 +22,7 @@ from .modeling.condgraph import build_condgraph
 from .modeling.discriminator import FCOSDiscriminator_con
 from .modeling import fcos as fcos_mod
 from .modeling.fcos import build_fcos
+from .modeling.resnet import build_resnet_fpn_backbone
 
 LEVELS = ("P3", "P4", "P5", "P6", "P7")
 DIS_ORDER = ("P7", "P6", "P5", "P4", "P3")  # order the reference builds / iterates them
@@ -32,13 +33,23 @@ CONFIGS = {
     "c2f": dict(num_classes=9, test_mode="precision", transfer_cfg=("NODES", "ADJ")),  # Cityscapes -> Foggy
     "s2c": dict(num_classes=2, test_mode="common", transfer_cfg=(None,)),  # Sim10k -> Cityscapes
     "k2c": dict(num_classes=2, test_mode="common", transfer_cfg=(None,)),  # KITTI -> Cityscapes
+    # BASELINE.json configs[3]: the K2C yaml with MODEL.BACKBONE.CONV_BODY R-50-FPN-RETINANET and
+    # MODEL.RESNETS.BACKBONE_OUT_CHANNELS 256 (the reference's own ResNet yamls, configs/epm/*R_101*, set these)
+    "k2c_r50": dict(num_classes=2, test_mode="common", transfer_cfg=(None,), conv_body="R-50-FPN-RETINANET"),
 }
 
 
-def build_model(num_classes=9, test_mode="precision", device="cuda", attn_dropout=0.1, transfer_cfg=("NODES", "ADJ")):
+def build_model(num_classes=9, test_mode="precision", device="cuda", attn_dropout=0.1, transfer_cfg=("NODES", "ADJ"),
+                conv_body="VGG-16-FPN-RETINANET"):
     """dict MODEL{backbone, middle_head, fcos, dis_P*_CON} like tools/train_net_da.py:43-48,223-274."""
+    if conv_body == "VGG-16-FPN-RETINANET":
+        backbone = build_backbone()
+    elif conv_body in ("R-50-FPN-RETINANET", "R-101-FPN-RETINANET"):
+        backbone = build_resnet_fpn_backbone(conv_body[:-len("-FPN-RETINANET")])
+    else:
+        raise ValueError("conv_body %r is not built" % conv_body)
     model = {
-        "backbone": build_backbone(),
+        "backbone": backbone,
         "middle_head": build_condgraph(None, 256, num_classes, transfer_cfg),
         "fcos": build_fcos(None, num_classes, test_mode),
     }
@@ -64,8 +75,8 @@ def load_state_dicts(model, sds):
                 p.data = p.data.contiguous(memory_format=torch.channels_last)
 
 
-def load_procedural_weights(model, num_classes=9):
-    load_state_dicts(model, synth.all_state_dicts(num_classes))
+def load_procedural_weights(model, num_classes=9, conv_body="VGG-16-FPN-RETINANET"):
+    load_state_dicts(model, synth.all_state_dicts(num_classes, conv_body))
 
 
 # ----------------------------------------------------------------------------- forward

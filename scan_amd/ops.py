@@ -210,7 +210,7 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
 
 
 class _Conv2d(torch.autograd.Function):
-    """conv (k in {1,3}, stride in {1,2}, pad k//2) + bias (+ ReLU) on a pyramid.
+    """conv (k in {1,3,5,7}, stride in {1,2}, pad k//2) + bias (+ ReLU) on a pyramid.
 
     relu = "deferred": the forward applies the ReLU, the backward does NOT mask dy -- the contract is that every
     consumer of y multiplies its dx by (y > 0) itself (mask_dx=True on a conv, relu_input=True on the max-pool),
@@ -378,6 +378,44 @@ def maxpool2x2(x, shape, relu_input=False):
     assert shape.n_levels == 1
     (h, w) = shape.sizes[0]
     return _MaxPool2x2.apply(x, shape, relu_input), PyramidShape(shape.n_images, [(h // 2, w // 2)])
+
+
+def maxpool3x3s2(x, shape):
+    """F.max_pool2d(x, 3, 2, 1) of a single-level pyramid (ResNet stem, reference backbone/resnet.py:335).
+    Forward only: the stem is frozen for FREEZE_CONV_BODY_AT >= 1."""
+    assert shape.n_levels == 1
+    _chk(x)
+    if x.requires_grad:
+        raise RuntimeError("maxpool3x3s2 has no backward: the ResNet stem must be frozen (FREEZE_CONV_BODY_AT >= 1)")
+    (h, w), n = shape.sizes[0], shape.n_images
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    y = x.new_empty((n * ho * wo, x.shape[1]))
+    call("scan_maxpool3x3s2_forward", _ptr(x), n, h, w, x.shape[1], _ptr(y), _stream())
+    return y, PyramidShape(n, [(ho, wo)])
+
+
+class _AddReLU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _chk(a, b)
+        assert a.shape == b.shape
+        y = torch.empty_like(a)
+        call("scan_add_relu", _ptr(a), _ptr(b), _ptr(y), a.numel(), _stream())
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        g = torch.empty_like(dy)
+        call("scan_relu_backward", _ptr(dy), _ptr(y), _ptr(g), dy.numel(), _stream())
+        return g, g
+
+
+def add_relu(a, b):
+    """max(a + b, 0): the residual join of a bottleneck block."""
+    return _AddReLU.apply(a, b)
 
 
 # ----------------------------------------------------------------------------- GroupNorm + ReLU

@@ -73,6 +73,50 @@ def backbone_state_dict():
     return sd
 
 
+RESNET_BLOCKS = {"R-50": (3, 4, 6, 3), "R-101": (3, 4, 23, 3)}
+
+
+def _conv_nobias(sd, name, cout, cin, k, gain):
+    sd[name + ".weight"] = _normal(name + ".weight", (cout, cin, k, k), gain / math.sqrt(cin * k * k))
+
+
+def _frozen_bn(sd, name, c, gain=1.0):
+    """FrozenBatchNorm2d buffers (reference layers/batch_norm.py:5-24); running_var strictly positive (no eps there)."""
+    sd[name + ".weight"] = gain * (1.0 + _normal(name + ".weight", (c,), 0.1))
+    sd[name + ".bias"] = _normal(name + ".bias", (c,), 0.1)
+    sd[name + ".running_mean"] = _normal(name + ".running_mean", (c,), 0.1)
+    sd[name + ".running_var"] = torch.from_numpy(_rs(name + ".running_var").uniform(0.5, 1.5, (c,)).astype(np.float32))
+
+
+def resnet_backbone_state_dict(arch="R-50"):
+    """ResNet body + FPN(P3..P5) + P6/P7 of R-50/101-FPN-RETINANET (reference backbone/backbone.py:94-117,
+    backbone/resnet.py).  The last BN of every block is scaled down so 16 residual joins keep O(1) activations."""
+    sd = {}
+    _conv_nobias(sd, "body.stem.conv1", 64, 3, 7, math.sqrt(2.0) / 60.0)  # inputs are O(70): bring them to O(1)
+    _frozen_bn(sd, "body.stem.bn1", 64)
+    cin = 64
+    for i, n in enumerate(RESNET_BLOCKS[arch], 1):
+        mid, cout = 64 * 2 ** (i - 1), 256 * 2 ** (i - 1)
+        for b in range(n):
+            p = "body.layer%d.%d" % (i, b)
+            if cin != cout:
+                _conv_nobias(sd, p + ".downsample.0", cout, cin, 1, 1.0)
+                _frozen_bn(sd, p + ".downsample.1", cout)
+            _conv_nobias(sd, p + ".conv1", mid, cin, 1, math.sqrt(2.0))
+            _frozen_bn(sd, p + ".bn1", mid)
+            _conv_nobias(sd, p + ".conv2", mid, mid, 3, math.sqrt(2.0))
+            _frozen_bn(sd, p + ".bn2", mid)
+            _conv_nobias(sd, p + ".conv3", cout, mid, 1, math.sqrt(2.0))
+            _frozen_bn(sd, p + ".bn3", cout, gain=0.5)
+            cin = cout
+    for idx, c in ((2, 512), (3, 1024), (4, 2048)):
+        _conv(sd, "fpn.fpn_inner%d" % idx, 256, c, 1, 1.0)
+        _conv(sd, "fpn.fpn_layer%d" % idx, 256, 256, 3, 1.0)
+    _conv(sd, "fpn.top_blocks.p6", 256, 256, 3, 1.0)
+    _conv(sd, "fpn.top_blocks.p7", 256, 256, 3, math.sqrt(2.0))
+    return sd
+
+
 def middle_head_state_dict(num_classes=9, proto_iter=3):
     """GRAPHModule (reference rpn/fcos/condgraph.py:127-253)."""
     K = num_classes
@@ -128,9 +172,10 @@ def discriminator_state_dict(level, num_classes=9):
 LEVEL_NAMES = ("P3", "P4", "P5", "P6", "P7")
 
 
-def all_state_dicts(num_classes=9):
+def all_state_dicts(num_classes=9, conv_body="VGG-16-FPN-RETINANET"):
     out = {
-        "backbone": backbone_state_dict(),
+        "backbone": backbone_state_dict() if conv_body.startswith("VGG") else
+        resnet_backbone_state_dict(conv_body[:-len("-FPN-RETINANET")]),
         "middle_head": middle_head_state_dict(num_classes),
         "fcos": fcos_state_dict(num_classes),
     }

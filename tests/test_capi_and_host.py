@@ -33,7 +33,7 @@ def test_argument_validation_without_device():
     with pytest.raises(RuntimeError, match="Cin_s"):
         _lib.call("scan_conv2d_forward", None, d.ref(), 6, None, None, None, d.ref(), 8, 8, 3, 1, 0, None)
     with pytest.raises(RuntimeError, match="ksize"):
-        _lib.call("scan_conv2d_forward", None, d.ref(), 8, None, None, None, d.ref(), 8, 8, 5, 1, 0, None)
+        _lib.call("scan_conv2d_forward", None, d.ref(), 8, None, None, None, d.ref(), 8, 8, 4, 1, 0, None)
     with pytest.raises(RuntimeError, match="SCAN_NMS_MAX"):
         _lib.call("scan_nms", None, None, None, 9000, 0.5, 1, None, ctypes.c_void_p(8), None, None)
     with pytest.raises(RuntimeError, match="K in"):

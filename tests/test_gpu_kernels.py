@@ -231,6 +231,10 @@ CONV_CASES = [
     ([(8, 16)], 2, 256, 5, 3, 1, False),     # bbox_pred + centerness fused
     ([(8, 16)], 1, 264, 1024, 3, 1, True),   # stacked CKA class branches
     ([(6, 10)], 2, 128, 40, 3, 1, False),    # Cout tail inside a 128-wide tile
+    ([(32, 48)], 2, 3, 64, 7, 2, True),      # ResNet stem 7x7 / stride 2 (+ folded FrozenBN + ReLU)
+    ([(12, 20)], 2, 256, 128, 1, 2, True),   # bottleneck conv1 with the stride in the 1x1 (layer2.0.conv1)
+    ([(11, 15)], 1, 256, 512, 1, 2, False),  # downsample 1x1 / stride 2, odd size
+    ([(8, 12)], 2, 128, 512, 1, 1, False),   # bottleneck conv3
 ]
 
 
@@ -438,3 +442,28 @@ def test_deferred_relu_backward_chain(device, monkeypatch, mode):
     for i in range(3):
         np.testing.assert_allclose(wd[i].grad.cpu().numpy(), wr[i].grad.numpy(), **tol)
         np.testing.assert_allclose(bd[i].grad.cpu().numpy(), br[i].grad.numpy(), **tol)
+
+
+def test_resnet_stem_pool_and_residual_join(device):
+    """F.max_pool2d(x, 3, 2, 1) (resnet.py:335) and out += identity; relu_ (resnet.py:312-313)."""
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(21)
+    for (h, w) in ((12, 20), (13, 17)):
+        x = torch.randn(2, 64, h, w, generator=g)
+        rows, shape = _rows(x, device)
+        y, oshape = ops.maxpool3x3s2(rows, shape)
+        ref = F.max_pool2d(x, 3, 2, 1)
+        assert oshape.sizes == [tuple(ref.shape[-2:])]
+        assert torch.equal(ops.rows_to_nchw(y, oshape).contiguous().cpu(), ref)
+    with pytest.raises(RuntimeError, match="frozen"):
+        ops.maxpool3x3s2(rows.clone().requires_grad_(True), shape)
+    a, b = torch.randn(300, 64, generator=g), torch.randn(300, 64, generator=g)
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.relu(ar + br)
+    gy = torch.randn(300, 64, generator=g)
+    yr.backward(gy)
+    ad, bd = a.to(device).requires_grad_(True), b.to(device).requires_grad_(True)
+    yd = ops.add_relu(ad, bd)
+    assert torch.equal(yd.detach().cpu(), yr.detach())
+    yd.backward(gy.to(device))
+    assert torch.equal(ad.grad.cpu(), ar.grad) and torch.equal(bd.grad.cpu(), br.grad)

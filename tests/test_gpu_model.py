@@ -308,3 +308,42 @@ def test_step_padded_batches_match_reference(device, gold_dir, name):
         ref = gold["grad_digest"][mk][name_]
         mine = _digest(dict(model[mk].named_parameters())[name_].grad)
         assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mk, name_, mine[1], ref[1])
+
+
+def test_step_resnet50_matches_reference(device, gold_dir):
+    """BASELINE.json configs[3] body: K2C yaml with MODEL.BACKBONE.CONV_BODY R-50-FPN-RETINANET (stem 7x7/2 +
+    FrozenBN + 3x3/2 max-pool, 16 bottleneck blocks with the stride in the 1x1, stem + layer1 frozen, FPN on C3..C5)."""
+    from scan_amd import engine, ops, synth
+    gold = json.load(open(os.path.join(gold_dir, "step_k2c_r50_128x256.json")))
+    assert gold["conv_body"] == "R-50-FPN-RETINANET" and gold["num_classes"] == 2
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    cfg = engine.CONFIGS["k2c_r50"]
+    for mode in ("fp32", "bf16x3"):
+        ops.CONV_MODE = mode
+        try:
+            model = engine.build_model(cfg["num_classes"], cfg["test_mode"], device=device, attn_dropout=0.0,
+                                       transfer_cfg=cfg["transfer_cfg"], conv_body=cfg["conv_body"])
+            engine.load_procedural_weights(model, 2, cfg["conv_body"])
+            trainer = engine.Trainer(model)
+            for g in trainer.groups.values():
+                g.lr = 0.0
+            losses = trainer.step(synth.synth_images(N, H, W, gold["seeds"]["src"]).to(device),
+                                  synth.synth_targets(N, H, W, 1, 12, gold["seeds"]["boxes"]),
+                                  synth.synth_images(N, H, W, gold["seeds"]["tgt"]).to(device))
+            torch.cuda.synchronize()
+        finally:
+            ops.CONV_MODE = "bf16x3"
+        for k, ref in gold["losses"].items():
+            v = float(losses[k])
+            if ref == 0.0:
+                assert v == 0.0
+            else:
+                assert abs(v - ref) <= LOSS_RTOL * abs(ref), (mode, k, v, ref)
+        named = dict(model["backbone"].named_parameters())
+        assert not named["body.stem.conv1.weight"].requires_grad and not named["body.layer1.2.conv3.weight"].requires_grad
+        assert set(k for k, p in named.items() if p.requires_grad) == set(gold["grad_digest"]["backbone"])
+        for name_ in ("body.layer2.0.conv1.weight", "body.layer2.0.downsample.0.weight", "body.layer3.5.conv2.weight",
+                      "body.layer4.2.conv3.weight", "fpn.fpn_inner4.weight", "fpn.fpn_layer2.bias"):
+            ref = gold["grad_digest"]["backbone"][name_]
+            mine = _digest(named[name_].grad)
+            assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mode, name_, mine[1], ref[1])

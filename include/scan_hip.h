@@ -156,6 +156,13 @@ int scan_weight_split(const float* w, int32_t O, int32_t T, int32_t Cs, int32_t 
 int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
                         int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns,
                         int32_t relu, void* stream);
+/* first-layer convolutions (3 input channels stored as 4; forward only, both live in frozen stages): the ResNet stem
+ * 7x7 / stride 2 / pad 3 (backbone/resnet.py:316-336) and VGG conv1_1 3x3 / stride 1 / pad 1
+ * (backbone/mmdetection/vgg.py:8-33).  x [N,H,W,4] NHWC rows, w [Cout][k*k][4] fp32, Cout <= 64,
+ * y [N,Ho,Wo,Cout_s]; bf16x3 product, optional bias and ReLU. */
+int scan_conv_smallcin_bf16x3(const float* x, int32_t N, int32_t H, int32_t W, const float* w, const float* bias,
+                              float* y, int32_t Cout, int32_t Cout_s, int32_t ksize, int32_t stride, int32_t relu,
+                              void* stream);
 /* weight gradient of the same conv, bf16x3 on the matrix cores, deterministic split-K through ws
  * (scan_conv3x3_wgrad_bf16x3_ws_floats floats).  dw [Cout][9][Cs]; db [Cout] or NULL = bias gradient (column
  * sums of dy, fused); accumulate != 0: dw += result, db += result. */

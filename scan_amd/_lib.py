@@ -64,6 +64,8 @@ SIGNATURES = {
     "scan_groupnorm_relu_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "scan_maxpool2x2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_maxpool2x2_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    "scan_conv_smallcin_bf16x3": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                                 c_i32, c_vp]),
     "scan_maxpool3x3s2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_add_relu": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "scan_sgd_momentum": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_i32, c_vp]),

@@ -230,7 +230,17 @@ class _Conv2d(torch.autograd.Function):
         fast = CONV_MODE == "bf16x3" and ksize == 3 and stride == 1
         flops = 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1]
         ckey = weight.data_ptr() if getattr(weight, "_scan_flat", False) else None
-        if fast:
+        # first layer of a frozen stage (3 input channels): dedicated K = taps x 4 kernel, forward only
+        first = CONV_MODE == "bf16x3" and cs == 4 and cout <= 64 and (ksize, stride) in ((3, 1), (7, 2)) \
+            and shape.n_levels == 1 and not any(ctx.needs_input_grad[:3])
+        if first:
+            (h, w_), n = shape.sizes[0], shape.n_images
+            y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
+            ev = kernel_timer.begin("conv_smallcin_bf16x3", flops)
+            call("scan_conv_smallcin_bf16x3", _ptr(x), n, h, w_, _ptr(wp), _ptr(bias), _ptr(y), cout, cout_s, ksize,
+                 stride, int(bool(relu)), _stream())
+            kernel_timer.end(ev)
+        elif fast:
             y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s, "conv3x3_bf16x3_fwd", flops,
                                 cache_key=ckey)
         else:

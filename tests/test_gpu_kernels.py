@@ -467,3 +467,37 @@ def test_resnet_stem_pool_and_residual_join(device):
     assert torch.equal(yd.detach().cpu(), yr.detach())
     yd.backward(gy.to(device))
     assert torch.equal(ad.grad.cpu(), ar.grad) and torch.equal(bd.grad.cpu(), br.grad)
+
+
+@pytest.mark.parametrize("k,stride,hw,n", [(3, 1, (24, 40), 2), (3, 1, (17, 70), 1), (7, 2, (64, 96), 2), (7, 2, (37, 75), 1)])
+def test_first_layer_conv_forward(device, k, stride, hw, n):
+    """scan_conv_smallcin_bf16x3 (frozen first layers: VGG conv1_1 3x3/1, ResNet stem 7x7/2) against fp32 torch and
+    against the generic fp32-MFMA kernel."""
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(31 + k)
+    x = torch.randn(n, 3, *hw, generator=g) * 50.0  # image-scale inputs
+    w = torch.randn(64, 3, k, k, generator=g) / (3 * k * k) ** 0.5
+    b = torch.randn(64, generator=g)
+    ref = F.relu(F.conv2d(x, w, b, stride=stride, padding=k // 2))
+    rows, shape = _rows(x, device, 4)
+    wd = w.to(device).contiguous(memory_format=torch.channels_last)
+    ops.kernel_timer.enabled = True
+    ops.kernel_timer.reset()
+    try:
+        y = ops.conv2d(rows, wd, b.to(device), shape, k, stride, relu=True)
+        assert "conv_smallcin_bf16x3" in ops.kernel_timer.records  # the dedicated kernel ran
+    finally:
+        ops.kernel_timer.enabled = False
+        ops.kernel_timer.reset()
+    oshape = shape.conv_out(k, stride)
+    got = ops.rows_to_nchw(y, oshape, 0, 64).cpu()
+    assert got.shape == ref.shape
+    scale = ref.abs().max().item()
+    assert (got - ref).abs().max().item() <= 2e-5 * scale
+    keep = ops.CONV_MODE
+    ops.CONV_MODE = "fp32"
+    try:
+        y32 = ops.conv2d(rows, wd, b.to(device), shape, k, stride, relu=True)
+    finally:
+        ops.CONV_MODE = keep
+    assert (y - y32).abs().max().item() <= 2e-5 * scale

@@ -52,6 +52,12 @@ SYMBOL = {"conv3x3_bf16x3_fwd_bn128": "conv3x3_bf16x3_kernel<128,16,512>",
           "conv3x3_bf16x3_fwd_bn64": "conv3x3_bf16x3_kernel<64,8,256>",
           "conv3x3_bf16x3_dgrad_bn64": "conv3x3_bf16x3_kernel<64,8,256>",
           "conv3x3_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel",
+          "conv1x1_bf16x3_fwd_bn128": "conv3x3_bf16x3_kernel<128,16,512,1>",
+          "conv1x1_bf16x3_dgrad_bn128": "conv3x3_bf16x3_kernel<128,16,512,1>",
+          "conv1x1_bf16x3_fwd_bn64": "conv3x3_bf16x3_kernel<64,8,256,1>",
+          "conv1x1_bf16x3_dgrad_bn64": "conv3x3_bf16x3_kernel<64,8,256,1>",
+          "conv1x1_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel<1,S>",
+          "conv_smallcin_bf16x3": "conv_smallcin_kernel",
           "conv_igemm_fwd": "conv_igemm_kernel<0,4>", "conv_igemm_dgrad": "conv_igemm_kernel<1,4>",
           "conv_wgrad": "conv_wgrad_kernel"}
 

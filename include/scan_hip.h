@@ -156,6 +156,20 @@ int scan_weight_split(const float* w, int32_t O, int32_t T, int32_t Cs, int32_t 
 int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
                         int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns,
                         int32_t relu, void* stream);
+/* 1x1 convolutions (FPN laterals backbone/fpn.py:52-66; ResNet bottleneck conv1 / conv3 / downsample,
+ * backbone/resnet.py:228-314, incl. the stride-2 ones: STRIDE_IN_1X1) on the same bf16x3 kernel (one tap, no halo).
+ * wh/wl: scan_weight_split planes with T = 1 (mode 0 forward, mode 1 data gradient).  map 0: stride 1 (xd == yd);
+ * map 1: stride-2 forward (yd = ceil(xd / 2)); map 2: data gradient of a stride-2 1x1 conv (x = dY on the coarse
+ * pyramid xd, y = dX on the fine pyramid yd, zero where a coordinate is odd).  mask as in scan_conv3x3_bf16x3. */
+int scan_conv1x1_bf16x3(const float* x, const scan_pyramid_t* xd, int32_t Cs, const void* wh, const void* wl,
+                        int32_t Csw, const float* bias, const float* mask, float* y, const scan_pyramid_t* yd,
+                        int32_t Nout, int32_t Ns, int32_t relu, int32_t map, void* stream);
+/* weight gradient of a 1x1 conv (stride 1 or 2): dw [Cout][1][Cs] (+)= dY^T X over all pixels of the dY pyramid yd; x on
+ * xd (yd = ceil(xd / stride)); db / accumulate / ws as for scan_conv3x3_wgrad_bf16x3. */
+int64_t scan_conv1x1_wgrad_bf16x3_ws_floats(const scan_pyramid_t* yd, int32_t Cs, int32_t Cout);
+int scan_conv1x1_wgrad_bf16x3(const float* x, const scan_pyramid_t* xd, int32_t Cs, const float* dy,
+                              const scan_pyramid_t* yd, int32_t Cout, int32_t Cout_s, int32_t stride, float* dw,
+                              float* db, int32_t accumulate, float* ws, void* stream);
 /* first-layer convolutions (3 input channels stored as 4; forward only, both live in frozen stages): the ResNet stem
  * 7x7 / stride 2 / pad 3 (backbone/resnet.py:316-336) and VGG conv1_1 3x3 / stride 1 / pad 1
  * (backbone/mmdetection/vgg.py:8-33).  x [N,H,W,4] NHWC rows, w [Cout][k*k][4] fp32, Cout <= 64,

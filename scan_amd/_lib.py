@@ -53,6 +53,7 @@ SIGNATURES = {
     "scan_weight_split": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "scan_conv3x3_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "scan_conv3x3_wgrad_bf16x3_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
+    "scan_conv1x1_wgrad_bf16x3_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
     "scan_conv3x3_wgrad_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "scan_weight_transpose": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "scan_colsum_ws_floats": (c_i64, [c_i64, c_i32]),
@@ -64,6 +65,10 @@ SIGNATURES = {
     "scan_groupnorm_relu_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "scan_maxpool2x2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_maxpool2x2_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
+    "scan_conv1x1_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, _PD, c_i32, c_i32, c_i32,
+                                           c_i32, c_vp]),
+    "scan_conv1x1_wgrad_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, _PD, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp,
+                                                 c_vp]),
     "scan_conv_smallcin_bf16x3": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                                  c_i32, c_vp]),
     "scan_maxpool3x3s2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

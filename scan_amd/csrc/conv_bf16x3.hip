@@ -57,14 +57,20 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
   lo[3] = (__bf16)(v.w - (float)hi[3]);
 }
 
-// BN: output channels per workgroup; TH: tile height in pixels (tile = TH x 16); NT: threads (TH * 32)
-template <int BN, int TH, int NT>
+// BN: output channels per workgroup; TH: tile height in pixels (tile = TH x 16); NT: threads (TH * 32);
+// KS: 3 (3x3, pad 1, stride 1) or 1 (1x1: no halo, one tap).  The 1x1 instance also serves the stride-2 1x1 convs of
+// the ResNet bottlenecks through MAP: 0 source pixel = output pixel (same pyramid), 1 source = 2 * output (forward of
+// a stride-2 conv, source pyramid sd is the finer one), 2 source = output / 2 where both coordinates are even, zero
+// elsewhere (its data gradient: sd is the coarser dY pyramid).
+template <int BN, int TH, int NT, int KS = 3>
 __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
     const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
-    float* __restrict__ dst, int Nout, int Ns, int relu, TileTab tt, int n_tiles) {
-  constexpr int PH = TH + 2;
-  constexpr int NPATCH = PH * PW;                 // halo pixels: 180 (TH 8) or 324 (TH 16)
+    float* __restrict__ dst, int Nout, int Ns, int relu, TileTab tt, int n_tiles, scan_pyramid_t sd, int map) {
+  constexpr int HALO = KS / 2, NTAPS = KS * KS;
+  constexpr int PH = TH + 2 * HALO;
+  constexpr int PWK = TW + 2 * HALO;
+  constexpr int NPATCH = PH * PWK;                // halo pixels: 180 (TH 8) or 324 (TH 16); 256 for the 1x1
   constexpr int WAVES = NT / 64;
   constexpr int WN_WAVES = BN / 64;               // 2 (BN=128) or 1 (BN=64)
   constexpr int WM_WAVES = WAVES / WN_WAVES;
@@ -104,11 +110,25 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
     for (int i = 0; i < ASLOTS; ++i) {
       const int slot = tid + NT * i;
       const int q = slot >> 3, c = c0 + 4 * (slot & 7);
-      const int py = q / PW, px = q - py * PW;
-      const int y = ty0 - 1 + py, x = tx0 - 1 + px;
-      const bool ok = (slot < NPATCH * 8) && y >= 0 && y < H && x >= 0 && x < W && c < Cs;
-      ra[i] = ok ? *reinterpret_cast<const float4*>(src + (rowbase + (int64_t)y * W + x) * Cs + c)
-                 : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int py = q / PWK, px = q - py * PWK;
+      const int y = ty0 - HALO + py, x = tx0 - HALO + px;
+      bool ok = (slot < NPATCH * 8) && y >= 0 && y < H && x >= 0 && x < W && c < Cs;
+      int64_t row = rowbase + (int64_t)y * W + x;
+      if (KS == 1 && map != 0) {
+        const int Hs = sd.h[lvl], Ws = sd.w[lvl];
+        int sy, sx;
+        if (map == 1) {
+          sy = 2 * y;
+          sx = 2 * x;
+        } else {
+          ok = ok && ((y | x) & 1) == 0;
+          sy = y >> 1;
+          sx = x >> 1;
+        }
+        ok = ok && sy < Hs && sx < Ws;
+        row = sd.row_off[lvl] + ((int64_t)img * Hs + sy) * Ws + sx;
+      }
+      ra[i] = ok ? *reinterpret_cast<const float4*>(src + row * Cs + c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store_a = [&]() {
@@ -117,7 +137,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
       const int slot = tid + NT * i;
       if (slot < NPATCH * 8) {
         const int q = slot >> 3, c4 = slot & 7;
-        const int py = q / PW, px = q - py * PW;
+        const int py = q / PWK, px = q - py * PWK;
         bf16x4 hi, lo;
         split4(ra[i], hi, lo);
         *reinterpret_cast<bf16x4*>(Ah + py * PPITCH + px * LROW + 4 * c4) = hi;
@@ -136,7 +156,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
       const int row = rem >> 2, seg = rem & 3;
       const int o = n0 + row, c = cc * CK + 8 * seg;
       const __bf16* base = plane ? wl : wh;
-      rb[i] = (o < Nout && c < Csw) ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * 9 + tap) * Csw + c)
+      rb[i] = (o < Nout && c < Csw) ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * NTAPS + tap) * Csw + c)
                                     : make_uint4(0u, 0u, 0u, 0u);
     }
   };
@@ -177,15 +197,15 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
     store_a();
     if (cc + 1 < nchunks) load_a(cc + 1);
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int buf = tap & 1;
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      const int buf = (cc * NTAPS + tap) & 1;
       store_b(buf);
-      if (tap < 8)
+      if (tap < NTAPS - 1)
         load_b(cc, tap + 1);
       else if (cc + 1 < nchunks)
         load_b(cc + 1, 0);
       __syncthreads();
-      const int ky = tap / 3, kx = tap - 3 * ky;
+      const int ky = tap / KS, kx = tap - KS * ky;
       const int shift = ky * PPITCH + kx * LROW;
       const __bf16* bh = Bs + (buf * 2 + 0) * BN * LROW + b_off;
       const __bf16* bl = Bs + (buf * 2 + 1) * BN * LROW + b_off;
@@ -317,15 +337,65 @@ extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int3
       done = true;
     }
     hipLaunchKernelGGL((conv3x3_bf16x3_kernel<128, 16, 512>), dim3(tiles * n_tiles), dim3(512), sh, st, x, *d, Cs, h, l,
-                       Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles);
+                       Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *d, 0);
   } else {
     make_tiles(d, &tt, 8);
     const int tiles = tt.tile_off[d->n_levels];
     const size_t sh = (size_t)(2 * 10 * PPITCH + 4 * 64 * LROW) * sizeof(__bf16);
     hipLaunchKernelGGL((conv3x3_bf16x3_kernel<64, 8, 256>), dim3(tiles), dim3(256), sh, st, x, *d, Cs, h, l, Csw, bias,
-                       mask, y, Nout, Ns, relu, tt, 1);
+                       mask, y, Nout, Ns, relu, tt, 1, *d, 0);
   }
   SCAN_LAUNCH_CHECK("conv3x3_bf16x3");
+  return 0;
+}
+
+// y[Mo][Ns] = conv1x1(x[Mi][Cs]) with pre-split weights wh/wl [Nout][1][Csw].  map 0: stride 1 (xd == yd);
+// map 1: stride 2 forward (yd = xd.conv_out(1, 2)); map 2: data gradient of a stride-2 1x1 conv (x = dY on the coarse
+// pyramid xd, y = dX on the fine pyramid yd, zero where a coordinate is odd).
+extern "C" int scan_conv1x1_bf16x3(const float* x, const scan_pyramid_t* xd, int32_t Cs, const void* wh, const void* wl,
+                                   int32_t Csw, const float* bias, const float* mask, float* y,
+                                   const scan_pyramid_t* yd, int32_t Nout, int32_t Ns, int32_t relu, int32_t map,
+                                   void* stream) {
+  SCAN_CHECK_ARG(xd && yd && yd->n_levels >= 1 && yd->n_levels <= SCAN_MAX_LEVELS && yd->n_images >= 1 &&
+                     xd->n_levels == yd->n_levels && xd->n_images == yd->n_images,
+                 "conv1x1_bf16x3: bad pyramids");
+  SCAN_CHECK_ARG(map >= 0 && map <= 2, "conv1x1_bf16x3: map=%d must be 0, 1 or 2", map);
+  SCAN_CHECK_ARG(Cs > 0 && Cs % 4 == 0, "conv1x1_bf16x3: Cs=%d must be a positive multiple of 4", Cs);
+  SCAN_CHECK_ARG(Csw % 8 == 0 && Csw >= Cs, "conv1x1_bf16x3: Csw=%d must be a multiple of 8 and >= Cs", Csw);
+  SCAN_CHECK_ARG(Nout > 0 && Ns >= Nout, "conv1x1_bf16x3: Nout=%d Ns=%d", Nout, Ns);
+  SCAN_CHECK_ARG(x && wh && wl && y, "conv1x1_bf16x3: null pointer");
+  for (int l = 0; l < yd->n_levels; ++l) {
+    const int eh = map == 0 ? xd->h[l] : map == 1 ? (xd->h[l] - 1) / 2 + 1 : yd->h[l];
+    const int ew = map == 0 ? xd->w[l] : map == 1 ? (xd->w[l] - 1) / 2 + 1 : yd->w[l];
+    SCAN_CHECK_ARG(eh == yd->h[l] && ew == yd->w[l] &&
+                       (map != 2 || ((yd->h[l] - 1) / 2 + 1 == xd->h[l] && (yd->w[l] - 1) / 2 + 1 == xd->w[l])),
+                   "conv1x1_bf16x3: level %d sizes do not match map %d", l, map);
+  }
+  TileTab tt;
+  hipStream_t st = as_stream(stream);
+  const __bf16* h = reinterpret_cast<const __bf16*>(wh);
+  const __bf16* l = reinterpret_cast<const __bf16*>(wl);
+  if (Nout > 64) {
+    make_tiles(yd, &tt, 16);
+    const int tiles = tt.tile_off[yd->n_levels];
+    const int n_tiles = (Nout + 127) / 128;
+    const size_t sh = (size_t)(2 * 16 * PPITCH + 4 * 128 * LROW) * sizeof(__bf16);
+    static bool done = false;
+    if (!done) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16x3_kernel<128, 16, 512, 1>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      done = true;
+    }
+    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<128, 16, 512, 1>), dim3(tiles * n_tiles), dim3(512), sh, st, x, *yd, Cs, h,
+                       l, Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *xd, map);
+  } else {
+    make_tiles(yd, &tt, 8);
+    const int tiles = tt.tile_off[yd->n_levels];
+    const size_t sh = (size_t)(2 * 8 * PPITCH + 4 * 64 * LROW) * sizeof(__bf16);
+    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<64, 8, 256, 1>), dim3(tiles), dim3(256), sh, st, x, *yd, Cs, h, l, Csw,
+                       bias, mask, y, Nout, Ns, relu, tt, 1, *xd, map);
+  }
+  SCAN_LAUNCH_CHECK("conv1x1_bf16x3");
   return 0;
 }
 
@@ -354,8 +424,8 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 #define WK 64     // pixels per K chunk (one image-row segment): ~2 us of MFMA work per chunk, enough to cover the
                   // HBM latency of the next chunk's loads, which are prefetched into registers meanwhile
 #define WNA (WK / 16)             // dY float4 per thread per chunk
-#define WNB ((WK + 2 + 15) / 16)  // X float4 per thread per chunk (1-pixel halo each side)
-#define WBUF ((WK + WK + 2) * 2 * WROW)  // bf16 elements of the LDS stage: dY hi/lo [WK], X hi/lo [WK + 2]
+#define WNB(KX) ((WK + (KX) - 1 + 15) / 16)  // X float4 per thread per chunk (KX/2-pixel halo each side)
+#define WBUF(KX) ((WK + WK + (KX) - 1) * 2 * WROW)  // bf16 elements of the LDS stage: dY hi/lo [WK], X hi/lo [WK+KX-1]
 
 struct ChunkTab {
   long long chunk_off[SCAN_MAX_LEVELS + 1];
@@ -376,9 +446,9 @@ __device__ __forceinline__ bf16x8 tr_read8(const __bf16* p0) {
 
 // MFMA work of one staged chunk for one wave: TMN = number of live 32-row o tiles (2, or 1 when the second lies
 // beyond Nout)
-template <int TMN>
+template <int TMN, int KX>
 __device__ __forceinline__ void wgrad_mma(const __bf16* Ah, const __bf16* Al, const __bf16* Bh, const __bf16* Bl,
-                                          int tr_off, int a_col, int b_col, f32x16 (&acc)[3][2]) {
+                                          int tr_off, int a_col, int b_col, f32x16 (&acc)[KX][2]) {
 #pragma unroll
   for (int s = 0; s < WK / 16; ++s) {
     bf16x8 ah[TMN], al[TMN];
@@ -389,7 +459,7 @@ __device__ __forceinline__ void wgrad_mma(const __bf16* Ah, const __bf16* Al, co
       al[t] = tr_read8(Al + oa);
     }
 #pragma unroll
-    for (int kx = 0; kx < 3; ++kx) {
+    for (int kx = 0; kx < KX; ++kx) {
       const int ob = tr_off + (16 * s + kx) * WROW + b_col;
       const bf16x8 bh = tr_read8(Bh + ob);
       const bf16x8 bl = tr_read8(Bl + ob);
@@ -403,10 +473,15 @@ __device__ __forceinline__ void wgrad_mma(const __bf16* Ah, const __bf16* Al, co
   }
 }
 
+// KX = 3: the 3x3 / stride-1 conv (three kx taps of one ky per workgroup).  KX = 1: 1x1 convs (one tap, no halo), whose
+// X operand may be gathered with stride S from the finer pyramid xd (ResNet's stride-2 1x1 convs); d is always the
+// pyramid of dY, over which the K chunks run.
+template <int KX, int S>
 __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
     float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
-    int chunks_per_split, int splits) {
+    int chunks_per_split, int splits, scan_pyramid_t xd) {
+  constexpr int HALO = KX / 2, T = KX * KX;
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
 
@@ -419,18 +494,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
   const int split = (qq / n_tiles) * 8 + xcd;
   const int c_tile = tile % c_tiles;
   tile /= c_tiles;
-  const int ky = tile % 3;
-  const int o_tile = tile / 3;
+  const int ky = tile % KX;
+  const int o_tile = tile / KX;
   const int o0 = o_tile * 128, c0 = c_tile * 128;
   const long long total_chunks = ct.chunk_off[d.n_levels];
   const long long ch_begin = (long long)split * chunks_per_split;
   long long ch_end = ch_begin + chunks_per_split;
   if (ch_end > total_chunks) ch_end = total_chunks;
-  const bool do_bias = (bias_slab != nullptr) && ky == 1 && c_tile == 0;
+  const bool do_bias = (bias_slab != nullptr) && ky == HALO && c_tile == 0;
 
   // staging roles: float4 column q4, pixel rows rr + 16 i
   const int q4 = tid & 31, rr = tid >> 5;
-  float4 ra[WNA], rb[WNB];
+  float4 ra[WNA], rb[WNB(KX)];
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_chunk = [&](long long ch) {
     int lvl = 0;
@@ -461,22 +536,26 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
         }
       }
     }
-    const int yy = y + ky - 1;
+    const int yy = y + ky - HALO;
     const bool yok = yy >= 0 && yy < H && c < Cs;
-    const long long xrow = rowbase + (long long)(ky - 1) * W;
+    // X row: same pyramid for the 3x3; for the 1x1 the (possibly finer) pyramid xd sampled with stride S
+    const int Wx = (KX == 1) ? xd.w[lvl] : W;
+    const long long xrow = (KX == 1) ? xd.row_off[lvl] + ((row / H) * xd.h[lvl] + (long long)S * y) * Wx
+                                     : rowbase + (long long)(ky - 1) * W;
 #pragma unroll
-    for (int i = 0; i < WNB; ++i) {
+    for (int i = 0; i < WNB(KX); ++i) {
       const int j = rr + 16 * i;
-      const int xx = x0 - 1 + j;
+      const int xx = x0 - HALO + j;
       rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (j < WK + 2 && yok && xx >= 0 && xx < W) rb[i] = *reinterpret_cast<const float4*>(x + (xrow + xx) * Cs + c);
+      if (j < WK + KX - 1 && yok && xx >= 0 && xx < W)
+        rb[i] = *reinterpret_cast<const float4*>(x + (xrow + (long long)S * xx) * Cs + c);
     }
   };
   auto store_chunk = [&]() {
     __bf16* Ah = sm;
     __bf16* Al = Ah + WK * WROW;
     __bf16* Bh = Al + WK * WROW;
-    __bf16* Bl = Bh + (WK + 2) * WROW;
+    __bf16* Bl = Bh + (WK + KX - 1) * WROW;
     bf16x4 hi, lo;
 #pragma unroll
     for (int i = 0; i < WNA; ++i) {
@@ -492,9 +571,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
       }
     }
 #pragma unroll
-    for (int i = 0; i < WNB; ++i) {
+    for (int i = 0; i < WNB(KX); ++i) {
       const int j = rr + 16 * i;
-      if (j < WK + 2) {
+      if (j < WK + KX - 1) {
         const int off = j * WROW + 4 * q4;
         split4(rb[i], hi, lo);
         *reinterpret_cast<bf16x4*>(Bh + off) = hi;
@@ -513,9 +592,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
   const bool c_act = c0 + b_col < Cs;
   const bool o_act0 = o0 + a_col < Nout, o_act1 = o0 + a_col + 32 < Nout;
 
-  f32x16 acc[3][2];
+  f32x16 acc[KX][2];
 #pragma unroll
-  for (int a = 0; a < 3; ++a)
+  for (int a = 0; a < KX; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -527,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
   const __bf16* Ah = sm;
   const __bf16* Al = Ah + WK * WROW;
   const __bf16* Bh = Al + WK * WROW;
-  const __bf16* Bl = Bh + (WK + 2) * WROW;
+  const __bf16* Bl = Bh + (WK + KX - 1) * WROW;
   for (long long ch = ch_begin; ch < ch_end; ++ch) {
     store_chunk();
     if (ch + 1 < ch_end) load_chunk(ch + 1);
@@ -535,22 +614,22 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     // wave-uniform skips: a wave whose 32 c columns lie beyond Cs (third c tile of Cin = 264 / 265) or whose o rows
     // lie beyond Nout (Cout = 8 / 5 / 1 heads) has nothing to contribute; it still stages and synchronises
     if (c_act && o_act1)
-      wgrad_mma<2>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
+      wgrad_mma<2, KX>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
     else if (c_act && o_act0)
-      wgrad_mma<1>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
+      wgrad_mma<1, KX>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
     __syncthreads();  // every wave is done with this chunk's LDS image
   }
 
-  float* out = slab + (long long)split * Nout * 9 * Cs;
+  float* out = slab + (long long)split * Nout * T * Cs;
   const int c = c0 + b_col + lr;
 #pragma unroll
-  for (int kx = 0; kx < 3; ++kx)
+  for (int kx = 0; kx < KX; ++kx)
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + a_col + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (o < Nout && c < Cs) out[((long long)o * 9 + ky * 3 + kx) * Cs + c] = acc[kx][tm][r];
+        if (o < Nout && c < Cs) out[((long long)o * T + ky * KX + kx) * Cs + c] = acc[kx][tm][r];
       }
 
   if (do_bias) {  // column sums of this split's dY rows: reduce the 16 pixel-row groups through LDS
@@ -614,7 +693,7 @@ extern "C" void scan_slab_reduce_launch(const float* slab, int splits, int64_t n
                                         hipStream_t st);
 
 static void wgrad3_plan(const scan_pyramid_t* d, int Cs, int Cout, ChunkTab* ct, int* n_tiles, int* c_tiles,
-                        int* splits, int* cps) {
+                        int* splits, int* cps, int KX = 3) {
   ct->chunk_off[0] = 0;
   for (int l = 0; l < SCAN_MAX_LEVELS; ++l) {
     if (l < d->n_levels) {
@@ -627,7 +706,7 @@ static void wgrad3_plan(const scan_pyramid_t* d, int Cs, int Cout, ChunkTab* ct,
   }
   const long long chunks = ct->chunk_off[d->n_levels];
   *c_tiles = (Cs + 127) / 128;
-  *n_tiles = ((Cout + 127) / 128) * 3 * *c_tiles;
+  *n_tiles = ((Cout + 127) / 128) * KX * *c_tiles;
   long long s = 768 / *n_tiles;  // ~3 workgroups per CU in total: split-K slabs cost HBM traffic
   if (s < 1) s = 1;
   const long long smax = (chunks + 7) / 8;
@@ -657,19 +736,68 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
   int nt, ctl, sp, cps;
   wgrad3_plan(d, Cs, Cout, &ct, &nt, &ctl, &sp, &cps);
   hipStream_t st = as_stream(stream);
-  const size_t sh = (size_t)WBUF * sizeof(__bf16);
+  const size_t sh = (size_t)WBUF(3) * sizeof(__bf16);
   static bool done = false;
   if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16x3_kernel),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16x3_kernel<3, 1>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     done = true;
   }
   float* bias_slab = db ? ws + (int64_t)sp * Cout * 9 * Cs : nullptr;
-  hipLaunchKernelGGL(conv3x3_wgrad_bf16x3_kernel, dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout, Cout_s, ws,
-                     bias_slab, ct, nt, ctl, cps, sp);
+  hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<3, 1>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout, Cout_s,
+                     ws, bias_slab, ct, nt, ctl, cps, sp, *d);
   SCAN_LAUNCH_CHECK("conv3x3_wgrad_bf16x3");
   // one launch reduces the weight slabs and (last block) the bias slabs
   const int64_t n = (int64_t)Cout * 9 * Cs;
+  hipLaunchKernelGGL(slab_bias_reduce_kernel, dim3(grid_for(n / 4, 256) + (db ? 1 : 0)), dim3(256), 0, st, ws, sp, n, dw,
+                     bias_slab, Cout, db, accumulate);
+  SCAN_LAUNCH_CHECK("slab_bias_reduce");
+  return 0;
+}
+
+// ---- 1x1 weight gradient (stride 1 or 2): dw[Cout][1][Cs] = sum_pixels dY^T X, same kernel with one tap.
+extern "C" int64_t scan_conv1x1_wgrad_bf16x3_ws_floats(const scan_pyramid_t* yd, int32_t Cs, int32_t Cout) {
+  ChunkTab ct;
+  int nt, ctl, sp, cps;
+  wgrad3_plan(yd, Cs, Cout, &ct, &nt, &ctl, &sp, &cps, 1);
+  return (int64_t)sp * Cout * Cs + (int64_t)sp * Cout;
+}
+
+extern "C" int scan_conv1x1_wgrad_bf16x3(const float* x, const scan_pyramid_t* xd, int32_t Cs, const float* dy,
+                                         const scan_pyramid_t* yd, int32_t Cout, int32_t Cout_s, int32_t stride,
+                                         float* dw, float* db, int32_t accumulate, float* ws, void* stream) {
+  SCAN_CHECK_ARG(xd && yd && yd->n_levels >= 1 && yd->n_levels <= SCAN_MAX_LEVELS && yd->n_images >= 1 &&
+                     xd->n_levels == yd->n_levels && xd->n_images == yd->n_images,
+                 "conv1x1_wgrad_bf16x3: bad pyramids");
+  SCAN_CHECK_ARG(stride == 1 || stride == 2, "conv1x1_wgrad_bf16x3: stride must be 1 or 2, got %d", stride);
+  for (int l = 0; l < yd->n_levels; ++l)
+    SCAN_CHECK_ARG((xd->h[l] - 1) / stride + 1 == yd->h[l] && (xd->w[l] - 1) / stride + 1 == yd->w[l],
+                   "conv1x1_wgrad_bf16x3: level %d sizes do not match stride %d", l, stride);
+  SCAN_CHECK_ARG(Cs > 0 && Cs % 4 == 0, "conv1x1_wgrad_bf16x3: Cs=%d must be a positive multiple of 4", Cs);
+  SCAN_CHECK_ARG(Cout > 0 && Cout_s >= Cout, "conv1x1_wgrad_bf16x3: Cout=%d Cout_s=%d", Cout, Cout_s);
+  SCAN_CHECK_ARG(x && dy && dw && ws, "conv1x1_wgrad_bf16x3: null pointer");
+  ChunkTab ct;
+  int nt, ctl, sp, cps;
+  wgrad3_plan(yd, Cs, Cout, &ct, &nt, &ctl, &sp, &cps, 1);
+  hipStream_t st = as_stream(stream);
+  const size_t sh = (size_t)WBUF(1) * sizeof(__bf16);
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16x3_kernel<1, 1>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16x3_kernel<1, 2>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    done = true;
+  }
+  float* bias_slab = db ? ws + (int64_t)sp * Cout * Cs : nullptr;
+  if (stride == 1)
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<1, 1>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
+                       Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *xd);
+  else
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<1, 2>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
+                       Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *xd);
+  SCAN_LAUNCH_CHECK("conv1x1_wgrad_bf16x3");
+  const int64_t n = (int64_t)Cout * Cs;
   hipLaunchKernelGGL(slab_bias_reduce_kernel, dim3(grid_for(n / 4, 256) + (db ? 1 : 0)), dim3(256), 0, st, ws, sp, n, dw,
                      bias_slab, Cout, db, accumulate);
   SCAN_LAUNCH_CHECK("slab_bias_reduce");

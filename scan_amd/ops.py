@@ -175,8 +175,9 @@ _split_cache = {}
 
 
 def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None,
-                    mask=None):
-    """wp: packed fp32 weights [O][9][Cs_w].  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
+                    mask=None, dst_shape=None, cmap=0):
+    """wp: packed fp32 weights [O][T][Cs_w], T = 9 (3x3 / stride 1) or 1 (1x1; dst_shape = output pyramid, cmap =
+    scan_conv1x1_bf16x3's map).  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
     st = _stream()
     O, T, cs_w = wp.shape
     if mode == 0:
@@ -203,8 +204,12 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
             _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
     y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
     ev = kernel_timer.begin(name + ("_bn128" if nout > 64 else "_bn64"), flops)  # the two template instances
-    call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask), _ptr(y),
-         nout, ns, int(bool(relu)), st)
+    if T == 1:
+        call("scan_conv1x1_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
+             _ptr(y), (dst_shape or shape).ref(), nout, ns, int(bool(relu)), cmap, st)
+    else:
+        call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
+             _ptr(y), nout, ns, int(bool(relu)), st)
     kernel_timer.end(ev)
     return y
 
@@ -227,7 +232,7 @@ class _Conv2d(torch.autograd.Function):
         cout_s = cout_s or pad4(cout)
         wp = pack_weight(weight, cs)
         oshape = shape.conv_out(ksize, stride)
-        fast = CONV_MODE == "bf16x3" and ksize == 3 and stride == 1
+        fast = CONV_MODE == "bf16x3" and ((ksize == 3 and stride == 1) or ksize == 1)
         flops = 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1]
         ckey = weight.data_ptr() if getattr(weight, "_scan_flat", False) else None
         # first layer of a frozen stage (3 input channels): dedicated K = taps x 4 kernel, forward only
@@ -241,8 +246,9 @@ class _Conv2d(torch.autograd.Function):
                  stride, int(bool(relu)), _stream())
             kernel_timer.end(ev)
         elif fast:
-            y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s, "conv3x3_bf16x3_fwd", flops,
-                                cache_key=ckey)
+            y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s,
+                                "conv3x3_bf16x3_fwd" if ksize == 3 else "conv1x1_bf16x3_fwd", flops, cache_key=ckey,
+                                dst_shape=oshape, cmap=stride - 1)
         else:
             y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
             ev = kernel_timer.begin("conv_igemm_fwd", flops)
@@ -278,9 +284,10 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         mask = x if ctx.mask_dx else None  # x is a deferred-ReLU output: dx *= (x > 0) in the dgrad epilogue
         if ctx.needs_input_grad[0] and fast:
-            dx = _conv3x3_bf16x3(dy, shape, pack_weight(weight, cs), cout, x.shape[0], cout_s, 1, None, False, cs,
-                                 "conv3x3_bf16x3_dgrad", 2.0 * oshape.rows * cout * T * cin, cache_key=ctx.ckey,
-                                 mask=mask)
+            dx = _conv3x3_bf16x3(dy, oshape, pack_weight(weight, cs), cout, x.shape[0], cout_s, 1, None, False, cs,
+                                 "conv3x3_bf16x3_dgrad" if ksize == 3 else "conv1x1_bf16x3_dgrad",
+                                 2.0 * oshape.rows * cout * T * cin, cache_key=ctx.ckey, mask=mask, dst_shape=shape,
+                                 cmap=0 if stride == 1 else 2)
         elif ctx.needs_input_grad[0]:
             wp = pack_weight(weight, cs)
             wt = x.new_empty((cs, T, cout_s))
@@ -293,7 +300,7 @@ class _Conv2d(torch.autograd.Function):
         direct_w = ctx.wgrad_buf is not None
         direct_b = direct_w and ctx.bgrad_buf is not None
         db_done = False
-        if ctx.needs_input_grad[1] and fast:
+        if ctx.needs_input_grad[1] and fast and ksize == 3:
             ws = x.new_empty((query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),))
             dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
             ev = kernel_timer.begin("conv3x3_bf16x3_wgrad", 2.0 * oshape.rows * cout * T * cin)
@@ -303,6 +310,22 @@ class _Conv2d(torch.autograd.Function):
                 db_done = True
             call("scan_conv3x3_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), cout, cout_s, _ptr(dwp),
                  _ptr(db) if want_db else None, int(direct_w), _ptr(ws), st)
+            kernel_timer.end(ev)
+            if want_db and direct_w and not direct_b:
+                raise RuntimeError("conv2d: flat weight gradient without a flat bias gradient")
+            dw = None if direct_w else unpack_weight_grad(dwp, weight)
+            if direct_b:
+                db = None
+        elif ctx.needs_input_grad[1] and fast:  # 1x1, stride 1 or 2
+            ws = x.new_empty((query("scan_conv1x1_wgrad_bf16x3_ws_floats", oshape.ref(), cs, cout),))
+            dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
+            ev = kernel_timer.begin("conv1x1_bf16x3_wgrad", 2.0 * oshape.rows * cout * T * cin)
+            want_db = has_bias and ctx.needs_input_grad[2]
+            if want_db:
+                db = ctx.bgrad_buf if direct_b else x.new_empty((cout,))
+                db_done = True
+            call("scan_conv1x1_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), oshape.ref(), cout, cout_s, stride,
+                 _ptr(dwp), _ptr(db) if want_db else None, int(direct_w), _ptr(ws), st)
             kernel_timer.end(ev)
             if want_db and direct_w and not direct_b:
                 raise RuntimeError("conv2d: flat weight gradient without a flat bias gradient")

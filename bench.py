@@ -218,7 +218,7 @@ def main():
                                              "share_of_serial_step": round(v["total_ms"] / (dtr * 1e3), 3)}
                                          for k, v in ksum.items()}}
         cpu = None
-        if not a.no_cpu_baseline and a.model == "c2f":
+        if not a.no_cpu_baseline and a.model == "c2f" and world == 1:  # rank 0 at N=1 only
             sh, sw = H, W  # one full-size pair: ~10 s on 16 host threads
             cdt, cores = cpu_baseline(sh, sw)
             scale = (sh * sw) / float(H * W)

@@ -707,7 +707,10 @@ static void wgrad3_plan(const scan_pyramid_t* d, int Cs, int Cout, ChunkTab* ct,
   const long long chunks = ct->chunk_off[d->n_levels];
   *c_tiles = (Cs + 127) / 128;
   *n_tiles = ((Cout + 127) / 128) * KX * *c_tiles;
-  long long s = 768 / *n_tiles;  // ~3 workgroups per CU in total: split-K slabs cost HBM traffic
+  // ~3 workgroups per CU in total.  Swept on the device (tower layer, us): 256 -> 499, 512 -> 428, 768 -> 355,
+  // 1024 -> 414, 1536 -> 411, 2304 -> 486: fewer splits lengthen each workgroup's serial chunk chain, more splits
+  // cost slab traffic and leave partial rounds
+  long long s = 768 / *n_tiles;
   if (s < 1) s = 1;
   const long long smax = (chunks + 7) / 8;
   if (s > smax) s = smax;

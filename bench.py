@@ -33,9 +33,9 @@ PEAK_BF16X3_TFLOPS = 2500.0 / 3.0
 def pmc_traffic(kernel_name):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
     (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction).  None if not recorded."""
-    key = {"conv3x3_wgrad_bf16x3_kernel": "conv3x3_bf16x3_wgrad",
-           "conv3x3_bf16x3_kernel<128,16,512>": "conv3x3_bf16x3_fwd_dgrad_bn128",
-           "conv3x3_bf16x3_kernel<64,8,256>": "conv3x3_bf16x3_fwd_bn64", "conv_igemm_kernel<0,4>": "conv_igemm_fwd",
+    key = {"conv3x3_wgrad_bf16x3_kernel<3,1>": "conv3x3_bf16x3_wgrad",
+           "conv3x3_bf16x3_kernel<128,16,512,3>": "conv3x3_bf16x3_fwd_dgrad_bn128",
+           "conv3x3_bf16x3_kernel<64,8,256,3>": "conv3x3_bf16x3_fwd_bn64", "conv_igemm_kernel<0,4>": "conv_igemm_fwd",
            "conv_igemm_kernel<1,4>": "conv_igemm_dgrad", "conv_wgrad_kernel": "conv_wgrad_fp32"}.get(kernel_name)
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
@@ -47,16 +47,16 @@ def pmc_traffic(kernel_name):
 
 # timer record name (scan_amd/ops.py) -> kernel symbol as rocprofv3 lists it: forward and data-gradient launches of
 # a conv are the SAME kernel (dgrad = forward on dY with flipped/transposed weights)
-SYMBOL = {"conv3x3_bf16x3_fwd_bn128": "conv3x3_bf16x3_kernel<128,16,512>",
-          "conv3x3_bf16x3_dgrad_bn128": "conv3x3_bf16x3_kernel<128,16,512>",
-          "conv3x3_bf16x3_fwd_bn64": "conv3x3_bf16x3_kernel<64,8,256>",
-          "conv3x3_bf16x3_dgrad_bn64": "conv3x3_bf16x3_kernel<64,8,256>",
-          "conv3x3_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel",
+SYMBOL = {"conv3x3_bf16x3_fwd_bn128": "conv3x3_bf16x3_kernel<128,16,512,3>",
+          "conv3x3_bf16x3_dgrad_bn128": "conv3x3_bf16x3_kernel<128,16,512,3>",
+          "conv3x3_bf16x3_fwd_bn64": "conv3x3_bf16x3_kernel<64,8,256,3>",
+          "conv3x3_bf16x3_dgrad_bn64": "conv3x3_bf16x3_kernel<64,8,256,3>",
           "conv1x1_bf16x3_fwd_bn128": "conv3x3_bf16x3_kernel<128,16,512,1>",
           "conv1x1_bf16x3_dgrad_bn128": "conv3x3_bf16x3_kernel<128,16,512,1>",
           "conv1x1_bf16x3_fwd_bn64": "conv3x3_bf16x3_kernel<64,8,256,1>",
           "conv1x1_bf16x3_dgrad_bn64": "conv3x3_bf16x3_kernel<64,8,256,1>",
           "conv1x1_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel<1,S>",
+          "conv3x3_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel<3,1>",
           "conv_smallcin_bf16x3": "conv_smallcin_kernel",
           "conv_igemm_fwd": "conv_igemm_kernel<0,4>", "conv_igemm_dgrad": "conv_igemm_kernel<1,4>",
           "conv_wgrad": "conv_wgrad_kernel"}

@@ -285,15 +285,12 @@ class FCOSPostProcessor:
             boxes = torch.cat([x[0] for x in lv], 0)
             scores = torch.cat([x[1] for x in lv], 0)
             labels = torch.cat([x[2] for x in lv], 0)
-            rb, rs, rl = [], [], []
-            for j in range(1, self.num_classes):
-                inds = (labels == j).nonzero().view(-1)
-                bj, sj = boxes[inds].view(-1, 4), scores[inds]
-                keep = _box_nms(bj, sj, self.nms_thresh).to(bj.device)
-                rb.append(bj[keep])
-                rs.append(sj[keep])
-                rl.append(torch.full((len(keep),), j, dtype=torch.int64, device=bj.device))
-            rb, rs, rl = torch.cat(rb), torch.cat(rs), torch.cat(rl)
+            # per-class NMS (reference inference.py:160-176 loops classes and calls boxlist_nms on each) as ONE
+            # class-aware launch: a box is suppressed only by a kept, higher-scored box of the SAME label, which is
+            # exactly greedy NMS run per class; output order = class-major, original index ascending within a class
+            keep = ops.nms_by_label(boxes, scores, labels, self.nms_thresh).to(boxes.device)
+            keep = keep[torch.argsort(labels[keep], stable=True)]
+            rb, rs, rl = boxes[keep], scores[keep], labels[keep]
             n = len(rs)
             if n > self.fpn_post_nms_top_n > 0:
                 th, _ = torch.kthvalue(rs.cpu(), n - self.fpn_post_nms_top_n + 1)

@@ -746,6 +746,12 @@ def nms(dets, scores, thr, rule_ge=True):
     return _nms_impl(dets, scores, None, thr, rule_ge)
 
 
+def nms_by_label(dets, scores, labels, thr):
+    """greedy NMS per label in one launch, CPU '>=' rule (= boxlist_nms applied class by class,
+    reference rpn/fcos/inference.py:160-176 + csrc/cpu/nms_cpu.cpp:60); kept original indices ascending."""
+    return _nms_impl(dets, scores, labels.float(), thr, True)
+
+
 def ml_nms(dets, scores, labels, thr):
     """label-aware NMS with the CUDA '>' rule (reference csrc/cuda/ml_nms.cu:13-24,62)."""
     return _nms_impl(dets, scores, labels, thr, False)

@@ -14,7 +14,6 @@ from torch import nn
 
 from .. import ops
 from ..layers import IOULoss, Scale, SigmoidFocalLoss
-from ..layers import nms as _box_nms
 from .backbone import conv_holder
 
 INF = 100000000  # reference rpn/fcos/loss.py:22

@@ -247,53 +247,62 @@ class FCOSPostProcessor:
 
     def __call__(self, shape, box_cls, box_regression, centerness, image_sizes):
         """box_cls [M,C] (logits for 'common', fused probabilities otherwise), box_regression [M,4],
-        centerness [M] logits.  Returns per image (boxes [k,4], scores [k], labels [k])."""
-        N = shape.n_images
-        locs = compute_locations(shape, box_cls.device)
-        C = box_cls.shape[1]
-        per_img = [[] for _ in range(N)]
+        centerness [M] logits.  Returns per image (boxes [k,4], scores [k], labels [k]).
+
+        Same selection as the reference (inference.py:49-118: candidates = score > pre_nms_thresh, at most
+        pre_nms_top_n per image and level by score x centerness, decode, clip, min-size; :140-194: per-class NMS,
+        top fpn_post_nms_top_n by kthvalue) but batched on the device: one top-k per level over all images, one
+        decode over everything selected, one class-aware NMS launch per image -- no host loop over levels x images x
+        classes and one host round trip for the candidate counts instead of one per (level, image)."""
+        N, C = shape.n_images, box_cls.shape[1]
+        dev = box_cls.device
+        locs = compute_locations(shape, dev)
+        prob = box_cls.sigmoid() if self.mode == "common" else box_cls
+        score = torch.where(prob > self.pre_nms_thresh, prob * centerness.sigmoid()[:, None], prob.new_full((), -1.0))
+        sel_score, sel_cls, sel_row, sel_loc = [], [], [], []
         for l in range(shape.n_levels):
             r0, r1 = shape.row_off[l], shape.row_off[l + 1]
-            cls = box_cls[r0:r1].reshape(N, -1, C)
-            if self.mode == "common":
-                cls = cls.sigmoid()
-            reg = box_regression[r0:r1].reshape(N, -1, 4)
-            ctr = centerness[r0:r1].reshape(N, -1).sigmoid()
-            cand = cls > self.pre_nms_thresh
-            topn = cand.reshape(N, -1).sum(1).clamp(max=self.pre_nms_top_n)
-            cls = cls * ctr[:, :, None]
-            for i in range(N):
-                sc = cls[i][cand[i]]
-                nz = cand[i].nonzero()
-                bl, kl = nz[:, 0], nz[:, 1] + 1
-                rg, lc = reg[i][bl], locs[l][bl]
-                if cand[i].sum().item() > topn[i].item():
-                    sc, ti = sc.topk(int(topn[i]), sorted=False)
-                    kl, rg, lc = kl[ti], rg[ti], lc[ti]
-                det = torch.stack([lc[:, 0] - rg[:, 0], lc[:, 1] - rg[:, 1], lc[:, 0] + rg[:, 2], lc[:, 1] + rg[:, 3]], 1)
-                h, w = image_sizes[i]
-                det[:, 0].clamp_(min=0, max=w - 1)  # BoxList.clip_to_image, TO_REMOVE = 1
-                det[:, 1].clamp_(min=0, max=h - 1)
-                det[:, 2].clamp_(min=0, max=w - 1)
-                det[:, 3].clamp_(min=0, max=h - 1)
-                ws, hs = det[:, 2] - det[:, 0] + 1, det[:, 3] - det[:, 1] + 1
-                keep = ((ws >= self.min_size) & (hs >= self.min_size)).nonzero().squeeze(1)
-                per_img[i].append((det[keep], torch.sqrt(sc)[keep], kl[keep]))
+            hw = (r1 - r0) // N
+            flat = score[r0:r1].reshape(N, hw * C)
+            k = min(self.pre_nms_top_n, hw * C)
+            val, idx = flat.topk(k, dim=1, sorted=False)
+            # candidates in flattened (location, class) order like the reference's nonzero(); non-candidates last
+            idx, perm = torch.sort(torch.where(val > 0, idx, idx.new_full((), hw * C)), dim=1)
+            val = val.gather(1, perm)
+            loc = torch.div(idx, C, rounding_mode="floor").clamp(max=hw - 1)
+            sel_score.append(val)
+            sel_cls.append(idx % C + 1)
+            sel_row.append(r0 + torch.arange(N, device=dev)[:, None] * hw + loc)
+            sel_loc.append(locs[l][loc])
+        val = torch.cat(sel_score, 1)  # [N, K]
+        lab = torch.cat(sel_cls, 1)
+        rg = box_regression[torch.cat(sel_row, 1)]  # [N, K, 4]
+        lc = torch.cat(sel_loc, 1)  # [N, K, 2]
+        det = torch.stack([lc[..., 0] - rg[..., 0], lc[..., 1] - rg[..., 1], lc[..., 0] + rg[..., 2],
+                           lc[..., 1] + rg[..., 3]], -1)
+        # BoxList.clip_to_image (TO_REMOVE = 1) against each image's true size
+        lim = torch.tensor([[w - 1, h - 1, w - 1, h - 1] for h, w in image_sizes], dtype=det.dtype, device=dev)
+        det = torch.minimum(det.clamp(min=0), lim[:, None, :])
+        ws, hs = det[..., 2] - det[..., 0] + 1, det[..., 3] - det[..., 1] + 1
+        ok = (val > 0) & (ws >= self.min_size) & (hs >= self.min_size)
+        counts = ok.sum(1).tolist()  # the one host round trip of the selection
         results = []
-        for lv in per_img:
-            boxes = torch.cat([x[0] for x in lv], 0)
-            scores = torch.cat([x[1] for x in lv], 0)
-            labels = torch.cat([x[2] for x in lv], 0)
+        for i in range(N):
+            if counts[i] == 0:
+                results.append((det.new_zeros((0, 4)), det.new_zeros((0,)), lab.new_zeros((0,))))
+                continue
+            m = ok[i]
+            boxes, scores, labels = det[i][m], torch.sqrt(val[i][m]), lab[i][m]
             # per-class NMS (reference inference.py:160-176 loops classes and calls boxlist_nms on each) as ONE
             # class-aware launch: a box is suppressed only by a kept, higher-scored box of the SAME label, which is
             # exactly greedy NMS run per class; output order = class-major, original index ascending within a class
-            keep = ops.nms_by_label(boxes, scores, labels, self.nms_thresh).to(boxes.device)
+            keep = ops.nms_by_label(boxes, scores, labels, self.nms_thresh).to(dev)
             keep = keep[torch.argsort(labels[keep], stable=True)]
             rb, rs, rl = boxes[keep], scores[keep], labels[keep]
             n = len(rs)
             if n > self.fpn_post_nms_top_n > 0:
-                th, _ = torch.kthvalue(rs.cpu(), n - self.fpn_post_nms_top_n + 1)
-                k = torch.nonzero(rs >= th.item()).squeeze(1)
+                th, _ = torch.kthvalue(rs, n - self.fpn_post_nms_top_n + 1)
+                k = torch.nonzero(rs >= th).squeeze(1)
                 rb, rs, rl = rb[k], rs[k], rl[k]
             results.append((rb, rs, rl))
         return results

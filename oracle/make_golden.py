@@ -211,10 +211,16 @@ def gen_step(check, H=128, W=256, N=2, name="step_128x256", forward_target=False
 
 
 def gen_inference(check, H=128, W=256, N=2, K=9, yaml_name="scan_vgg16_cityscapace_to_foggy.yaml",
-                  name="inference_128x256"):
+                  name="inference_128x256", sizes=None):
     out = {}
     sds = synth.all_state_dicts(K)
-    imgs = synth.synth_images(N, H, W, 3234)
+    if sizes is None:
+        imgs = ref_imgs = synth.synth_images(N, H, W, 3234)
+    else:  # ragged batch through the reference's collation: boxes are clipped to each image's TRUE size
+        rh.setup()
+        from fcos_core.structures.image_list import to_image_list
+        imgs = synth.synth_image_list(sizes, 3234)
+        ref_imgs = to_image_list(imgs, 32)
     for mode in ("common", "precision"):
         c = rh.make_cfg(["TEST.MODE", mode], yaml_name=yaml_name)
         model = rh.build_models(c)
@@ -233,7 +239,7 @@ def gen_inference(check, H=128, W=256, N=2, K=9, yaml_name="scan_vgg16_cityscapa
         torch.Tensor.view = safe_view
         try:
             with torch.no_grad():
-                res = rh.forward_detector(c, model, imgs, None)
+                res = rh.forward_detector(c, model, ref_imgs, None)
         finally:
             torch.Tensor.view = ov
         for i, bl in enumerate(res):
@@ -292,6 +298,8 @@ def main():
                  extra_cfg=R50_CFG, conv_body="R-50-FPN-RETINANET")
     if "inference" in todo:
         gen_inference(a.check)
+    if "inference_pad" in todo:
+        gen_inference(a.check, name="inference_pad_333x500", sizes=[(333, 500), (320, 480)])
     if "inference_s2c" in todo:
         gen_inference(a.check, K=2, yaml_name="scan_vgg16_sim10k_to_cityscapes.yaml", name="inference_s2c_128x256")
 

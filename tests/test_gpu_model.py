@@ -99,11 +99,15 @@ def test_prototype_and_kernels_match_reference(step_result, gold_dir):
         np.testing.assert_allclose(mh.get_conded_weight().cpu().numpy(), g["kernels"], rtol=1e-3, atol=a)
 
 
-@pytest.mark.parametrize("K,fixture", [(9, "inference_128x256"), (2, "inference_s2c_128x256")])
+@pytest.mark.parametrize("K,fixture", [(9, "inference_128x256"), (2, "inference_s2c_128x256"),
+                                       (9, "inference_pad_333x500")])
 def test_inference_matches_reference(device, gold_dir, K, fixture):
     from scan_amd import engine, synth
     g = np.load(os.path.join(gold_dir, fixture + ".npz"))
-    imgs = synth.synth_images(2, 128, 256, 3234).to(device)
+    if "pad" in fixture:  # ragged batch, zero-padded to 352x512; boxes are clipped to each image's true size
+        imgs = engine.to_image_list([t.to(device) for t in synth.synth_image_list([(333, 500), (320, 480)], 3234)], 32)
+    else:
+        imgs = synth.synth_images(2, 128, 256, 3234).to(device)
     for mode in ("common", "precision"):
         model = engine.build_model(K, test_mode=mode, device=device)
         engine.load_procedural_weights(model, K)

@@ -1,0 +1,75 @@
+"""Data-parallel Trainer on the GPU with two ranks sharing one device (gloo carries the collectives; RCCL refuses two
+ranks on one GPU).  Exercises everything engine.Trainer adds for N > 1 -- gradient averaging through the per-sub-model
+flat buffers on the side stream, the paradigm all-reduce inside the source forward, the waits before the fused SGD --
+around the real HIP kernels:
+  (a) different shards per rank -> parameters, momentum and the paradigm buffer are identical on both ranks;
+  (b) the same shard on both ranks -> identical to the single-process run (averaging equal gradients is a no-op)."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STEPS, H, W = 2, 128, 128
+
+
+def _run(rank, world, same_shard):
+    from scan_amd import engine, synth
+    dev = torch.device("cuda", 0)
+    model = engine.build_model(9, device=dev, attn_dropout=0.0)
+    engine.load_procedural_weights(model)
+    trainer = engine.Trainer(model, distributed=True if world > 1 else None)
+    shard = 0 if same_shard else rank
+    imgs_s = synth.synth_images(1, H, W, 11 + 10 * shard).to(dev)
+    imgs_t = synth.synth_images(1, H, W, 12 + 10 * shard).to(dev)
+    tg = synth.synth_targets(1, H, W, 8, 6, 13 + 10 * shard)
+    for _ in range(STEPS):
+        losses = trainer.step(imgs_s, tg, imgs_t)
+    torch.cuda.synchronize()
+    assert all(bool(torch.isfinite(v)) for v in losses.values())
+    out = {k: g.flat_p.detach().cpu().clone() for k, g in trainer.groups.items()}
+    out["momentum_backbone"] = trainer.groups["backbone"].flat_m.detach().cpu().clone()
+    out["prototype"] = model["middle_head"].prototype.detach().cpu().clone()
+    return out
+
+
+def _worker(rank, world, port, same_shard, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.save(_run(rank, world, same_shard), os.path.join(outdir, "rank%d.pt" % rank))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(same_shard, outdir):
+    ctx = mp.get_context("spawn")
+    port = 29600 + os.getpid() % 2000 + (1 if same_shard else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, same_shard, str(outdir))) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0
+    return tuple(torch.load(os.path.join(str(outdir), "rank%d.pt" % r)) for r in range(2))
+
+
+def test_two_ranks_different_shards_stay_identical(device, tmp_path):
+    a, b = _spawn(False, tmp_path)
+    for k in a:
+        assert torch.equal(a[k], b[k]), "rank 0 and rank 1 diverged in %s" % k
+
+
+def test_two_ranks_same_shard_equal_single_process(device, tmp_path):
+    a, b = _spawn(True, tmp_path)
+    ref = _run(0, 1, True)
+    for k in ref:
+        assert torch.equal(a[k], b[k]), k
+        assert torch.allclose(a[k], ref[k], rtol=1e-5, atol=1e-7), (k, (a[k] - ref[k]).abs().max().item())

@@ -226,6 +226,21 @@ int scan_maxpool2x2_backward(const float* x, const float* y, const float* dy, in
 int scan_maxpool3x3s2_forward(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, void* stream);
 int scan_add_relu(const float* a, const float* b, float* y, int64_t n, void* stream);
 
+/* ---- target-node density clustering on the device (replaces sklearn.cluster.DBSCAN(eps, min_samples = 5) inside
+ *      PrototypeComputation.DBSCAN_batch_cpu, rpn/fcos/loss.py:397-423, which only asks "is the point in cluster 0?"
+ *      -- noise -> 1, cluster 0 -> 0, selected = non-zero).  pts [n][D] fp32 rows, D % 4 == 0, n <= SCAN_DBSCAN_MAX.
+ *      ws: scan_dbscan_ws_bytes(n) bytes (adjacency bit matrix n^2/8 + masks), 8-byte aligned.
+ *      prepare: neighbour bit matrix (fp32 matrix-core P P^T, fp64 re-check at the threshold), core mask, seed;
+ *               info[0] <- lowest core index (n when there is no core point).
+ *      bfs_step: one breadth-first level over the core graph; call with parity 0, 1, 0, ... while *changed reads 1.
+ *      finish:  in_cluster0[i] = 1 iff sklearn would label point i with 0. ---- */
+#define SCAN_DBSCAN_MAX 1200000
+int64_t scan_dbscan_ws_bytes(int64_t n);
+int scan_dbscan_prepare(const float* pts, int64_t n, int32_t D, float eps, int32_t min_samples, void* ws,
+                        int32_t* info, void* stream);
+int scan_dbscan_bfs_step(int64_t n, void* ws, int32_t parity, int32_t* changed, void* stream);
+int scan_dbscan_finish(int64_t n, void* ws, uint8_t* in_cluster0, void* stream);
+
 /* ---- fused SGD with momentum (replaces torch.optim.SGD as configured by solver/build.py:7-43) ----
  * g' = g + wd*p ; buf = momentum*buf + g' ; p -= lr*buf   (first_step != 0: buf = g') */
 int scan_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float wd, float momentum,

@@ -53,6 +53,7 @@ SIGNATURES = {
     "scan_weight_split": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp]),
     "scan_conv3x3_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "scan_conv3x3_wgrad_bf16x3_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
+    "scan_dbscan_ws_bytes": (c_i64, [c_i64]),
     "scan_conv1x1_wgrad_bf16x3_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
     "scan_conv3x3_wgrad_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "scan_weight_transpose": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
@@ -73,6 +74,9 @@ SIGNATURES = {
                                                  c_i32, c_vp]),
     "scan_maxpool3x3s2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_add_relu": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
+    "scan_dbscan_prepare": (ctypes.c_int, [c_vp, c_i64, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp]),
+    "scan_dbscan_bfs_step": (ctypes.c_int, [c_i64, c_vp, c_i32, c_vp, c_vp]),
+    "scan_dbscan_finish": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp]),
     "scan_sgd_momentum": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_i32, c_vp]),
 }
 

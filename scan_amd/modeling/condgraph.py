@@ -111,12 +111,15 @@ def sim_matrix(a, b, eps=1e-8):
     return torch.mm(a / torch.clamp(a_n, min=eps), (b / torch.clamp(b_n, min=eps)).transpose(0, 1))
 
 
+DBSCAN_BACKEND = "device"  # "host": sklearn on the host cores, the reference's own call (kept for cross-checks)
+
+
 def dbscan_positive_rows(feat_l, act_l, n_images, eps, thr):
-    """PrototypeComputation.DBSCAN_batch_cpu (reference loss.py:397-423) on one level, HOST tier (north star:
-    DBSCAN target-node sampling stays on the host; sklearn, all cores).  feat_l [N*HW, C], act_l [N*HW, K]
-    rows.  Points are feat * act[c] at the (image, class, pixel) entries with act > thr, in that order; noise
-    (-1) -> 1, cluster 0 -> 0; a pixel row is selected when any of its class entries is non-zero."""
-    from sklearn import cluster
+    """PrototypeComputation.DBSCAN_batch_cpu (reference loss.py:397-423) on one level.  feat_l [N*HW, C], act_l
+    [N*HW, K] rows.  Points are feat * act[c] at the (image, class, pixel) entries with act > thr, in that order;
+    noise (-1) -> 1, cluster 0 -> 0; a pixel row is selected when any of its class entries is non-zero -- i.e. a point
+    counts iff it is NOT in DBSCAN's cluster 0, which ops.dbscan_in_cluster0 decides on the device (the reference
+    runs sklearn with n_jobs=-1 on the host: O(n^2), seconds per iteration once tens of thousands of pixels pass)."""
     K = act_l.shape[1]
     hw = feat_l.shape[0] // n_images
     act = act_l.detach().view(n_images, hw, K)[:, :, 1:].permute(0, 2, 1).contiguous()  # [N, CLS, HW]
@@ -126,9 +129,13 @@ def dbscan_positive_rows(feat_l, act_l, n_images, eps, thr):
     if idx.shape[0] > 0:
         pts = feat_l.detach().view(n_images, hw, -1)[idx[:, 0], idx[:, 2]] * act[mask][:, None]
         if bool(pts.bool().any()):
-            y = cluster.DBSCAN(eps=eps, n_jobs=-1).fit_predict(pts.cpu().numpy())
-            y[y < 0] = 1
-            sel[mask] = torch.from_numpy(y.astype(np.float32)).to(sel.device)
+            if DBSCAN_BACKEND == "host":
+                from sklearn import cluster
+                y = cluster.DBSCAN(eps=eps, n_jobs=-1).fit_predict(pts.cpu().numpy())
+                y[y < 0] = 1
+                sel[mask] = torch.from_numpy(y.astype(np.float32)).to(sel.device)
+            else:
+                sel[mask] = (~ops.dbscan_in_cluster0(pts.contiguous(), eps, 5)).to(sel.dtype)
         else:
             sel[mask] = 1.0
     return sel.sum(1).bool().reshape(-1)  # [N*HW] in row order

@@ -757,6 +757,37 @@ def ml_nms(dets, scores, labels, thr):
     return _nms_impl(dets, scores, labels, thr, False)
 
 
+# ----------------------------------------------------------------------------- density clustering (target nodes)
+def dbscan_in_cluster0(pts, eps, min_samples=5):
+    """bool [n]: True where sklearn.cluster.DBSCAN(eps, min_samples).fit_predict(pts) would return label 0 -- all the
+    target-node sampling needs (reference rpn/fcos/loss.py:397-423: noise -> 1, cluster 0 -> 0, selected = non-zero).
+    Neighbour search, core test, breadth-first growth of cluster 0 and border assignment run on the device
+    (scan_dbscan_*); the host only reads one flag per breadth-first level."""
+    _chk(pts)
+    n, d = pts.shape
+    if n == 0:
+        return torch.zeros((0,), dtype=torch.bool, device=pts.device)
+    nbytes = query("scan_dbscan_ws_bytes", n)
+    if nbytes < 0:
+        raise RuntimeError("dbscan: n=%d exceeds SCAN_DBSCAN_MAX" % n)
+    ws = torch.empty((nbytes // 8 + 1,), dtype=torch.float64, device=pts.device)
+    info = torch.empty((2,), dtype=torch.int32, device=pts.device)
+    st = _stream()
+    call("scan_dbscan_prepare", _ptr(pts), n, d, float(eps), int(min_samples), _ptr(ws), _ptr(info), st)
+    if int(info[0].item()) >= n:  # no core point: everything is noise
+        return torch.zeros((n,), dtype=torch.bool, device=pts.device)
+    changed = torch.zeros((1,), dtype=torch.int32, device=pts.device)
+    parity = 0
+    while True:
+        call("scan_dbscan_bfs_step", n, _ptr(ws), parity, _ptr(changed), st)
+        if int(changed.item()) == 0:
+            break
+        parity ^= 1
+    out = torch.empty((n,), dtype=torch.uint8, device=pts.device)
+    call("scan_dbscan_finish", n, _ptr(ws), _ptr(out), st)
+    return out.bool()
+
+
 # ----------------------------------------------------------------------------- optimizer
 def sgd_momentum_(p, g, buf, lr, wd, momentum, first_step):
     _chk(p, g, buf)

@@ -501,3 +501,52 @@ def test_first_layer_conv_forward(device, k, stride, hw, n):
     finally:
         ops.CONV_MODE = keep
     assert (y - y32).abs().max().item() <= 2e-5 * scale
+
+
+def _sk_in0(pts, eps, min_samples=5):
+    from sklearn import cluster
+    return cluster.DBSCAN(eps=eps, min_samples=min_samples).fit_predict(pts) == 0
+
+
+@pytest.mark.parametrize("case", ["blobs", "chain", "all_noise", "one_blob", "duplicates", "ragged_n", "borders"])
+def test_dbscan_cluster0_matches_sklearn(device, case):
+    """scan_dbscan_* against sklearn.cluster.DBSCAN labels: membership of cluster 0 (all the reference's selection uses,
+    rpn/fcos/loss.py:417-421) must be identical point by point."""
+    from scan_amd import ops
+    import zlib
+    rs = np.random.RandomState(zlib.crc32(case.encode()) % 100000)
+    D, eps = 256, 3.0
+    if case == "blobs":  # several dense blobs + uniform noise, shuffled
+        centers = rs.randn(6, D) * 4
+        pts = np.concatenate([c + rs.randn(300, D) * 0.12 for c in centers] + [rs.randn(200, D) * 4])
+        pts = pts[rs.permutation(len(pts))]
+    elif case == "chain":  # long thin cluster: many breadth-first levels
+        t = np.linspace(0, 400, 1500)[:, None]
+        d = np.zeros((1, D)); d[0, 0] = 1.0
+        pts = t * d + rs.randn(1500, D) * 0.05
+        pts = np.concatenate([pts, rs.randn(100, D) * 50])[rs.permutation(1600)]
+    elif case == "all_noise":
+        pts = rs.randn(500, D) * 10
+    elif case == "one_blob":
+        pts = rs.randn(700, D) * 0.1
+    elif case == "duplicates":  # exact duplicates (d = 0) plus points just inside / just outside eps along one axis.
+        # (A pair at EXACTLY eps is a coin toss inside sklearn itself: its fp64 |x|^2 + |y|^2 - 2 x.y carries 1e-12 of
+        #  rounding noise either way -- probed on the host: 57 of 200 such pairs come out as non-neighbours.)
+        base = rs.randn(40, D) * 5
+        pts = np.repeat(base, 8, axis=0)
+        pts[::16, 0] += eps - 1e-3
+        pts[8::16, 0] += eps + 1e-3
+    elif case == "ragged_n":  # n not a multiple of the 128 tile / 32-bit word
+        centers = rs.randn(3, D) * 3
+        pts = np.concatenate([c + rs.randn(211, D) * 0.15 for c in centers] + [rs.randn(30, D) * 6])
+    else:  # borders: sparse ring of non-core points around a dense core, some reachable from two clusters
+        a = rs.randn(200, D) * 0.05
+        b = rs.randn(200, D) * 0.05; b[:, 0] += 5.0
+        ring = rs.randn(60, D); ring = ring / np.linalg.norm(ring, axis=1, keepdims=True) * 2.8
+        mid = rs.randn(10, D) * 0.01; mid[:, 0] += 2.5
+        pts = np.concatenate([ring[:30], a, mid, b, ring[30:] + np.eye(1, D)[0] * 5.0])
+    pts = pts.astype(np.float32)
+    ref = _sk_in0(pts, eps)
+    got = ops.dbscan_in_cluster0(torch.from_numpy(pts).to(device), eps, 5).cpu().numpy()
+    assert got.shape == ref.shape
+    assert np.array_equal(got, ref), "cluster-0 membership differs at %d of %d points" % ((got != ref).sum(), len(ref))

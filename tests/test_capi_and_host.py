@@ -192,3 +192,55 @@ def test_to_image_list_padding():
     assert tuple(to_image_list(torch.zeros(3, 40, 40), 32).tensors.shape) == (1, 3, 64, 64)
     with pytest.raises(TypeError):
         to_image_list(np.zeros((3, 4, 4)))
+
+
+def test_target_plan_is_consistent_and_per_batch(gold_dir):
+    """fcos.target_plan (the once-per-batch, ground-truth-only part of the source pass): same labels / node order as the
+    stand-alone functions pinned above, centerness targets on the positives, cached for one batch only."""
+    gold = json.load(open(os.path.join(gold_dir, "step_128x256.json")))
+    g = np.load(os.path.join(gold_dir, "step_128x256.npz"))
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    shape = ops.PyramidShape(N, [(H // s, W // s) for s in fcos.FPN_STRIDES])
+    cpu = torch.device("cpu")
+    tg = synth.synth_targets(N, H, W, 8, 12, 4321)
+    fcos.reset_target_plan()
+    plan = fcos.target_plan(shape, tg, cpu)
+    for l in range(5):
+        assert np.array_equal(plan.labels[shape.row_off[l]:shape.row_off[l + 1]].numpy(), g["label_map_%d" % l])
+    assert np.array_equal(plan.node_labels.numpy(), g["node_labels"])
+    assert plan.labels_i32.dtype == torch.int32 and torch.equal(plan.labels_i32.long(), plan.labels)
+    assert torch.equal(plan.pos_inds, torch.nonzero(plan.labels > 0).squeeze(1)) and plan.n_pos == len(plan.pos_inds)
+    assert torch.equal(plan.reg_pos, plan.reg_targets[plan.pos_inds])
+    assert torch.allclose(plan.ctr_pos, fcos.centerness_targets(plan.reg_pos))
+    idx, labs = fcos.source_node_index(plan.labels, shape)
+    assert torch.equal(idx, plan.node_index) and torch.equal(labs, plan.node_labels)
+    # node features are a plain gather with that index
+    feats = torch.randn(shape.rows, 8)
+    pts, _ = condgraph.sample_source_nodes(feats, plan.labels, shape)
+    assert torch.equal(pts, feats[plan.node_index])
+    # cache: same batch object -> same plan; another batch or a reset -> a new one
+    assert fcos.target_plan(shape, tg, cpu) is plan
+    assert fcos.target_plan(shape, synth.synth_targets(N, H, W, 8, 12, 999), cpu) is not plan
+    fcos.reset_target_plan()
+    assert fcos.target_plan(shape, tg, cpu) is not plan
+
+
+def test_model_configs_build_on_cpu():
+    """engine.CONFIGS: the shipped yamls' model variants have the reference's parameter names / shapes."""
+    for name, cfg in engine.CONFIGS.items():
+        body = cfg.get("conv_body", "VGG-16-FPN-RETINANET")
+        model = engine.build_model(cfg["num_classes"], cfg["test_mode"], device="cpu", transfer_cfg=cfg["transfer_cfg"],
+                                   conv_body=body)
+        sds = synth.all_state_dicts(cfg["num_classes"], body)
+        for k, m in model.items():
+            missing, unexpected = m.load_state_dict(sds[k], strict=False)
+            assert not unexpected and not [x for x in missing if "cond_2" not in x], (name, k, missing, unexpected)
+        K = cfg["num_classes"]
+        assert model["fcos"].head.cls_logits.weight.shape[0] == K - 1
+        assert model["middle_head"].prototype.shape == (K, 256, 3)
+        assert model["middle_head"].transfer_cfg == tuple(cfg["transfer_cfg"])
+        assert model["fcos"].box_selector_test.mode == cfg["test_mode"]
+        if body.startswith("R-"):
+            frozen = [n for n, p in model["backbone"].named_parameters() if not p.requires_grad]
+            assert "body.stem.conv1.weight" in frozen and "body.layer1.2.conv3.weight" in frozen
+            assert all(not n.startswith(("body.layer2", "body.layer3", "body.layer4", "fpn.")) for n in frozen)

@@ -195,6 +195,10 @@ class Trainer:
         self.tgt_stream = torch.cuda.Stream() if on_gpu else None
         self.overlap_target = True
         self.merge_source_backward = True
+        # source and target frames as ONE batch through backbone / middle head / discriminators and one backward
+        # (step_paired): same losses and gradients as the three phases, larger launches.  Used when the target
+        # pass needs no node sampling (forward_target False) and both batches have the same padded size.
+        self.paired = True
 
     def _allreduce_async(self, keys):
         """all-reduce the flat gradient buffers of sub-models whose gradients are final, on the side stream."""
@@ -238,8 +242,67 @@ class Trainer:
         if self.tgt_stream is not None:
             main.wait_stream(self.tgt_stream)
 
+    def step_paired(self, il_s, targets_s, il_t):
+        """The DA iteration with the source and the target frames in one pyramid (frames [0, B) source, [B, 2B)
+        target).  Per image nothing changes -- convolutions, GroupNorm, dynamic conv and the CKA towers treat images
+        independently -- and everything that is per DOMAIN keeps its own rows: node sampling, paradigm update, act
+        loss and the FCOS head see the source rows, each discriminator takes its source loss (label 1) and its target
+        loss (label 0) on the two halves of a level.  The reference's three backward calls (trainer.py:299,343,377)
+        accumulate into the same .grad, so ONE backward of the summed losses leaves identical gradients."""
+        model, lam = self.model, self.con_dis_lambda
+        ops.SPLIT_EPOCH = (id(self), self.iteration)
+        fcos_mod.reset_target_plan()
+        for m in model.values():
+            m.train()
+        for g in self.groups.values():
+            g.zero_grad()
+        B = il_s.tensors.shape[0]
+        images = torch.cat([il_s.tensors, il_t.tensors], 0)
+        inputs_ready = torch.cuda.Event()
+        inputs_ready.record(torch.cuda.current_stream())
+        rows, shape = model["backbone"](images)
+        shape_src = ops.PyramidShape(B, shape.sizes)
+        fcos_mod.target_plan(shape_src, targets_s, images.device, side_stream=_plan_stream(images.device),
+                             after=inputs_ready)
+        feats, node_loss, act_loss, maps = model["middle_head"].forward_pair(rows, shape, targets_s, B)
+        losses = {"node_loss_gs": node_loss, "act_loss_gs": act_loss}
+        src_feats, _ = ops.take_images(feats, shape, 0, B)
+        _, fl = model["fcos"](il_s.image_sizes, src_feats, shape_src, targets=targets_s)
+        losses.update({k + "_gs": v for k, v in fl.items()})
+        f, a = ops.split_levels(feats, shape), ops.split_levels(maps, shape)
+        main = torch.cuda.current_stream()
+        for lvl in DIS_ORDER:
+            i = LEVELS.index(lvl)
+            side = self.dis_streams.get(lvl)
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side if side is not None else main):
+                ls, lt = model["dis_%s_CON" % lvl].forward_pair(f[i], a[i], shape.level(i), B)
+                losses["loss_adv_%s_CON_ds" % lvl] = lam * ls
+                losses["loss_adv_%s_CON_dt" % lvl] = lam * lt
+        for side in self.dis_streams.values():
+            main.wait_stream(side)
+        sum(losses.values()).backward()
+        self._join_streams()
+        losses["zero_gt"] = feats.new_zeros(())
+        self._allreduce_async(list(self.groups))
+        if self.distributed:
+            for w in self._pending:
+                w.wait()
+            self._pending = []
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        fac = warmup_factor(self.iteration)
+        for g in self.groups.values():
+            g.step(fac)
+        self.iteration += 1
+        return losses
+
     def step(self, images_s, targets_s, images_t, forward_target=False):
         """One DA iteration; returns the loss dict (0-dim GPU tensors, reference key names)."""
+        if self.paired and not forward_target and self.tgt_stream is not None:
+            il_s, il_t = to_image_list(images_s), to_image_list(images_t)
+            if il_s.tensors.shape == il_t.tensors.shape:
+                return self.step_paired(il_s, targets_s, il_t)
         model, lam = self.model, self.con_dis_lambda
         ops.SPLIT_EPOCH = (id(self), self.iteration)  # parameters change once per iteration: reuse their bf16 planes
         fcos_mod.reset_target_plan()

@@ -291,6 +291,23 @@ class GRAPHModule(nn.Module):
         return out, None, None, maps
 
 
+    def forward_pair(self, rows, shape, targets, n_src):
+        """Source and target frames in ONE pyramid (images [0, n_src) are the source batch): the towers, the dynamic
+        conv and head_out run once over all frames; node sampling, the paradigm update and the act loss use the source
+        rows only.  Same arithmetic as forward(mode='source') followed by forward(mode='target'): the target frames
+        see the kernels generated from the paradigm the source frames have just updated (reference trainer.py:284-296
+        then :346-352).  -> out [M,256], node_loss, act_loss, act_maps [M,K]."""
+        feats = self.head_in(rows, shape)
+        src, shape_src = ops.take_images(feats, shape, 0, n_src)
+        plan = target_plan(shape_src, targets, rows.device)
+        node_loss, proto_batch = self._forward_gcns(src[plan.node_index], plan.node_labels)
+        self.update_prototype_nx1_rnn(proto_batch)
+        kernels = self.get_conded_weight()
+        logits, maps, out = self._act_and_out(feats, shape, kernels)
+        act_loss = self.lamda2 * self.act_loss_func(ops.take_images(logits, shape, 0, n_src)[0], plan.labels.long())
+        return out, node_loss, act_loss, maps
+
+
 def build_condgraph(cfg=None, in_channels=256, num_classes=9, transfer_cfg=("NODES", "ADJ")):
     """transfer_cfg = MODEL.MIDDLE_HEAD.TRANSFER_CFG: ('NODES', 'ADJ') in the C2F yaml, the default (None,)
     (reference config/defaults.py:694) in the Sim10k / KITTI yamls."""

@@ -55,9 +55,7 @@ class FCOSDiscriminator_con(nn.Module):
         b2 = torch.cat([b[2].bias for b in blocks], 0)
         return w1, b1, w2, b2
 
-    def forward(self, feature, target, act_maps=None, domain="source", shape=None):
-        """feature [M_l,256], act_maps [M_l,K] rows of ONE level; shape = that level's PyramidShape."""
-        assert target in (0, 1, 0.1, 0.9) and domain in ("source", "target")
+    def _logits(self, feature, act_maps, shape):
         Cf = self.num_classes
         feature = self.grad_reverse(feature)
         act_maps = self.grad_reverse(act_maps)
@@ -68,9 +66,28 @@ class FCOSDiscriminator_con(nn.Module):
         if pad:
             xcat = torch.nn.functional.pad(xcat, (0, pad))
         h = ops.conv2d(xcat, w1, b1, shape, 3, 1, relu="deferred")  # its only consumer masks dx by (h > 0)
-        logits = ops.conv2d(h, w2, b2, shape, 3, 1, mask_dx=True)[:, :Cf]
+        return ops.conv2d(h, w2, b2, shape, 3, 1, mask_dx=True)[:, :Cf], act_maps
+
+    def _loss(self, logits, act_maps, target):
+        Cf = self.num_classes
         if Cf == 1:
             # single foreground class (Sim10k / KITTI): plain mean BCE, no act-map weight (reference :122-123)
             logits = logits.reshape(-1)
             return ops.bce_with_logits_mean(logits, torch.full_like(logits, float(target)))
         return ops.cka_bce(logits, act_maps.detach(), float(target), Cf)
+
+    def forward(self, feature, target, act_maps=None, domain="source", shape=None):
+        """feature [M_l,256], act_maps [M_l,K] rows of ONE level; shape = that level's PyramidShape."""
+        assert target in (0, 1, 0.1, 0.9) and domain in ("source", "target")
+        logits, act_maps = self._logits(feature, act_maps, shape)
+        return self._loss(logits, act_maps, target)
+
+    def forward_pair(self, feature, act_maps, shape, n_src):
+        """source frames [0, n_src) and target frames [n_src, N) of one level in ONE pass through the tower and the
+        class branches; the two domain losses (labels 1.0 / 0.0, each with its own act-map normaliser) are taken on
+        the two halves of the rows.  Same values and gradients as forward(.., 1.0, 'source') + forward(.., 0.0,
+        'target') (reference trainer.py:314-333, 373-376)."""
+        logits, act_maps = self._logits(feature, act_maps, shape)
+        (h, w) = shape.sizes[0]
+        m = n_src * h * w
+        return self._loss(logits[:m], act_maps[:m], 1.0), self._loss(logits[m:], act_maps[m:], 0.0)

@@ -382,6 +382,35 @@ def split_levels(rows, shape):
     return _SplitLevels.apply(rows, shape)
 
 
+class _TakeImages(torch.autograd.Function):
+    """rows of images [i0, i1) of every level, as the pyramid of those images (level-major order is kept)."""
+
+    @staticmethod
+    def forward(ctx, rows, shape, i0, i1):
+        ctx.cfg = (shape, i0, i1, rows.shape)
+        parts = []
+        for l, (h, w) in enumerate(shape.sizes):
+            r0 = shape.row_off[l]
+            parts.append(rows[r0 + i0 * h * w:r0 + i1 * h * w])
+        return torch.cat(parts, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        shape, i0, i1, full = ctx.cfg
+        out = g.new_zeros(full)
+        o = 0
+        for l, (h, w) in enumerate(shape.sizes):
+            r0, n = shape.row_off[l], (i1 - i0) * h * w
+            out[r0 + i0 * h * w:r0 + i0 * h * w + n] = g[o:o + n]
+            o += n
+        return out, None, None, None
+
+
+def take_images(rows, shape, i0, i1):
+    """sub-batch [i0, i1) of a pyramid -> (rows, PyramidShape of i1 - i0 images)."""
+    return _TakeImages.apply(rows, shape, i0, i1), PyramidShape(i1 - i0, shape.sizes)
+
+
 # ----------------------------------------------------------------------------- 2x2 max pooling
 class _MaxPool2x2(torch.autograd.Function):
     @staticmethod

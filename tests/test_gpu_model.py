@@ -201,10 +201,12 @@ def test_stream_overlap_is_race_free(device):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (k, (a - b).abs().max().item())
 
 
-@pytest.mark.parametrize("name", ["step_ragged_160x224", "step_cfg1_800x1600"])
-def test_step_other_sizes_match_reference(device, gold_dir, name):
+@pytest.mark.parametrize("name,paired", [("step_ragged_160x224", True), ("step_ragged_160x224", False),
+                                         ("step_cfg1_800x1600", True), ("step_128x256", False)])
+def test_step_other_sizes_match_reference(device, gold_dir, name, paired):
     """ragged level sizes (20x28 ... 2x2: partial kernel tiles everywhere) and BASELINE.json configs[0]
-    (one 800x1600 frame: 100x200, 50x100, 25x50, 13x25, 7x13), both conv modes, all losses within 1e-4."""
+    (one 800x1600 frame: 100x200, 50x100, 25x50, 13x25, 7x13), both conv modes, all losses within 1e-4; with the
+    source + target frames in one pyramid (Trainer.step_paired, the default) and as the reference's three phases."""
     from scan_amd import engine, ops, synth
     gold = json.load(open(os.path.join(gold_dir, name + ".json")))
     H, W, N = gold["H"], gold["W"], gold["N"]
@@ -214,6 +216,7 @@ def test_step_other_sizes_match_reference(device, gold_dir, name):
             model = engine.build_model(9, device=device, attn_dropout=0.0)
             engine.load_procedural_weights(model)
             trainer = engine.Trainer(model)
+            trainer.paired = paired
             for g in trainer.groups.values():
                 g.lr = 0.0
             losses = trainer.step(synth.synth_images(N, H, W, gold["seeds"]["src"]).to(device),

@@ -241,6 +241,18 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
     const float bv = (bias != nullptr && o < Nout) ? bias[o] : 0.f;
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
+      // the ReLU mask of a data gradient: fetch the 16 values of this MFMA tile first so the loads overlap
+      // (one dependent load per store serialises on the memory latency and costs ~20 us per tile)
+      float mk[16];
+      if (mask != nullptr) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int p = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int y = ty0 + (p >> 4), x = tx0 + (p & 15);
+          const bool ok = y < H && x < W && o < Nout;
+          mk[r] = ok ? mask[(rowbase + (int64_t)y * W + x) * Ns + o] : 0.f;
+        }
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int p = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -249,7 +261,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
           const int64_t m = rowbase + (int64_t)y * W + x;
           float v = acc[tm][tn][r] + bv;
           if (relu) v = fmaxf(v, 0.f);
-          if (mask != nullptr) v = (mask[m * Ns + o] > 0.f) ? v : 0.f;
+          if (mask != nullptr) v = (mk[r] > 0.f) ? v : 0.f;
           dst[m * Ns + o] = v;
         }
       }

@@ -41,11 +41,14 @@ __global__ __launch_bounds__(256) void dbscan_sqnorm_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __restrict__ p, int64_t n, int D,
                                                                const double* __restrict__ sq, double eps2,
-                                                               uint32_t* __restrict__ bits, int64_t nw,
-                                                               int* __restrict__ counts) {
+                                                               uint32_t* __restrict__ bits, int64_t nw) {
   __shared__ float As[DB_T * DB_LD];
   __shared__ float Bs[DB_T * DB_LD];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  // the relation is symmetric: only tiles on or above the diagonal are computed, each writes its bits in both
+  // orientations (row words by wave ballot, column words from the lane's own 16 accumulator rows)
+  if (blockIdx.x < blockIdx.y) return;
+  const bool off_diag = blockIdx.x != blockIdx.y;
   const int64_t i0 = (int64_t)blockIdx.y * DB_T, j0 = (int64_t)blockIdx.x * DB_T;
   const int c4 = tid & 7, r0 = tid >> 3;
   const int wm = wid >> 1, wn = wid & 1, lrow = lane & 31, lh = lane >> 5;
@@ -58,19 +61,30 @@ __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __re
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
+  // the next K chunk is fetched into registers while the matrix cores work on the current one
+  float4 ra[4], rb[4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + 32 * i, k = k0 + 4 * c4;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[i] = ra[i];
+      if (k < D) {
+        if (i0 + r < n) ra[i] = *reinterpret_cast<const float4*>(p + (i0 + r) * D + k);
+        if (j0 + r < n) rb[i] = *reinterpret_cast<const float4*>(p + (j0 + r) * D + k);
+      }
+    }
+  };
+  fetch(0);
   for (int k0 = 0; k0 < D; k0 += DB_K) {
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = r0 + 32 * i, k = k0 + 4 * c4;
-      float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
-      if (k < D) {
-        if (i0 + r < n) va = *reinterpret_cast<const float4*>(p + (i0 + r) * D + k);
-        if (j0 + r < n) vb = *reinterpret_cast<const float4*>(p + (j0 + r) * D + k);
-      }
-      *reinterpret_cast<float4*>(As + r * DB_LD + 4 * c4) = va;
-      *reinterpret_cast<float4*>(Bs + r * DB_LD + 4 * c4) = vb;
+      const int r = r0 + 32 * i;
+      *reinterpret_cast<float4*>(As + r * DB_LD + 4 * c4) = ra[i];
+      *reinterpret_cast<float4*>(Bs + r * DB_LD + 4 * c4) = rb[i];
     }
+    if (k0 + DB_K < D) fetch(k0 + DB_K);
     __syncthreads();
     const float* a = As + (wm * 64 + lrow) * DB_LD + 4 * lh;
     const float* b = Bs + (wn * 64 + lrow) * DB_LD + 4 * lh;
@@ -102,15 +116,18 @@ __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __re
     const int64_t jw = (j0 + (wn * 2 + tn) * 32) >> 5;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
+      uint32_t colbits = 0u;  // this lane's column j over the 16 rows it holds
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int64_t i = i0 + (wm * 2 + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int64_t i = i0 + (wm * 2 + tm) * 32 + rr;
         bool pred = false;
         if (i < n && j < n) {
           const double si = sq[i];
           double d2 = si + sj - 2.0 * (double)acc[tm][tn][r];
-          // fp32 accumulation error of the dot product: a few 1e-6 of |p_i||p_j| <= (si + sj) / 2
-          const double band = 4e-5 * (si + sj) + 1e-9;
+          // worst-case fp32 accumulation error of the 256-term dot product: (K - 1) 2^-24 sum |a_k b_k|
+          // <= 1.53e-5 (si + sj) / 2, doubled by the factor 2 in front of it
+          const double band = 1.6e-5 * (si + sj) + 1e-9;
           if (fabs(d2 - eps2) <= band) {
             double e = 0.0;
             for (int k = 0; k < D; ++k) {
@@ -121,25 +138,40 @@ __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __re
           }
           pred = d2 <= eps2;
         }
+        colbits |= pred ? (1u << rr) : 0u;
         const unsigned long long m = __ballot(pred);
         // lanes 0..31 hold row i(lh = 0), lanes 32..63 row i + 4
         if (lrow == 0 && i < n) {
           const uint32_t half = lh ? (uint32_t)(m >> 32) : (uint32_t)m;
           bits[i * nw + jw] = half;
-          if (half) atomicAdd(&counts[i], __popc(half));
+        }
+      }
+      if (off_diag) {  // mirrored tile: row j, the word over rows i
+        colbits |= (uint32_t)__shfl_xor((int)colbits, 32, 64);
+        if (lh == 0 && j < n) {
+          bits[j * nw + ((i0 + (wm * 2 + tm) * 32) >> 5)] = colbits;
         }
       }
     }
   }
 }
 
-__global__ void dbscan_core_kernel(const int* __restrict__ counts, int64_t n, int min_samples,
-                                   uint32_t* __restrict__ core, int* __restrict__ first_core) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// neighbour count of a point = popcount of its row (self included); core: count >= min_samples.  A wave per row.
+__global__ __launch_bounds__(256) void dbscan_core_kernel(const uint32_t* __restrict__ bits, int64_t n, int64_t nw,
+                                                          int min_samples, int* __restrict__ counts,
+                                                          uint32_t* __restrict__ core, int* __restrict__ first_core) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (i >= n) return;
-  if (counts[i] >= min_samples) {
-    atomicOr(&core[i >> 5], 1u << (i & 31));
-    atomicMin(first_core, (int)i);
+  int c = 0;
+  for (int64_t w = lane; w < nw; w += 64) c += __popc(bits[i * nw + w]);
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if (lane == 0) {
+    counts[i] = c;
+    if (c >= min_samples) {
+      atomicOr(&core[i >> 5], 1u << (i & 31));
+      atomicMin(first_core, (int)i);
+    }
   }
 }
 
@@ -253,9 +285,9 @@ extern "C" int scan_dbscan_prepare(const float* pts, int64_t n, int32_t D, float
   hipLaunchKernelGGL(dbscan_sqnorm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, pts, n, D, w.sq);
   const unsigned tiles = (unsigned)((n + DB_T - 1) / DB_T);
   hipLaunchKernelGGL(dbscan_neighbors_kernel, dim3(tiles, tiles), dim3(256), 0, st, pts, n, D, w.sq,
-                     (double)eps * (double)eps, w.bits, w.nw, w.counts);
-  hipLaunchKernelGGL(dbscan_core_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w.counts, n, min_samples,
-                     w.core, w.first_core);
+                     (double)eps * (double)eps, w.bits, w.nw);
+  hipLaunchKernelGGL(dbscan_core_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.bits, n, w.nw, min_samples,
+                     w.counts, w.core, w.first_core);
   hipLaunchKernelGGL(dbscan_seed_kernel, dim3(1), dim3(1), 0, st, w.first_core, n, w.visited, w.fa);
   if (hipMemcpyAsync(info, w.first_core, 8, hipMemcpyDeviceToDevice, st) != hipSuccess) {
     scan_set_error("dbscan_prepare: info copy failed");

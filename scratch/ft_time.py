@@ -9,6 +9,34 @@ import os
 H, W, N = (1024, 2048, 2) if os.environ.get('FULL') else (256, 512, 2)
 s = synth.synth_images(N, H, W, 1234).to(dev); t = synth.synth_images(N, H, W, 2234).to(dev)
 tg = synth.synth_targets(N, H, W, 8, 12, 4321)
+from scan_amd import ops as _ops
+_orig_db = _ops.dbscan_in_cluster0
+def _db(pts, eps, ms=5):
+    import time as _t
+    n, d = pts.shape
+    nbytes = _ops.query("scan_dbscan_ws_bytes", n)
+    ws = torch.empty((nbytes // 8 + 1,), dtype=torch.float64, device=pts.device)
+    info = torch.empty((2,), dtype=torch.int32, device=pts.device)
+    st = _ops._stream()
+    torch.cuda.synchronize(); t0 = _t.time()
+    _ops.call("scan_dbscan_prepare", _ops._ptr(pts), n, d, float(eps), int(ms), _ops._ptr(ws), _ops._ptr(info), st)
+    torch.cuda.synchronize(); t1 = _t.time()
+    first = int(info[0].item())
+    changed = torch.zeros((1,), dtype=torch.int32, device=pts.device)
+    parity = 0; it = 0
+    if first < n:
+        while True:
+            _ops.call("scan_dbscan_bfs_step", n, _ops._ptr(ws), parity, _ops._ptr(changed), st)
+            it += 1
+            if int(changed.item()) == 0: break
+            parity ^= 1
+    torch.cuda.synchronize(); t2 = _t.time()
+    out = torch.empty((n,), dtype=torch.uint8, device=pts.device)
+    _ops.call("scan_dbscan_finish", n, _ops._ptr(ws), _ops._ptr(out), st)
+    torch.cuda.synchronize(); t3 = _t.time()
+    print("      dbscan n=%d: prepare %.1f ms, bfs %d levels %.1f ms, finish %.1f ms, in0=%d" % (n, (t1-t0)*1e3, it, (t2-t1)*1e3, (t3-t2)*1e3, int(out.sum())))
+    return out.bool() if first < n else torch.zeros((n,), dtype=torch.bool, device=pts.device)
+_ops.dbscan_in_cluster0 = _db
 orig = condgraph.dbscan_positive_rows
 acc = {"t": 0.0, "n": 0, "pts": 0}
 def timed(feat_l, act_l, n_images, eps, thr):

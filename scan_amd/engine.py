@@ -196,8 +196,8 @@ class Trainer:
         self.overlap_target = True
         self.merge_source_backward = True
         # source and target frames as ONE batch through backbone / middle head / discriminators and one backward
-        # (step_paired): same losses and gradients as the three phases, larger launches.  Used when the target
-        # pass needs no node sampling (forward_target False) and both batches have the same padded size.
+        # (step_paired): same losses and gradients as the three phases, larger launches.  Used when both batches
+        # have the same padded size.
         self.paired = True
 
     def _allreduce_async(self, keys):
@@ -242,7 +242,7 @@ class Trainer:
         if self.tgt_stream is not None:
             main.wait_stream(self.tgt_stream)
 
-    def step_paired(self, il_s, targets_s, il_t):
+    def step_paired(self, il_s, targets_s, il_t, forward_target=False):
         """The DA iteration with the source and the target frames in one pyramid (frames [0, B) source, [B, 2B)
         target).  Per image nothing changes -- convolutions, GroupNorm, dynamic conv and the CKA towers treat images
         independently -- and everything that is per DOMAIN keeps its own rows: node sampling, paradigm update, act
@@ -264,8 +264,11 @@ class Trainer:
         shape_src = ops.PyramidShape(B, shape.sizes)
         fcos_mod.target_plan(shape_src, targets_s, images.device, side_stream=_plan_stream(images.device),
                              after=inputs_ready)
-        feats, node_loss, act_loss, maps = model["middle_head"].forward_pair(rows, shape, targets_s, B)
+        feats, node_loss, act_loss, maps, consistency = model["middle_head"].forward_pair(
+            rows, shape, targets_s, B, forward_target=forward_target)
         losses = {"node_loss_gs": node_loss, "act_loss_gs": act_loss}
+        if consistency is not None:
+            losses["consistency_loss_gt"] = consistency
         src_feats, _ = ops.take_images(feats, shape, 0, B)
         _, fl = model["fcos"](il_s.image_sizes, src_feats, shape_src, targets=targets_s)
         losses.update({k + "_gs": v for k, v in fl.items()})
@@ -299,10 +302,10 @@ class Trainer:
 
     def step(self, images_s, targets_s, images_t, forward_target=False):
         """One DA iteration; returns the loss dict (0-dim GPU tensors, reference key names)."""
-        if self.paired and not forward_target and self.tgt_stream is not None:
+        if self.paired and self.tgt_stream is not None:
             il_s, il_t = to_image_list(images_s), to_image_list(images_t)
             if il_s.tensors.shape == il_t.tensors.shape:
-                return self.step_paired(il_s, targets_s, il_t)
+                return self.step_paired(il_s, targets_s, il_t, forward_target)
         model, lam = self.model, self.con_dis_lambda
         ops.SPLIT_EPOCH = (id(self), self.iteration)  # parameters change once per iteration: reuse their bf16 planes
         fcos_mod.reset_target_plan()

@@ -291,12 +291,14 @@ class GRAPHModule(nn.Module):
         return out, None, None, maps
 
 
-    def forward_pair(self, rows, shape, targets, n_src):
+    def forward_pair(self, rows, shape, targets, n_src, forward_target=False):
         """Source and target frames in ONE pyramid (images [0, n_src) are the source batch): the towers, the dynamic
         conv and head_out run once over all frames; node sampling, the paradigm update and the act loss use the source
         rows only.  Same arithmetic as forward(mode='source') followed by forward(mode='target'): the target frames
         see the kernels generated from the paradigm the source frames have just updated (reference trainer.py:284-296
-        then :346-352).  -> out [M,256], node_loss, act_loss, act_maps [M,K]."""
+        then :346-352).  With forward_target the target rows additionally go through DBSCAN node sampling, the graph
+        aggregation and the GST losses (_forward_train_target).
+        -> out [M,256], node_loss, act_loss, act_maps [M,K], consistency loss or None."""
         feats = self.head_in(rows, shape)
         src, shape_src = ops.take_images(feats, shape, 0, n_src)
         plan = target_plan(shape_src, targets, rows.device)
@@ -305,7 +307,17 @@ class GRAPHModule(nn.Module):
         kernels = self.get_conded_weight()
         logits, maps, out = self._act_and_out(feats, shape, kernels)
         act_loss = self.lamda2 * self.act_loss_func(ops.take_images(logits, shape, 0, n_src)[0], plan.labels.long())
-        return out, node_loss, act_loss, maps
+        consistency = None
+        if forward_target:
+            tgt, shape_t = ops.take_images(feats, shape, n_src, shape.n_images)
+            tmaps, _ = ops.take_images(maps, shape, n_src, shape.n_images)
+            pts, labs = sample_target_nodes(tgt, tmaps, shape_t, self.dbscan_eps, self.dbscan_thr)
+            if pts is not None and self.transfer_cfg and self.transfer_cfg[0] is not None:
+                _, tg_proto = self._forward_gcns(pts, labs)
+                tl = self.get_transfer_loss(tg_proto, pts, labs)
+                if tl is not None:
+                    consistency = self.lamda3 * tl
+        return out, node_loss, act_loss, maps, consistency
 
 
 def build_condgraph(cfg=None, in_channels=256, num_classes=9, transfer_cfg=("NODES", "ADJ")):

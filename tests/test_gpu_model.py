@@ -146,7 +146,8 @@ def test_two_steps_run_and_update(device):
     assert trainer.groups["backbone"].flat_m.abs().sum().item() > 0
 
 
-def test_step_with_target_sampling_matches_reference(device, gold_dir):
+@pytest.mark.parametrize("paired", [True, False])
+def test_step_with_target_sampling_matches_reference(device, gold_dir, paired):
     """forward_target=True: DBSCAN target-node sampling (host) + GST consistency loss (reference loss.py:397-518,
     condgraph.py:457-534) in the fp32-MFMA mode; golden captured at 2 x 256x512."""
     from scan_amd import engine, ops, synth
@@ -158,6 +159,7 @@ def test_step_with_target_sampling_matches_reference(device, gold_dir):
             model = engine.build_model(9, device=device, attn_dropout=0.0)
             engine.load_procedural_weights(model)
             trainer = engine.Trainer(model)
+            trainer.paired = paired
             for g in trainer.groups.values():
                 g.lr = 0.0
             losses = trainer.step(synth.synth_images(N, H, W, gold["seeds"]["src"]).to(device),

@@ -177,6 +177,11 @@ int scan_conv1x1_wgrad_bf16x3(const float* x, const scan_pyramid_t* xd, int32_t 
 int scan_conv_smallcin_bf16x3(const float* x, int32_t N, int32_t H, int32_t W, const float* w, const float* bias,
                               float* y, int32_t Cout, int32_t Cout_s, int32_t ksize, int32_t stride, int32_t relu,
                               void* stream);
+/* conv3x3 + bias (+ ReLU) + nn.MaxPool2d(2, 2) in one launch (last conv of a FROZEN VGG stage, vgg.py:8-33: forward only):
+ * single-level pyramid d with even H, W; y [N, H/2, W/2, Ns]. */
+int scan_conv3x3_pool2_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                              int32_t Csw, const float* bias, float* y, int32_t Nout, int32_t Ns, int32_t relu,
+                              void* stream);
 /* weight gradient of the same conv, bf16x3 on the matrix cores, deterministic split-K through ws
  * (scan_conv3x3_wgrad_bf16x3_ws_floats floats).  dw [Cout][9][Cs]; db [Cout] or NULL = bias gradient (column
  * sums of dy, fused); accumulate != 0: dw += result, db += result. */

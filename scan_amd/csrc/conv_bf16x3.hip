@@ -239,6 +239,26 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
   for (int tn = 0; tn < TN; ++tn) {
     const int o = n0 + wn * 64 + tn * 32 + lr;
     const float bv = (bias != nullptr && o < Nout) ? bias[o] : 0.f;
+    if (relu & 2) {
+      // fused 2x2 / stride-2 max-pool (frozen VGG stages, single-level pyramid): a window's four pixels are the
+      // registers r, r+1 (x, x+1) and r+8, r+9 (next row) of ONE lane, so the pooled tensor is written directly and
+      // the full-resolution activation never reaches HBM
+      const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = 2 * q;  // 0, 2, 4, 6
+          const int p = (wm * TM + tm) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          const int y = ty0 + (p >> 4), x = tx0 + (p & 15);
+          if (y < H && x < W && o < Nout) {
+            float v = fmaxf(fmaxf(acc[tm][tn][r], acc[tm][tn][r + 1]), fmaxf(acc[tm][tn][r + 8], acc[tm][tn][r + 9])) + bv;
+            if (relu & 1) v = fmaxf(v, 0.f);
+            dst[((int64_t)img * Hp * Wp + (int64_t)(y >> 1) * Wp + (x >> 1)) * Ns + o] = v;
+          }
+        }
+      continue;
+    }
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       // the ReLU mask of a data gradient: fetch the 16 values of this MFMA tile first so the loads overlap
@@ -260,7 +280,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
         if (y < H && x < W && o < Nout) {
           const int64_t m = rowbase + (int64_t)y * W + x;
           float v = acc[tm][tn][r] + bv;
-          if (relu) v = fmaxf(v, 0.f);
+          if (relu & 1) v = fmaxf(v, 0.f);
           if (mask != nullptr) v = (mk[r] > 0.f) ? v : 0.f;
           dst[m * Ns + o] = v;
         }
@@ -321,9 +341,9 @@ extern "C" int scan_weight_split(const float* w, int32_t O, int32_t T, int32_t C
 }
 
 // y[M][Ns] = conv3x3_s1(x[M][Cs]) with pre-split weights wh/wl [Nout][9][Csw]; same pyramid in and out.
-extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
-                                   int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout,
-                                   int32_t Ns, int32_t relu, void* stream) {
+static int conv3x3_bf16x3_launch(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                                 int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns,
+                                 int32_t relu, void* stream) {
   SCAN_CHECK_ARG(d && d->n_levels >= 1 && d->n_levels <= SCAN_MAX_LEVELS && d->n_images >= 1,
                  "conv3x3_bf16x3: bad pyramid");
   SCAN_CHECK_ARG(Cs > 0 && Cs % 4 == 0, "conv3x3_bf16x3: Cs=%d must be a positive multiple of 4", Cs);
@@ -359,6 +379,22 @@ extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int3
   }
   SCAN_LAUNCH_CHECK("conv3x3_bf16x3");
   return 0;
+}
+
+extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                                   int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout,
+                                   int32_t Ns, int32_t relu, void* stream) {
+  return conv3x3_bf16x3_launch(x, d, Cs, wh, wl, Csw, bias, mask, y, Nout, Ns, relu ? 1 : 0, stream);
+}
+
+// conv3x3 + bias (+ ReLU) + 2x2 / stride-2 max-pool in one launch: y [N, H/2, W/2, Ns] (forward only; single-level
+// pyramid with even H, W).  max and the monotone bias / ReLU commute, so the result equals pooling the conv output.
+extern "C" int scan_conv3x3_pool2_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh,
+                                         const void* wl, int32_t Csw, const float* bias, float* y, int32_t Nout,
+                                         int32_t Ns, int32_t relu, void* stream) {
+  SCAN_CHECK_ARG(d && d->n_levels == 1 && (d->h[0] & 1) == 0 && (d->w[0] & 1) == 0,
+                 "conv3x3_pool2_bf16x3: needs a single-level pyramid with even H and W");
+  return conv3x3_bf16x3_launch(x, d, Cs, wh, wl, Csw, bias, nullptr, y, Nout, Ns, (relu ? 1 : 0) | 2, stream);
 }
 
 // y[Mo][Ns] = conv1x1(x[Mi][Cs]) with pre-split weights wh/wl [Nout][1][Csw].  map 0: stride 1 (xd == yd);

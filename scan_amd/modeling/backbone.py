@@ -62,8 +62,15 @@ class VGGBody(nn.Module):
         for stage in VGG_STAGES:
             for j, idx in enumerate(stage):
                 m = self.features[idx]
+                if j == len(stage) - 1 and ops.conv_pool_fusable(rows, m.weight, m.bias, shape):
+                    # frozen stage: conv + ReLU + max-pool in one launch, the full-resolution map is never stored
+                    rows = ops.conv2d(rows, m.weight, m.bias, shape, 3, 1, relu=True, pool=True)
+                    (h, w) = shape.sizes[0]
+                    shape = PyramidShape(shape.n_images, [(h // 2, w // 2)])
+                    break
                 rows = ops.conv2d(rows, m.weight, m.bias, shape, 3, 1, relu="deferred", mask_dx=j > 0)
-            rows, shape = maxpool2x2(rows, shape, relu_input=True)
+            else:
+                rows, shape = maxpool2x2(rows, shape, relu_input=True)
             outs.append((rows, shape))
         return outs
 

@@ -175,7 +175,7 @@ _split_cache = {}
 
 
 def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None,
-                    mask=None, dst_shape=None, cmap=0):
+                    mask=None, dst_shape=None, cmap=0, pool=False):
     """wp: packed fp32 weights [O][T][Cs_w], T = 9 (3x3 / stride 1) or 1 (1x1; dst_shape = output pyramid, cmap =
     scan_conv1x1_bf16x3's map).  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
     st = _stream()
@@ -204,7 +204,10 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
             _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
     y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
     ev = kernel_timer.begin(name + ("_bn128" if nout > 64 else "_bn64"), flops)  # the two template instances
-    if T == 1:
+    if pool:
+        call("scan_conv3x3_pool2_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(y),
+             nout, ns, int(bool(relu)), st)
+    elif T == 1:
         call("scan_conv1x1_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
              _ptr(y), (dst_shape or shape).ref(), nout, ns, int(bool(relu)), cmap, st)
     else:
@@ -222,7 +225,7 @@ class _Conv2d(torch.autograd.Function):
     which those kernels do for free in their epilogue; it removes the separate relu-backward pass over dy."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx=False):
+    def forward(ctx, x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx=False, pool=False):
         _chk(x, bias)
         if not weight.is_cuda:
             raise RuntimeError("scan_amd ops run only on the GPU (HIP); no CPU fallback")
@@ -235,9 +238,9 @@ class _Conv2d(torch.autograd.Function):
         fast = CONV_MODE == "bf16x3" and ((ksize == 3 and stride == 1) or ksize == 1)
         flops = 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1]
         ckey = weight.data_ptr() if getattr(weight, "_scan_flat", False) else None
-        # first layer of a frozen stage (3 input channels): dedicated K = taps x 4 kernel, forward only
+        # first layer (3 input channels): dedicated K = taps x 4 forward kernel (the backward, if any, is generic)
         first = CONV_MODE == "bf16x3" and cs == 4 and cout <= 64 and (ksize, stride) in ((3, 1), (7, 2)) \
-            and shape.n_levels == 1 and not any(ctx.needs_input_grad[:3])
+            and shape.n_levels == 1
         if first:
             (h, w_), n = shape.sizes[0], shape.n_images
             y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
@@ -246,9 +249,16 @@ class _Conv2d(torch.autograd.Function):
                  stride, int(bool(relu)), _stream())
             kernel_timer.end(ev)
         elif fast:
-            y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s,
-                                "conv3x3_bf16x3_fwd" if ksize == 3 else "conv1x1_bf16x3_fwd", flops, cache_key=ckey,
-                                dst_shape=oshape, cmap=stride - 1)
+            if pool:  # conv + ReLU + 2x2 max-pool in one launch: forward only (frozen stages)
+                if ksize != 3 or shape.n_levels != 1:
+                    raise RuntimeError("conv2d(pool=True) needs a 3x3 conv on a single-level pyramid")
+                (h, w_) = shape.sizes[0]
+                y = _conv3x3_bf16x3(x, shape, wp, cout, shape.n_images * (h // 2) * (w_ // 2), cs, 0, bias, relu, cout_s,
+                                    "conv3x3_bf16x3_fwd", flops, cache_key=ckey, pool=True)
+            else:
+                y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s,
+                                    "conv3x3_bf16x3_fwd" if ksize == 3 else "conv1x1_bf16x3_fwd", flops,
+                                    cache_key=ckey, dst_shape=oshape, cmap=stride - 1)
         else:
             y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
             ev = kernel_timer.begin("conv_igemm_fwd", flops)
@@ -348,14 +358,28 @@ class _Conv2d(torch.autograd.Function):
             call("scan_colsum", _ptr(dy), M, cout, cout_s, _ptr(db), int(direct_b), _ptr(ws), st)
             if direct_b:
                 db = None
-        return dx, dw, db, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None, mask_dx=False):
+def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None, mask_dx=False, pool=False):
     """Returns rows [M_out, Cout_s]; the output PyramidShape is shape.conv_out(ksize, stride).
-    relu: False | True | "deferred" (see _Conv2d); mask_dx: x is a deferred-ReLU output."""
+    relu: False | True | "deferred" (see _Conv2d); mask_dx: x is a deferred-ReLU output; pool: fuse the following
+    2x2 / stride-2 max-pool (forward-only, bf16x3 mode: frozen VGG stages) -- the rows returned are the pooled ones."""
     assert relu in (False, True, "deferred")
-    return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx)
+    if pool and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad
+                                             or (bias is not None and bias.requires_grad)):
+        raise RuntimeError("conv2d(pool=True) is forward-only (frozen 3x3 conv on a single-level pyramid)")
+    return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx, pool)
+
+
+def conv_pool_fusable(x, weight, bias, shape):
+    """True when conv2d(pool=True) applies: bf16x3 mode, a 3x3 conv on a single-level pyramid with even sizes that is
+    not the 3-channel first layer, and nothing on it needs a gradient."""
+    (h, w_) = shape.sizes[0]
+    needs = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad
+                                         or (bias is not None and bias.requires_grad))
+    return (CONV_MODE == "bf16x3" and shape.n_levels == 1 and h % 2 == 0 and w_ % 2 == 0 and x.shape[1] != 4
+            and tuple(weight.shape[2:]) == (3, 3) and not needs)
 
 
 # ----------------------------------------------------------------------------- pyramid row split

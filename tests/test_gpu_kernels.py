@@ -550,3 +550,28 @@ def test_dbscan_cluster0_matches_sklearn(device, case):
     got = ops.dbscan_in_cluster0(torch.from_numpy(pts).to(device), eps, 5).cpu().numpy()
     assert got.shape == ref.shape
     assert np.array_equal(got, ref), "cluster-0 membership differs at %d of %d points" % ((got != ref).sum(), len(ref))
+
+
+@pytest.mark.parametrize("cin,cout,hw", [(64, 64, (24, 48)), (128, 128, (32, 32)), (64, 128, (18, 34))])
+def test_conv_relu_pool_fused(device, cin, cout, hw):
+    """scan_conv3x3_pool2_bf16x3 (frozen VGG stages): conv + bias + ReLU + 2x2 max-pool in one launch equals the two
+    separate ops, for both kernel instances (Cout <= 64 / > 64) and partial tiles."""
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, *hw, generator=g)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5)
+    b = torch.randn(cout, generator=g)
+    ref = F.max_pool2d(F.relu(F.conv2d(x, w, b, padding=1)), 2, 2)
+    rows, shape = _rows(x, device)
+    wd = w.to(device).contiguous(memory_format=torch.channels_last)
+    assert ops.conv_pool_fusable(rows, wd, b.to(device), shape)
+    y = ops.conv2d(rows, wd, b.to(device), shape, 3, 1, relu=True, pool=True)
+    pshape = ops.PyramidShape(2, [(hw[0] // 2, hw[1] // 2)])
+    got = ops.rows_to_nchw(y, pshape, 0, cout).cpu()
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+    # identical to the unfused HIP ops bit for bit (same accumulators, max commutes with the monotone epilogue)
+    y2, _ = ops.maxpool2x2(ops.conv2d(rows, wd, b.to(device), shape, 3, 1, relu=True), shape)
+    assert torch.equal(y, y2)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        ops.conv2d(rows.clone().requires_grad_(True), wd, b.to(device), shape, 3, 1, relu=True, pool=True)

@@ -35,7 +35,8 @@ def _worker(rank, world, port, q):
     flat = torch.full((1000,), float(rank + 1))
     flat.div_(world)
     dist.all_reduce(flat)
-    q.put((rank, mh.prototype.clone(), flat.clone(), torch.stack(pbs)))
+    # numpy arrays are pickled by value; torch tensors would travel as shared-memory handles that die with this process
+    q.put((rank, mh.prototype.clone().numpy(), flat.clone().numpy(), torch.stack(pbs).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -48,6 +49,7 @@ def test_two_rank_gloo():
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    res = [(r, torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(c)) for r, a, b, c in res]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

@@ -241,7 +241,14 @@ def main():
                        "losses_finite": finite},
             "roofline": roof, "cpu_baseline": cpu,
         }
-        print(json.dumps(line))
+        # RCCL prints a version banner through C stdio, which is still buffered here when stdout is a pipe: push it
+        # out first so the JSON line is the LAST line on stdout
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
 

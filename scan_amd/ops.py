@@ -211,8 +211,25 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
         call("scan_conv1x1_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
              _ptr(y), (dst_shape or shape).ref(), nout, ns, int(bool(relu)), cmap, st)
     else:
-        call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
-             _ptr(y), nout, ns, int(bool(relu)), st)
+        rem = nout % 128
+        if nout > 128 and 0 < rem <= 64 and cs_src >= 512 and rows_out >= 100000:
+            # 128-wide output tiles plus a small remainder (data gradient of the 264-channel discriminator input at
+            # P3, K = 1024): the remainder columns go through the 64-channel instance instead of a third, almost empty
+            # 128-wide tile (2022 -> 1794 us).  With a short K loop or few rows the extra launch costs more than the
+            # empty tile (265-channel head_out input: 614 -> 721 us), hence the size test.
+            main = nout - rem
+
+            def off(t, nbytes):
+                return ctypes.c_void_p(t.data_ptr() + nbytes) if t is not None else ctypes.c_void_p(0)
+
+            call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
+                 _ptr(y), main, ns, int(bool(relu)), st)
+            call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, off(wh, main * T * csw * 2),
+                 off(wl, main * T * csw * 2), csw, off(bias, main * 4), off(mask, main * 4), off(y, main * 4), rem, ns,
+                 int(bool(relu)), st)
+        else:
+            call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
+                 _ptr(y), nout, ns, int(bool(relu)), st)
     kernel_timer.end(ev)
     return y
 

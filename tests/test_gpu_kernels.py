@@ -575,3 +575,39 @@ def test_conv_relu_pool_fused(device, cin, cout, hw):
     assert torch.equal(y, y2)
     with pytest.raises(RuntimeError, match="forward-only"):
         ops.conv2d(rows.clone().requires_grad_(True), wd, b.to(device), shape, 3, 1, relu=True, pool=True)
+
+
+def test_dgrad_remainder_split_full_size(device):
+    """data gradient of a 264-channel input at discriminator-P3 size (K = 512, M = 100,352): the 8 remainder output
+    channels run as a second launch of the 64-channel instance (ops._conv3x3_bf16x3); result must equal the
+    independent fp32-MFMA kernel."""
+    from scan_amd import _lib, ops
+    g = torch.Generator().manual_seed(77)
+    shape = ops.PyramidShape(1, [(224, 448)])
+    x = torch.randn(shape.rows, 264, generator=g).to(device).requires_grad_(True)
+    w = (torch.randn(512, 264, 3, 3, generator=g) / (264 * 9) ** 0.5).to(device).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(shape.rows, 512, generator=g).to(device)
+    calls = []
+    orig = ops.call
+
+    def spy(name, *a):
+        if name == "scan_conv3x3_bf16x3":
+            calls.append(a[9])  # Nout
+        return orig(name, *a)
+
+    ops.call = spy
+    try:
+        ops.conv2d(x, w, None, shape, 3, 1).backward(gy)
+    finally:
+        ops.call = orig
+    assert 256 in calls and 8 in calls, calls  # main (2 x 128) + remainder launch
+    dx = x.grad.clone()
+    x.grad = None
+    keep = ops.CONV_MODE
+    ops.CONV_MODE = "fp32"
+    try:
+        ops.conv2d(x, w, None, shape, 3, 1).backward(gy)
+    finally:
+        ops.CONV_MODE = keep
+    ref = x.grad
+    assert (dx - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()

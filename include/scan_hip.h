@@ -177,6 +177,15 @@ int scan_conv1x1_wgrad_bf16x3(const float* x, const scan_pyramid_t* xd, int32_t 
 int scan_conv_smallcin_bf16x3(const float* x, int32_t N, int32_t H, int32_t W, const float* w, const float* bias,
                               float* y, int32_t Cout, int32_t Cout_s, int32_t ksize, int32_t stride, int32_t relu,
                               void* stream);
+/* conv3x3 + bias whose 256-channel output feeds GroupNorm(32, 256) (the [conv, GN, ReLU] towers of condgraph.py:86-106,
+ * fcos.py:25-49, fcos_head_discriminator_con.py:20-34): the epilogue also accumulates the GroupNorm sums into gn_ws
+ * (8-byte aligned, n_levels * N * 32 * 2 fp64 values, zeroed by the call); scan_groupnorm_stats_from_sums turns them into
+ * the (mean, rstd) table scan_groupnorm_stats would have produced. */
+int scan_conv3x3_gn_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                           int32_t Csw, const float* bias, float* y, int32_t Nout, int32_t Ns, float* gn_ws,
+                           void* stream);
+int scan_groupnorm_stats_from_sums(const float* ws, const scan_pyramid_t* d, int32_t C, int32_t G, float eps,
+                                   float* stats, void* stream);
 /* conv3x3 + bias (+ ReLU) + nn.MaxPool2d(2, 2) in one launch (last conv of a FROZEN VGG stage, vgg.py:8-33: forward only):
  * single-level pyramid d with even H, W; y [N, H/2, W/2, Ns]. */
 int scan_conv3x3_pool2_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,

@@ -66,7 +66,8 @@ template <int BN, int TH, int NT, int KS = 3>
 __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
     const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
-    float* __restrict__ dst, int Nout, int Ns, int relu, TileTab tt, int n_tiles, scan_pyramid_t sd, int map) {
+    float* __restrict__ dst, int Nout, int Ns, int relu, TileTab tt, int n_tiles, scan_pyramid_t sd, int map,
+    double* __restrict__ gn_ws) {
   constexpr int HALO = KS / 2, NTAPS = KS * KS;
   constexpr int PH = TH + 2 * HALO;
   constexpr int PWK = TW + 2 * HALO;
@@ -239,6 +240,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
   for (int tn = 0; tn < TN; ++tn) {
     const int o = n0 + wn * 64 + tn * 32 + lr;
     const float bv = (bias != nullptr && o < Nout) ? bias[o] : 0.f;
+    float gs = 0.f, gq = 0.f;
     if (relu & 2) {
       // fused 2x2 / stride-2 max-pool (frozen VGG stages, single-level pyramid): a window's four pixels are the
       // registers r, r+1 (x, x+1) and r+8, r+9 (next row) of ONE lane, so the pooled tensor is written directly and
@@ -283,7 +285,26 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
           if (relu & 1) v = fmaxf(v, 0.f);
           if (mask != nullptr) v = (mk[r] > 0.f) ? v : 0.f;
           dst[m * Ns + o] = v;
+          gs += v;
+          gq += v * v;
         }
+      }
+    }
+    if (gn_ws != nullptr) {
+      // GroupNorm(32) statistics of the 256-channel output this conv feeds: sum / sum of squares per (level, image,
+      // group of 8 channels = 8 adjacent lanes, both lane halves), one fp64 atomic pair per group and wave
+      double ds = (double)gs, dq = (double)gq;
+#pragma unroll
+      for (int sh = 1; sh <= 4; sh <<= 1) {
+        ds += __shfl_xor(ds, sh, 64);
+        dq += __shfl_xor(dq, sh, 64);
+      }
+      ds += __shfl_xor(ds, 32, 64);
+      dq += __shfl_xor(dq, 32, 64);
+      if ((lr & 7) == 0 && lh == 0 && o < Nout) {
+        const int64_t slot = ((int64_t)(lvl * d.n_images + img) * 32 + (o >> 3)) * 2;
+        atomicAdd(&gn_ws[slot], ds);
+        atomicAdd(&gn_ws[slot + 1], dq);
       }
     }
   }
@@ -343,7 +364,7 @@ extern "C" int scan_weight_split(const float* w, int32_t O, int32_t T, int32_t C
 // y[M][Ns] = conv3x3_s1(x[M][Cs]) with pre-split weights wh/wl [Nout][9][Csw]; same pyramid in and out.
 static int conv3x3_bf16x3_launch(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
                                  int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns,
-                                 int32_t relu, void* stream) {
+                                 int32_t relu, void* stream, double* gn_ws = nullptr) {
   SCAN_CHECK_ARG(d && d->n_levels >= 1 && d->n_levels <= SCAN_MAX_LEVELS && d->n_images >= 1,
                  "conv3x3_bf16x3: bad pyramid");
   SCAN_CHECK_ARG(Cs > 0 && Cs % 4 == 0, "conv3x3_bf16x3: Cs=%d must be a positive multiple of 4", Cs);
@@ -369,13 +390,13 @@ static int conv3x3_bf16x3_launch(const float* x, const scan_pyramid_t* d, int32_
       done = true;
     }
     hipLaunchKernelGGL((conv3x3_bf16x3_kernel<128, 16, 512>), dim3(tiles * n_tiles), dim3(512), sh, st, x, *d, Cs, h, l,
-                       Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *d, 0);
+                       Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *d, 0, gn_ws);
   } else {
     make_tiles(d, &tt, 8);
     const int tiles = tt.tile_off[d->n_levels];
     const size_t sh = (size_t)(2 * 10 * PPITCH + 4 * 64 * LROW) * sizeof(__bf16);
     hipLaunchKernelGGL((conv3x3_bf16x3_kernel<64, 8, 256>), dim3(tiles), dim3(256), sh, st, x, *d, Cs, h, l, Csw, bias,
-                       mask, y, Nout, Ns, relu, tt, 1, *d, 0);
+                       mask, y, Nout, Ns, relu, tt, 1, *d, 0, gn_ws);
   }
   SCAN_LAUNCH_CHECK("conv3x3_bf16x3");
   return 0;
@@ -385,6 +406,23 @@ extern "C" int scan_conv3x3_bf16x3(const float* x, const scan_pyramid_t* d, int3
                                    int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout,
                                    int32_t Ns, int32_t relu, void* stream) {
   return conv3x3_bf16x3_launch(x, d, Cs, wh, wl, Csw, bias, mask, y, Nout, Ns, relu ? 1 : 0, stream);
+}
+
+// conv3x3 + bias whose output feeds GroupNorm(32, 256): the epilogue also accumulates the per-(level, image, group)
+// sum and sum of squares into gn_ws (fp64, n_levels * n_images * 32 * 2 values, zeroed here), which
+// scan_groupnorm_stats_from_sums turns into (mean, rstd) -- the separate statistics pass over y disappears.
+extern "C" int scan_conv3x3_gn_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                                      int32_t Csw, const float* bias, float* y, int32_t Nout, int32_t Ns, float* gn_ws,
+                                      void* stream) {
+  SCAN_CHECK_ARG(Nout == 256 && gn_ws, "conv3x3_gn_bf16x3: needs Nout == 256 (GroupNorm(32, 256)) and a workspace");
+  SCAN_CHECK_ARG(d && d->n_levels >= 1 && d->n_levels <= SCAN_MAX_LEVELS && d->n_images >= 1, "conv3x3_gn_bf16x3: bad pyramid");
+  const size_t bytes = sizeof(double) * 2 * 32 * (size_t)d->n_levels * d->n_images;
+  if (hipMemsetAsync(gn_ws, 0, bytes, as_stream(stream)) != hipSuccess) {
+    scan_set_error("conv3x3_gn_bf16x3: memset failed");
+    return -2;
+  }
+  return conv3x3_bf16x3_launch(x, d, Cs, wh, wl, Csw, bias, nullptr, y, Nout, Ns, 0, stream,
+                               reinterpret_cast<double*>(gn_ws));
 }
 
 // conv3x3 + bias (+ ReLU) + 2x2 / stride-2 max-pool in one launch: y [N, H/2, W/2, Ns] (forward only; single-level
@@ -435,13 +473,13 @@ extern "C" int scan_conv1x1_bf16x3(const float* x, const scan_pyramid_t* xd, int
       done = true;
     }
     hipLaunchKernelGGL((conv3x3_bf16x3_kernel<128, 16, 512, 1>), dim3(tiles * n_tiles), dim3(512), sh, st, x, *yd, Cs, h,
-                       l, Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *xd, map);
+                       l, Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *xd, map, nullptr);
   } else {
     make_tiles(yd, &tt, 8);
     const int tiles = tt.tile_off[yd->n_levels];
     const size_t sh = (size_t)(2 * 8 * PPITCH + 4 * 64 * LROW) * sizeof(__bf16);
     hipLaunchKernelGGL((conv3x3_bf16x3_kernel<64, 8, 256, 1>), dim3(tiles), dim3(256), sh, st, x, *yd, Cs, h, l, Csw,
-                       bias, mask, y, Nout, Ns, relu, tt, 1, *xd, map);
+                       bias, mask, y, Nout, Ns, relu, tt, 1, *xd, map, nullptr);
   }
   SCAN_LAUNCH_CHECK("conv1x1_bf16x3");
   return 0;

@@ -248,6 +248,18 @@ extern "C" int scan_groupnorm_stats(const float* x, const scan_pyramid_t* d, int
   return 0;
 }
 
+// (mean, rstd) from sums accumulated elsewhere (scan_conv3x3_gn_bf16x3's epilogue): ws = fp64 [n_levels*N*G][2]
+extern "C" int scan_groupnorm_stats_from_sums(const float* ws, const scan_pyramid_t* d, int32_t C, int32_t G, float eps,
+                                              float* stats, void* stream) {
+  if (gn_check(d, C, G, "groupnorm_stats_from_sums")) return -1;
+  SCAN_CHECK_ARG(ws && stats, "groupnorm_stats_from_sums: null pointer");
+  const int total = d->n_levels * d->n_images * G;
+  hipLaunchKernelGGL(gn_stats_final_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream),
+                     reinterpret_cast<const double*>(ws), *d, G, eps, stats);
+  SCAN_LAUNCH_CHECK("gn_stats_final");
+  return 0;
+}
+
 extern "C" int scan_groupnorm_relu_forward(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
                                            const float* stats, const float* gamma, const float* beta, int32_t relu,
                                            float* y, void* stream) {

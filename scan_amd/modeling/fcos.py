@@ -33,7 +33,7 @@ def run_tower(tower, rows, shape, n):
     one launch per layer covers the whole pyramid."""
     for i in range(n):
         conv, gn = tower[3 * i], tower[3 * i + 1]
-        rows = ops.conv2d(rows, conv.weight, conv.bias, shape, 3, 1)
+        rows = ops.conv2d(rows, conv.weight, conv.bias, shape, 3, 1, gn_sums=True)  # GN sums from the conv epilogue
         rows = ops.groupnorm_relu(rows, gn.weight, gn.bias, shape, relu=True, eps=gn.eps)
     return rows
 

@@ -174,8 +174,12 @@ SPLIT_EPOCH = None
 _split_cache = {}
 
 
+# GroupNorm sums produced by a conv epilogue, handed to the groupnorm_relu call that consumes that conv's output
+_gn_sums = {}
+
+
 def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None,
-                    mask=None, dst_shape=None, cmap=0, pool=False):
+                    mask=None, dst_shape=None, cmap=0, pool=False, gn_sums=False):
     """wp: packed fp32 weights [O][T][Cs_w], T = 9 (3x3 / stride 1) or 1 (1x1; dst_shape = output pyramid, cmap =
     scan_conv1x1_bf16x3's map).  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
     st = _stream()
@@ -204,7 +208,13 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
             _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
     y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
     ev = kernel_timer.begin(name + ("_bn128" if nout > 64 else "_bn64"), flops)  # the two template instances
-    if pool:
+    if gn_sums:
+        sums = torch.empty((shape.n_levels * shape.n_images * 32 * 2,), dtype=torch.float64, device=x.device)
+        call("scan_conv3x3_gn_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(y), nout,
+             ns, _ptr(sums), st)
+        _gn_sums.clear()  # at most one pending hand-over: conv and its GroupNorm are adjacent calls of one thread
+        _gn_sums[y.data_ptr()] = sums
+    elif pool:
         call("scan_conv3x3_pool2_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(y),
              nout, ns, int(bool(relu)), st)
     elif T == 1:
@@ -242,7 +252,7 @@ class _Conv2d(torch.autograd.Function):
     which those kernels do for free in their epilogue; it removes the separate relu-backward pass over dy."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx=False, pool=False):
+    def forward(ctx, x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx=False, pool=False, gn_sums=False):
         _chk(x, bias)
         if not weight.is_cuda:
             raise RuntimeError("scan_amd ops run only on the GPU (HIP); no CPU fallback")
@@ -275,7 +285,8 @@ class _Conv2d(torch.autograd.Function):
             else:
                 y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s,
                                     "conv3x3_bf16x3_fwd" if ksize == 3 else "conv1x1_bf16x3_fwd", flops,
-                                    cache_key=ckey, dst_shape=oshape, cmap=stride - 1)
+                                    cache_key=ckey, dst_shape=oshape, cmap=stride - 1,
+                                    gn_sums=gn_sums and ksize == 3 and cout == 256 and cout_s == 256 and not relu)
         else:
             y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
             ev = kernel_timer.begin("conv_igemm_fwd", flops)
@@ -375,18 +386,21 @@ class _Conv2d(torch.autograd.Function):
             call("scan_colsum", _ptr(dy), M, cout, cout_s, _ptr(db), int(direct_b), _ptr(ws), st)
             if direct_b:
                 db = None
-        return dx, dw, db, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None, mask_dx=False, pool=False):
+def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None, mask_dx=False, pool=False,
+           gn_sums=False):
     """Returns rows [M_out, Cout_s]; the output PyramidShape is shape.conv_out(ksize, stride).
     relu: False | True | "deferred" (see _Conv2d); mask_dx: x is a deferred-ReLU output; pool: fuse the following
-    2x2 / stride-2 max-pool (forward-only, bf16x3 mode: frozen VGG stages) -- the rows returned are the pooled ones."""
+    2x2 / stride-2 max-pool (forward-only, bf16x3 mode: frozen VGG stages) -- the rows returned are the pooled ones;
+    gn_sums: the output feeds groupnorm_relu -- let the conv epilogue accumulate the GroupNorm sums (bf16x3 mode,
+    256 channels; otherwise ignored and groupnorm_relu computes its own statistics)."""
     assert relu in (False, True, "deferred")
     if pool and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad
                                              or (bias is not None and bias.requires_grad)):
         raise RuntimeError("conv2d(pool=True) is forward-only (frozen 3x3 conv on a single-level pyramid)")
-    return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx, pool)
+    return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx, pool, gn_sums)
 
 
 def conv_pool_fusable(x, weight, bias, shape):
@@ -531,7 +545,11 @@ class _GroupNormReLU(torch.autograd.Function):
         nws = query("scan_groupnorm_ws_floats", shape.ref(), C, 32)
         ws = torch.empty((nws // 2 + 1,), dtype=torch.float64, device=x.device)
         stats = x.new_empty((shape.n_levels * shape.n_images * 32 * 2,))
-        call("scan_groupnorm_stats", _ptr(x), shape.ref(), C, 32, eps, _ptr(stats), _ptr(ws), st)
+        sums = _gn_sums.pop(x.data_ptr(), None)
+        if sums is not None:  # accumulated by the epilogue of the conv that produced x
+            call("scan_groupnorm_stats_from_sums", _ptr(sums), shape.ref(), C, 32, eps, _ptr(stats), st)
+        else:
+            call("scan_groupnorm_stats", _ptr(x), shape.ref(), C, 32, eps, _ptr(stats), _ptr(ws), st)
         y = torch.empty_like(x)
         call("scan_groupnorm_relu_forward", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta), int(relu),
              _ptr(y), st)

@@ -611,3 +611,28 @@ def test_dgrad_remainder_split_full_size(device):
         ops.CONV_MODE = keep
     ref = x.grad
     assert (dx - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("sizes", [[(16, 32), (8, 16), (4, 8), (2, 4), (1, 2)], [(9, 21)]])
+def test_groupnorm_sums_from_conv_epilogue(device, sizes):
+    """scan_conv3x3_gn_bf16x3 + scan_groupnorm_stats_from_sums: the GroupNorm statistics accumulated by the conv
+    epilogue give the same normalised output (and the same gradients) as the separate statistics pass."""
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, 256, h, w, generator=g) for h, w in sizes]
+    rows, shape = _pyr(xs, device)
+    w = (torch.randn(256, 256, 3, 3, generator=g) / 48).to(device).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(256, generator=g).to(device)
+    gamma = (1 + 0.1 * torch.randn(256, generator=g)).to(device)
+    beta = (0.1 * torch.randn(256, generator=g)).to(device)
+    outs = []
+    for fused in (False, True):
+        r = rows.clone().requires_grad_(True)
+        wv, bv = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        gv, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        y = ops.groupnorm_relu(ops.conv2d(r, wv, bv, shape, 3, 1, gn_sums=fused), gv, bt, shape)
+        assert not ops._gn_sums  # the hand-over was consumed
+        (y * y).sum().backward()
+        outs.append((y.detach(), r.grad, wv.grad, gv.grad, bt.grad))
+    for a, c in zip(*outs):
+        assert (a - c).abs().max().item() <= 2e-5 * max(1.0, c.abs().max().item())

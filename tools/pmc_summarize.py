@@ -19,9 +19,9 @@ GROUPS = [  # (substring of the kernel name, group key)
     ("conv3x3_bf16x3_kernelILi64ELi8ELi256ELi3", "conv3x3_bf16x3_fwd_bn64"),
     ("conv3x3_bf16x3_kernelILi128ELi16ELi512ELi1", "conv1x1_bf16x3_fwd_dgrad_bn128"),
     ("conv3x3_bf16x3_kernelILi64ELi8ELi256ELi1", "conv1x1_bf16x3_fwd_dgrad_bn64"),
-    ("conv3x3_wgrad_bf16x3_kernelILi3", "conv3x3_bf16x3_wgrad"),
-    ("conv3x3_wgrad_bf16x3_kernelILi1", "conv1x1_bf16x3_wgrad"),
-    ("conv_smallcin_kernel", "conv_smallcin_bf16x3"),
+    ("conv3x3_wgrad_bf16x3_kernelILi3", "conv3x3_bf16x3_wgrad"), ("conv3x3_wgrad_bf16x3_kernel<3", "conv3x3_bf16x3_wgrad"),
+    ("conv3x3_wgrad_bf16x3_kernelILi1", "conv1x1_bf16x3_wgrad"), ("conv3x3_wgrad_bf16x3_kernel<1", "conv1x1_bf16x3_wgrad"),
+    ("conv_smallcin_kernel", "conv_smallcin_bf16x3"), ("dbscan_neighbors_kernel", "dbscan_neighbors"),
     ("slab_bias_reduce_kernel", "slab_bias_reduce"),
     ("conv_igemm_kernel<0", "conv_igemm_fwd"), ("conv_igemm_kernel<1", "conv_igemm_dgrad"),
     ("conv_wgrad_kernel", "conv_wgrad_fp32"),

@@ -316,6 +316,8 @@ class Trainer:
         sum(losses.values()).backward()
         self._join_streams()
         losses["zero_gt"] = feats.new_zeros(())
+        if self.distributed and pending["n"] > 0:  # a hook did not fire (no gradient path): reduce the heads now
+            self._allreduce_async(early)
         self._allreduce_async([k for k in self.groups if k not in early])
         if self.distributed:
             for w in self._pending:

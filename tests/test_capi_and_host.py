@@ -244,3 +244,29 @@ def test_model_configs_build_on_cpu():
             frozen = [n for n, p in model["backbone"].named_parameters() if not p.requires_grad]
             assert "body.stem.conv1.weight" in frozen and "body.layer1.2.conv3.weight" in frozen
             assert all(not n.startswith(("body.layer2", "body.layer3", "body.layer4", "fpn.")) for n in frozen)
+
+
+def test_take_images_and_split_levels_autograd():
+    """ops.take_images (sub-batch of a pyramid, used by the paired step) and ops.split_levels: forward equals plain
+    indexing, backward scatters / concatenates the gradients back into the full pyramid."""
+    shape = ops.PyramidShape(4, [(4, 6), (2, 3), (1, 2)])
+    g = torch.Generator().manual_seed(0)
+    rows = torch.randn(shape.rows, 5, generator=g, requires_grad=True)
+    sub, sshape = ops.take_images(rows, shape, 1, 3)
+    assert sshape.n_images == 2 and sshape.sizes == shape.sizes and sub.shape[0] == sshape.rows
+    idx = torch.cat([torch.arange(shape.row_off[l] + 1 * h * w, shape.row_off[l] + 3 * h * w)
+                     for l, (h, w) in enumerate(shape.sizes)])
+    assert torch.equal(sub, rows[idx])
+    wgt = torch.randn(sub.shape, generator=g)
+    (sub * wgt).sum().backward()
+    ref = torch.zeros_like(rows)
+    ref[idx] = wgt
+    assert torch.equal(rows.grad, ref)
+    rows.grad = None
+    parts = ops.split_levels(rows, shape)
+    assert [p.shape[0] for p in parts] == [shape.row_off[l + 1] - shape.row_off[l] for l in range(3)]
+    (parts[0].sum() * 2.0 + parts[2].sum() * 3.0).backward()  # level 1 unused: its gradient is zero
+    exp = torch.zeros_like(rows)
+    exp[:shape.row_off[1]] = 2.0
+    exp[shape.row_off[2]:] = 3.0
+    assert torch.equal(rows.grad, exp)

@@ -133,7 +133,12 @@ class FlatGroup:
     """All trainable parameters of one sub-model in one flat fp32 buffer (weights | biases), with
     matching flat gradient and momentum buffers.  Parameters and .grad become views into them."""
 
-    def __init__(self, module, lr, bias_lr_factor=2.0, wd=1e-4, wd_bias=0.0, momentum=0.9):
+    @staticmethod
+    def numel(module):
+        return sum(p.numel() for p in module.parameters() if p.requires_grad)
+
+    def __init__(self, module, lr, bias_lr_factor=2.0, wd=1e-4, wd_bias=0.0, momentum=0.9, flat_g=None):
+        """flat_g: optional pre-allocated, zeroed gradient storage (a slice of the Trainer's gradient arena)."""
         params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
         wts = [(n, p) for n, p in params if "bias" not in n]
         bss = [(n, p) for n, p in params if "bias" in n]
@@ -141,7 +146,8 @@ class FlatGroup:
         self.n_b = sum(p.numel() for _, p in bss)
         dev = params[0][1].device
         self.flat_p = torch.empty(self.n_w + self.n_b, device=dev)
-        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_g = torch.zeros_like(self.flat_p) if flat_g is None else flat_g
+        assert self.flat_g.numel() == self.flat_p.numel()
         self.flat_m = torch.zeros_like(self.flat_p)
         off = 0
         for _, p in wts + bss:
@@ -182,7 +188,22 @@ class Trainer:
     def __init__(self, model, base_lr=0.0025, con_dis_lambda=0.1, distributed=None):
         self.model = model
         self.con_dis_lambda = con_dis_lambda
-        self.groups = {k: FlatGroup(m, base_lr) for k, m in model.items()}
+        # ONE gradient arena for all sub-models, ordered so that what becomes final together is contiguous: the FCOS
+        # head, the discriminators, then middle head and backbone.  Gradient zeroing is one fill and data parallelism
+        # is one all-reduce per contiguous range (two per iteration) instead of one per sub-model.
+        order = [k for k in model if k == "fcos"] + [k for k in model if k.startswith("dis_")] + \
+            [k for k in model if k != "fcos" and not k.startswith("dis_")]
+        sizes = {k: FlatGroup.numel(model[k]) for k in order}
+        pad = lambda n: (n + 63) // 64 * 64  # keep every sub-model's base 256-byte aligned (float4 kernels)
+        dev0 = next(next(iter(model.values())).parameters()).device
+        self.grad_arena = torch.zeros(sum(pad(n) for n in sizes.values()), device=dev0)
+        self.arena_range, off = {}, 0
+        for k in order:
+            self.arena_range[k] = (off, off + pad(sizes[k]))
+            off += pad(sizes[k])
+        self.groups = {k: FlatGroup(model[k], base_lr,
+                                    flat_g=self.grad_arena[self.arena_range[k][0]:self.arena_range[k][0] + sizes[k]])
+                       for k in order}
         self.iteration = 0
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.comm_stream = torch.cuda.Stream() if self.distributed else None
@@ -211,11 +232,13 @@ class Trainer:
             if self.tgt_stream is not None:
                 self.comm_stream.wait_stream(self.tgt_stream)
         ws = dist.get_world_size()
+        lo = min(self.arena_range[k][0] for k in keys)
+        hi = max(self.arena_range[k][1] for k in keys)
+        assert sum(b - a for a, b in (self.arena_range[k] for k in keys)) == hi - lo, "keys must be contiguous in the arena"
         with torch.cuda.stream(self.comm_stream):
-            for k in keys:
-                g = self.groups[k].flat_g
-                g.div_(ws)
-                self._pending.append(dist.all_reduce(g, async_op=True))
+            g = self.grad_arena[lo:hi]
+            g.div_(ws)
+            self._pending.append(dist.all_reduce(g, async_op=True))
 
     def _discriminators(self, feats, maps, shape, label, domain, tag):
         """con_dis_lambda * dis_CON(feat[l], label, act_maps[l]) for the five levels (reference trainer.py:314-333,
@@ -259,8 +282,7 @@ class Trainer:
         fcos_mod.reset_target_plan()
         for m in model.values():
             m.train()
-        for g in self.groups.values():
-            g.zero_grad()
+        self.grad_arena.zero_()
         B = il_s.tensors.shape[0]
         images = torch.cat([il_s.tensors, il_t.tensors], 0)
         inputs_ready = torch.cuda.Event()
@@ -341,8 +363,7 @@ class Trainer:
         fcos_mod.reset_target_plan()
         for m in model.values():
             m.train()
-        for g in self.groups.values():
-            g.zero_grad()
+        self.grad_arena.zero_()
         out = {}
         # (1) generator on source
         loss_dict, feat_s, maps_s, shape = forward_detector(model, images_s, targets_s, mode="source")

@@ -198,9 +198,12 @@ def test_stream_overlap_is_race_free(device):
             trainer.step(imgs_s, tg, imgs_t)
         torch.cuda.synchronize()
         res.append({k: g.flat_p.clone() for k, g in trainer.groups.items()})
+    # two runs of the SAME schedule already differ by ~7e-7 in the parameters after two iterations (float atomics in
+    # the loss reductions and in torch's index_put backward, amplified through the net; scratch/determinism.py), so the
+    # bar sits above that noise floor and far below what a missed dependency would do (>= 1e-3)
     for k in res[0]:
         a, b = res[0][k], res[1][k]
-        assert torch.allclose(a, b, rtol=1e-4, atol=1e-6), (k, (a - b).abs().max().item())
+        assert torch.allclose(a, b, rtol=1e-4, atol=5e-6), (k, (a - b).abs().max().item())
 
 
 @pytest.mark.parametrize("name,paired", [("step_ragged_160x224", True), ("step_ragged_160x224", False),

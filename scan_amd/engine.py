@@ -149,6 +149,8 @@ class FlatGroup:
         self.flat_g = torch.zeros_like(self.flat_p) if flat_g is None else flat_g
         assert self.flat_g.numel() == self.flat_p.numel()
         self.flat_m = torch.zeros_like(self.flat_p)
+        self._order = wts + bss  # layout of the flat buffers
+        self._named_order = [n for n, _ in params]  # the reference optimizer's parameter order
         off = 0
         for _, p in wts + bss:
             n = p.numel()
@@ -164,6 +166,41 @@ class FlatGroup:
 
     def zero_grad(self):
         self.flat_g.zero_()
+
+    # ---- optimizer state in torch.optim.SGD's state_dict layout, as the reference's make_optimizer builds it
+    # (solver/build.py:7-43: ONE param group per trainable parameter, named_parameters order) -- what
+    # DetectronCheckpointer stores under "optimizer_<sub-model>" (utils/checkpoint.py:201-245)
+    def _logical(self):
+        off = 0
+        for name, p in self._order:
+            n = p.numel()
+            yield name, p, self.flat_m[off:off + n].as_strided(p.shape, p.data.stride())
+            off += n
+
+    def optimizer_state_dict(self):
+        by_name = {name: (p, m) for name, p, m in self._logical()}
+        state, groups = {}, []
+        for i, name in enumerate(self._named_order):
+            p, m = by_name[name]
+            bias = "bias" in name
+            if not self.first:
+                state[i] = {"momentum_buffer": m.detach().clone().contiguous().cpu()}
+            groups.append({"lr": self.lr * (self.bias_lr_factor if bias else 1.0),
+                           "weight_decay": self.wd_bias if bias else self.wd, "momentum": self.momentum, "dampening": 0,
+                           "nesterov": False, "params": [i]})
+        return {"state": state, "param_groups": groups}
+
+    def load_optimizer_state_dict(self, sd):
+        by_name = {name: m for name, p, m in self._logical()}
+        if len(sd["param_groups"]) != len(self._named_order):
+            raise ValueError("optimizer state has %d parameter groups, the sub-model has %d trainable parameters"
+                             % (len(sd["param_groups"]), len(self._named_order)))
+        self.flat_m.zero_()
+        for i, name in enumerate(self._named_order):
+            st = sd["state"].get(i, sd["state"].get(str(i)))
+            if st is not None and st.get("momentum_buffer") is not None:
+                by_name[name].copy_(st["momentum_buffer"].to(self.flat_m.device))
+        self.first = len(sd["state"]) == 0
 
     def step(self, lr_factor=1.0):
         lr = self.lr * lr_factor
@@ -269,6 +306,29 @@ class Trainer:
             main.wait_stream(s)
         if self.tgt_stream is not None:
             main.wait_stream(self.tgt_stream)
+
+    def save_checkpoint(self, save_dir, name):
+        """reference DetectronCheckpointer.save (utils/checkpoint.py:141-301): the model state_dicts plus
+        optimizer_<sub-model> (torch.optim.SGD layout) and the iteration, so training resumes where it stopped."""
+        from . import checkpoint
+        extra = {"optimizer_" + k: g.optimizer_state_dict() for k, g in self.groups.items()}
+        mh = self.model["middle_head"]
+        return checkpoint.save(self.model, save_dir, name, iteration=self.iteration,
+                               proto_counter=mh.counter_rnn.counter, **extra)
+
+    def load_checkpoint(self, path, load_dis=True):
+        from . import checkpoint
+        rest = checkpoint.load(self.model, path, load_dis=load_dis)
+        # load_state_dict copies into the parameters in place, so they stay views of the flat buffers
+        for k, g in self.groups.items():
+            sd = rest.pop("optimizer_" + k, None)
+            if sd is not None and (load_dis or not k.startswith("dis_")):
+                g.load_optimizer_state_dict(sd)
+        self.iteration = int(rest.pop("iteration", self.iteration))
+        pc = rest.pop("proto_counter", None)
+        if pc is not None:
+            self.model["middle_head"].counter_rnn.counter = pc
+        return rest
 
     def step_paired(self, il_s, targets_s, il_t, forward_target=False):
         """The DA iteration with the source and the target frames in one pyramid (frames [0, B) source, [B, 2B)

@@ -270,3 +270,28 @@ def test_take_images_and_split_levels_autograd():
     exp[:shape.row_off[1]] = 2.0
     exp[shape.row_off[2]:] = 3.0
     assert torch.equal(rows.grad, exp)
+
+
+def test_optimizer_state_round_trip():
+    """FlatGroup.optimizer_state_dict: torch.optim.SGD layout with one group per trainable parameter in
+    named_parameters order (reference solver/build.py:7-43), momentum buffers in the parameters' logical shapes."""
+    model = engine.build_model(9, device="cpu")
+    g = engine.FlatGroup(model["fcos"], 0.0025)
+    assert g.optimizer_state_dict()["state"] == {}  # no step taken yet
+    g.flat_m.copy_(torch.arange(g.flat_m.numel(), dtype=torch.float32))
+    g.first = False
+    sd = g.optimizer_state_dict()
+    names = [n for n, p in model["fcos"].named_parameters() if p.requires_grad]
+    assert len(sd["param_groups"]) == len(names) == len(sd["state"])
+    for i, n in enumerate(names):
+        p = dict(model["fcos"].named_parameters())[n]
+        grp = sd["param_groups"][i]
+        assert grp["params"] == [i] and grp["momentum"] == 0.9
+        assert grp["lr"] == (0.005 if "bias" in n else 0.0025) and grp["weight_decay"] == (0.0 if "bias" in n else 1e-4)
+        assert sd["state"][i]["momentum_buffer"].shape == p.shape
+    model2 = engine.build_model(9, device="cpu")
+    g2 = engine.FlatGroup(model2["fcos"], 0.0025)
+    g2.load_optimizer_state_dict(sd)
+    assert torch.equal(g2.flat_m, g.flat_m) and g2.first is False
+    with pytest.raises(ValueError):
+        engine.FlatGroup(model2["middle_head"], 0.0025).load_optimizer_state_dict(sd)

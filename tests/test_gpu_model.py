@@ -359,3 +359,43 @@ def test_step_resnet50_matches_reference(device, gold_dir):
             ref = gold["grad_digest"]["backbone"][name_]
             mine = _digest(named[name_].grad)
             assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mode, name_, mine[1], ref[1])
+
+
+def test_checkpoint_resume_continues_training(device, tmp_path):
+    """Trainer.save_checkpoint / load_checkpoint (DetectronCheckpointer wire format + optimizer_<sub-model> in
+    torch.optim.SGD layout): 2 iterations + save + restore into a fresh model + 1 iteration == 3 iterations."""
+    from scan_amd import engine, synth
+    H, W, B = 128, 256, 1
+    batches = [(synth.synth_images(B, H, W, 40 + i).to(device), synth.synth_targets(B, H, W, 8, 6, 50 + i),
+                synth.synth_images(B, H, W, 60 + i).to(device)) for i in range(3)]
+
+    def fresh():
+        model = engine.build_model(9, device=device, attn_dropout=0.0)
+        engine.load_procedural_weights(model)
+        return model, engine.Trainer(model)
+
+    model_a, tr_a = fresh()
+    for s, tg, t in batches:
+        tr_a.step(s, tg, t)
+    model_b, tr_b = fresh()
+    for s, tg, t in batches[:2]:
+        tr_b.step(s, tg, t)
+    path = tr_b.save_checkpoint(str(tmp_path), "model_0000002")
+    raw = torch.load(path)
+    assert raw["iteration"] == 2 and "optimizer_backbone" in raw and "optimizer_dis_P3_CON" in raw
+    sd = raw["optimizer_fcos"]
+    n_train = sum(1 for p in model_b["fcos"].parameters() if p.requires_grad)
+    assert len(sd["param_groups"]) == n_train and len(sd["state"]) == n_train  # one group per parameter, like the reference
+    # a stock torch SGD built the reference's way (one group per parameter, solver/build.py:41) accepts it
+    torch.optim.SGD([{"params": [torch.nn.Parameter(torch.zeros_like(p.detach().cpu()))]}
+                     for p in model_b["fcos"].parameters() if p.requires_grad], lr=0.1, momentum=0.9).load_state_dict(sd)
+    model_c, tr_c = fresh()
+    rest = tr_c.load_checkpoint(path)
+    assert tr_c.iteration == 2 and not rest
+    tr_c.step(*batches[2])
+    torch.cuda.synchronize()
+    for k in tr_a.groups:
+        a, c = tr_a.groups[k].flat_p, tr_c.groups[k].flat_p
+        assert torch.allclose(a, c, rtol=1e-4, atol=5e-6), (k, (a - c).abs().max().item())
+        assert torch.allclose(tr_a.groups[k].flat_m, tr_c.groups[k].flat_m, rtol=1e-3, atol=1e-5), k
+    assert torch.allclose(model_a["middle_head"].prototype, model_c["middle_head"].prototype, rtol=1e-4, atol=1e-5)

@@ -63,7 +63,7 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
 // a stride-2 conv, source pyramid sd is the finer one), 2 source = output / 2 where both coordinates are even, zero
 // elsewhere (its data gradient: sd is the coarser dY pyramid).
 template <int BN, int TH, int NT, int KS = 3>
-__global__ __launch_bounds__(NT, NT > 512 ? 1 : 2) void conv3x3_bf16x3_kernel(
+__global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
     const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
     float* __restrict__ dst, int Nout, int Ns, int relu, TileTab tt, int n_tiles, scan_pyramid_t sd, int map,
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : 2) void conv3x3_bf16x3_kernel(
   constexpr int TM = (TH * TW / 32) / WM_WAVES;   // 32-pixel MFMA tiles per wave
   constexpr int TN = 2;                           // 32-channel MFMA tiles per wave
   constexpr int ASLOTS = (NPATCH * 8 + NT - 1) / NT;  // float4 of the halo patch per thread per chunk
-  constexpr int BSEG = (BN * 4 * 2 + NT - 1) / NT;  // 16-byte weight segments per thread per (chunk, tap)
+  constexpr int BSEG = BN * 4 * 2 / NT;           // 16-byte weight segments per thread per (chunk, tap)
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __bf16* Ah = reinterpret_cast<__bf16*>(smem_raw);  // [PH][PPITCH]
@@ -157,9 +157,8 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : 2) void conv3x3_bf16x3_kernel(
       const int row = rem >> 2, seg = rem & 3;
       const int o = n0 + row, c = cc * CK + 8 * seg;
       const __bf16* base = plane ? wl : wh;
-      rb[i] = (slot < BN * 8 && o < Nout && c < Csw)
-                  ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * NTAPS + tap) * Csw + c)
-                  : make_uint4(0u, 0u, 0u, 0u);
+      rb[i] = (o < Nout && c < Csw) ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * NTAPS + tap) * Csw + c)
+                                    : make_uint4(0u, 0u, 0u, 0u);
     }
   };
   auto store_b = [&](int buf) {
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(NT, NT > 512 ? 1 : 2) void conv3x3_bf16x3_kernel(
       const int plane = slot / (BN * 4);
       const int rem = slot - plane * BN * 4;
       const int row = rem >> 2, seg = rem & 3;
-      if (slot < BN * 8) *reinterpret_cast<uint4*>(Bs + ((buf * 2 + plane) * BN + row) * LROW + 8 * seg) = rb[i];
+      *reinterpret_cast<uint4*>(Bs + ((buf * 2 + plane) * BN + row) * LROW + 8 * seg) = rb[i];
     }
   };
 
@@ -376,29 +375,7 @@ static int conv3x3_bf16x3_launch(const float* x, const scan_pyramid_t* d, int32_
   hipStream_t st = as_stream(stream);
   const __bf16* h = reinterpret_cast<const __bf16*>(wh);
   const __bf16* l = reinterpret_cast<const __bf16*>(wl);
-  // single-level launches whose height is (nearly) a multiple of 24 -- conv2_x / conv3_x at 1024x2048: H = 512 / 256
-  // -> 3 % of partial-tile rows -- take 24 x 16 pixel tiles with 768 threads: 12 waves = THREE per SIMD instead of
-  // two (166 VGPRs), +6 % on those layers (conv3_x 1575 -> 1489 us).  Where H is far from a multiple of 24 the partial
-  // tiles eat the gain (conv4_x -2 %, pyramid towers -33 %), so everything else keeps the 16-row tile.
-  bool th24 = Nout > 64 && d->n_levels == 1;
-  if (th24) {
-    const int h = d->h[0];
-    th24 = ((h + 23) / 24 * 24) * 100 <= h * 104;
-  }
-  if (th24) {
-    make_tiles(d, &tt, 24);
-    const int tiles = tt.tile_off[d->n_levels];
-    const int n_tiles = (Nout + 127) / 128;
-    const size_t sh = (size_t)(2 * 26 * PPITCH + 4 * 128 * LROW) * sizeof(__bf16);
-    static bool done3 = false;
-    if (!done3) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16x3_kernel<128, 24, 768>),
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      done3 = true;
-    }
-    hipLaunchKernelGGL((conv3x3_bf16x3_kernel<128, 24, 768>), dim3(tiles * n_tiles), dim3(768), sh, st, x, *d, Cs, h, l,
-                       Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *d, 0, gn_ws);
-  } else if (Nout > 64) {
+  if (Nout > 64) {
     // 16 x 16 pixel tiles, 512 threads (8 waves = 4 x 2 of 64 px x 64 ch): one weight tile feeds 256 pixels.
     // (A/B on one device, tower layer: 8x16/256 thr x2 per CU 305 TF, this 332 TF, a 3-deep software-pipelined
     //  variant of it 330 TF -- not kept.)

@@ -231,8 +231,6 @@ CONV_CASES = [
     ([(8, 16)], 2, 256, 5, 3, 1, False),     # bbox_pred + centerness fused
     ([(8, 16)], 1, 264, 1024, 3, 1, True),   # stacked CKA class branches
     ([(6, 10)], 2, 128, 40, 3, 1, False),    # Cout tail inside a 128-wide tile
-    ([(48, 40)], 2, 128, 256, 3, 1, True),   # H = 2 x 24: the 24-row / 768-thread instance (three waves per SIMD)
-    ([(47, 19)], 1, 256, 128, 3, 1, False),  # same instance (47 -> 48 rows: 2 % partial), ragged width
     ([(32, 48)], 2, 3, 64, 7, 2, True),      # ResNet stem 7x7 / stride 2 (+ folded FrozenBN + ReLU)
     ([(12, 20)], 2, 256, 128, 1, 2, True),   # bottleneck conv1 with the stride in the 1x1 (layer2.0.conv1)
     ([(11, 15)], 1, 256, 512, 1, 2, False),  # downsample 1x1 / stride 2, odd size

@@ -552,22 +552,46 @@ def da_iteration(P, state, images_s, targets_s, images_t, con_lambda=0.1, K=9, s
     return out
 
 
-def sgd_step(P, bufs, lr=0.0025, momentum=0.9, wd=1e-4, warmup=1.0 / 3):
-    """solver/build.py:7-43 + lr_scheduler.py:39-52 (constant warm-up factor 1/3
-    for the first 1000 iterations): weights lr, wd; biases 2*lr, wd 0."""
+def lr_factor(iteration, warmup_iters=1000, factor=1.0 / 3, steps=(60000, 80000), gamma=0.1, method="constant"):
+    """WarmupMultiStepLR.get_lr / base_lr with last_epoch = iteration (solver/lr_scheduler.py:39-52)."""
+    from bisect import bisect_right
+    f = 1.0
+    if iteration < warmup_iters:
+        if method == "constant":
+            f = factor
+        else:
+            alpha = float(iteration) / warmup_iters
+            f = factor * (1 - alpha) + alpha
+    return f * gamma ** bisect_right(list(steps), iteration)
+
+
+def sgd_step(P, bufs, lr=0.0025, momentum=0.9, wd=1e-4, warmup=1.0 / 3, solver=None, iteration=0):
+    """solver/build.py:7-43 + lr_scheduler.py:39-52: torch.optim.SGD(momentum, dampening 0) with one group per
+    parameter -- weights lr / wd, biases lr * BIAS_LR_FACTOR / WEIGHT_DECAY_BIAS; parameters without a gradient are
+    skipped (no decay, no buffer).  Default: the C2F yaml inside its constant warm-up (factor 1/3 for 1000
+    iterations).  solver = {sub-model or 'dis': dict(lr, bias_lr_factor, wd, wd_bias, momentum, steps, gamma,
+    warmup_iters, warmup_factor, warmup_method)} + iteration selects per-sub-model schedules."""
     with torch.no_grad():
         for mname, pd in P.items():
+            if solver is not None:
+                sv = solver["dis" if mname.startswith("dis_") else mname]
+                f = lr_factor(iteration, sv["warmup_iters"], sv["warmup_factor"], sv["steps"], sv["gamma"],
+                              sv["warmup_method"])
+                lr_w, lr_b, wd_w, wd_b, mom = sv["lr"] * f, sv["lr"] * sv["bias_lr_factor"] * f, sv["wd"], sv["wd_bias"], \
+                    sv["momentum"]
+            else:
+                lr_w, lr_b, wd_w, wd_b, mom = lr * warmup, 2 * lr * warmup, wd, 0.0, momentum
             for k, v in pd.items():
                 if v.grad is None:
                     continue
                 is_bias = "bias" in k
-                g = v.grad + (0.0 if is_bias else wd) * v
+                g = v.grad + (wd_b if is_bias else wd_w) * v
                 key = mname + "/" + k
                 if key not in bufs:
                     bufs[key] = g.clone()
                 else:
-                    bufs[key].mul_(momentum).add_(g)
-                v.add_(bufs[key], alpha=-(lr * (2 if is_bias else 1) * warmup))
+                    bufs[key].mul_(mom).add_(g)
+                v.add_(bufs[key], alpha=-(lr_b if is_bias else lr_w))
                 v.grad = None
 
 

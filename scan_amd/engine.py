@@ -15,7 +15,7 @@ HIP stream as soon as that sub-model's last backward contribution is final.
 import torch
 import torch.distributed as dist
 
-from . import ops, synth
+from . import config, ops, synth
 from .structures import ImageList, to_image_list  # noqa: F401
 from .modeling.backbone import build_backbone
 from .modeling.condgraph import build_condgraph
@@ -28,20 +28,21 @@ LEVELS = ("P3", "P4", "P5", "P6", "P7")
 DIS_ORDER = ("P7", "P6", "P5", "P4", "P3")  # order the reference builds / iterates them
 
 
-# the shipped yamls (reference configs/scan/*.yaml): what differs between them on this path
-CONFIGS = {
-    "c2f": dict(num_classes=9, test_mode="precision", transfer_cfg=("NODES", "ADJ")),  # Cityscapes -> Foggy
-    "s2c": dict(num_classes=2, test_mode="common", transfer_cfg=(None,)),  # Sim10k -> Cityscapes
-    "k2c": dict(num_classes=2, test_mode="common", transfer_cfg=(None,)),  # KITTI -> Cityscapes
-    # BASELINE.json configs[3]: the K2C yaml with MODEL.BACKBONE.CONV_BODY R-50-FPN-RETINANET and
-    # MODEL.RESNETS.BACKBONE_OUT_CHANNELS 256 (the reference's own ResNet yamls, configs/epm/*R_101*, set these)
-    "k2c_r50": dict(num_classes=2, test_mode="common", transfer_cfg=(None,), conv_body="R-50-FPN-RETINANET"),
-}
+# the shipped experiment definitions (scan_amd/configs/*.yaml, parsed by scan_amd/config.py: same keys as the
+# reference's configs/scan/*.yaml) as the flat settings dict build_model / Trainer consume.  "k2c_r50" = BASELINE.json
+# configs[3]: the K2C yaml with MODEL.BACKBONE.CONV_BODY R-50-FPN-RETINANET.
+CONFIGS = {name: config.settings(config.load(name)) for name in ("c2f", "s2c", "k2c", "k2c_r50")}
 
 
 def build_model(num_classes=9, test_mode="precision", device="cuda", attn_dropout=0.1, transfer_cfg=("NODES", "ADJ"),
-                conv_body="VGG-16-FPN-RETINANET"):
-    """dict MODEL{backbone, middle_head, fcos, dis_P*_CON} like tools/train_net_da.py:43-48,223-274."""
+                conv_body="VGG-16-FPN-RETINANET", settings=None):
+    """dict MODEL{backbone, middle_head, fcos, dis_P*_CON} like tools/train_net_da.py:43-48,223-274.
+    settings: a config.settings(cfg) dict (e.g. engine.CONFIGS["s2c"]); it overrides the four model keywords."""
+    s = dict(CONFIGS["c2f"])
+    s.update(num_classes=num_classes, test_mode=test_mode, transfer_cfg=tuple(transfer_cfg), conv_body=conv_body)
+    if settings is not None:
+        s.update(settings)
+    conv_body = s["conv_body"]
     if conv_body == "VGG-16-FPN-RETINANET":
         backbone = build_backbone()
     elif conv_body in ("R-50-FPN-RETINANET", "R-101-FPN-RETINANET"):
@@ -50,13 +51,14 @@ def build_model(num_classes=9, test_mode="precision", device="cuda", attn_dropou
         raise ValueError("conv_body %r is not built" % conv_body)
     model = {
         "backbone": backbone,
-        "middle_head": build_condgraph(None, 256, num_classes, transfer_cfg),
-        "fcos": build_fcos(None, num_classes, test_mode),
+        "middle_head": build_condgraph(s, 256, s["num_classes"], s["transfer_cfg"]),
+        "fcos": build_fcos(s, s["num_classes"], s["test_mode"]),
     }
     model["middle_head"].multihead_attn.dropout.p = attn_dropout
     model["middle_head"].multihead_attn.attn_dropout.p = attn_dropout
     for lvl in DIS_ORDER:
-        model["dis_%s_CON" % lvl] = FCOSDiscriminator_con(num_convs=4, num_classes=num_classes, grad_reverse_lambda=0.02)
+        model["dis_%s_CON" % lvl] = FCOSDiscriminator_con(num_convs=s["dis_num_convs"][lvl], num_classes=s["num_classes"],
+                                                          grad_reverse_lambda=s["grl_weight"][lvl])
     for m in model.values():
         m.to(device)
         for p in m.parameters():
@@ -66,6 +68,7 @@ def build_model(num_classes=9, test_mode="precision", device="cuda", attn_dropou
 
 
 def load_state_dicts(model, sds):
+    ops.invalidate_weight_planes()  # in-place copies keep data_ptr: cached bf16 planes of the old values must go
     for k, m in model.items():
         missing, unexpected = m.load_state_dict(sds[k], strict=False)
         if missing or unexpected:
@@ -134,17 +137,26 @@ class FlatGroup:
     matching flat gradient and momentum buffers.  Parameters and .grad become views into them."""
 
     @staticmethod
-    def numel(module):
-        return sum(p.numel() for p in module.parameters() if p.requires_grad)
+    def numel(module, skip=()):
+        return sum(p.numel() for n, p in module.named_parameters() if p.requires_grad and not n.startswith(tuple(skip)))
 
-    def __init__(self, module, lr, bias_lr_factor=2.0, wd=1e-4, wd_bias=0.0, momentum=0.9, flat_g=None):
-        """flat_g: optional pre-allocated, zeroed gradient storage (a slice of the Trainer's gradient arena)."""
+    def __init__(self, module, lr, bias_lr_factor=2.0, wd=1e-4, wd_bias=0.0, momentum=0.9, flat_g=None, skip=()):
+        """flat_g: optional pre-allocated, zeroed gradient storage (a slice of the Trainer's gradient arena).
+        skip: name prefixes of trainable parameters that never receive a gradient on this path (middle head:
+        cond_2.*, unused in RNN mode, reference condgraph.py:237 vs 315-319).  torch.optim.SGD skips parameters whose
+        .grad is None -- no weight decay, no momentum buffer -- so they stay out of the flat buffers and are never
+        touched; they still appear (stateless) in optimizer_state_dict like in the reference's checkpoint."""
         params = [(n, p) for n, p in module.named_parameters() if p.requires_grad]
-        wts = [(n, p) for n, p in params if "bias" not in n]
-        bss = [(n, p) for n, p in params if "bias" in n]
+        self.skipped = [n for n, _ in params if n.startswith(tuple(skip))] if skip else []
+        live = [(n, p) for n, p in params if n not in self.skipped]
+        wts = [(n, p) for n, p in live if "bias" not in n]
+        bss = [(n, p) for n, p in live if "bias" in n]
         self.n_w = sum(p.numel() for _, p in wts)
         self.n_b = sum(p.numel() for _, p in bss)
         dev = params[0][1].device
+        for n, p in params:
+            if n in self.skipped:
+                p.grad = None
         self.flat_p = torch.empty(self.n_w + self.n_b, device=dev)
         self.flat_g = torch.zeros_like(self.flat_p) if flat_g is None else flat_g
         assert self.flat_g.numel() == self.flat_p.numel()
@@ -181,9 +193,9 @@ class FlatGroup:
         by_name = {name: (p, m) for name, p, m in self._logical()}
         state, groups = {}, []
         for i, name in enumerate(self._named_order):
-            p, m = by_name[name]
+            m = by_name[name][1] if name in by_name else None
             bias = "bias" in name
-            if not self.first:
+            if not self.first and m is not None:
                 state[i] = {"momentum_buffer": m.detach().clone().contiguous().cpu()}
             groups.append({"lr": self.lr * (self.bias_lr_factor if bias else 1.0),
                            "weight_decay": self.wd_bias if bias else self.wd, "momentum": self.momentum, "dampening": 0,
@@ -198,6 +210,8 @@ class FlatGroup:
         self.flat_m.zero_()
         for i, name in enumerate(self._named_order):
             st = sd["state"].get(i, sd["state"].get(str(i)))
+            if name not in by_name:
+                continue
             if st is not None and st.get("momentum_buffer") is not None:
                 by_name[name].copy_(st["momentum_buffer"].to(self.flat_m.device))
         self.first = len(sd["state"]) == 0
@@ -212,25 +226,43 @@ class FlatGroup:
         self.first = False
 
 
-def warmup_factor(iteration, warmup_iters=1000, factor=1.0 / 3, steps=(60000, 80000), gamma=0.1):
-    """WarmupMultiStepLR.get_lr, 'constant' warm-up (reference solver/lr_scheduler.py:39-52)."""
-    f = factor if iteration < warmup_iters else 1.0
+def warmup_factor(iteration, warmup_iters=1000, factor=1.0 / 3, steps=(60000, 80000), gamma=0.1, method="constant"):
+    """WarmupMultiStepLR.get_lr / base_lr at scheduler step ``iteration`` (reference solver/lr_scheduler.py:39-52;
+    the scheduler is stepped after the optimizer, engine/trainer.py:418-424, so iteration i of the loop runs with
+    last_epoch = i).  gamma ** bisect_right(steps, i) == gamma ** #{s <= i}."""
+    if method not in ("constant", "linear"):
+        raise ValueError("Only 'constant' or 'linear' warmup_method accepted, got %r" % (method,))
+    f = 1.0
+    if iteration < warmup_iters:
+        if method == "constant":
+            f = factor
+        else:
+            alpha = float(iteration) / warmup_iters
+            f = factor * (1 - alpha) + alpha
     return f * gamma ** sum(1 for s in steps if s <= iteration)
+
+
+# trainable parameters of a sub-model that get no gradient on this path (see FlatGroup: skip)
+NO_GRAD_PARAMS = {"middle_head": ("cond_2.",)}
 
 
 class Trainer:
     """One process per GPU.  world_size > 1: per-rank shard of the batch, local graph / normalisers,
     gradients averaged by one all-reduce per sub-model flat buffer."""
 
-    def __init__(self, model, base_lr=0.0025, con_dis_lambda=0.1, distributed=None):
+    def __init__(self, model, base_lr=None, con_dis_lambda=None, distributed=None, settings=None):
+        """settings: a config.settings(cfg) dict (engine.CONFIGS[name]) -- per-sub-model SGD / WarmupMultiStepLR
+        settings (SOLVER.{BACKBONE,FCOS,MIDDLE_HEAD,DIS}.*, reference solver/build.py:7-84) and CON_DIS_LAMBDA;
+        default: the C2F yaml.  base_lr / con_dis_lambda override it."""
         self.model = model
-        self.con_dis_lambda = con_dis_lambda
+        self.settings = settings = dict(settings or CONFIGS["c2f"])
+        self.con_dis_lambda = settings["con_dis_lambda"] if con_dis_lambda is None else con_dis_lambda
         # ONE gradient arena for all sub-models, ordered so that what becomes final together is contiguous: the FCOS
         # head, the discriminators, then middle head and backbone.  Gradient zeroing is one fill and data parallelism
         # is one all-reduce per contiguous range (two per iteration) instead of one per sub-model.
         order = [k for k in model if k == "fcos"] + [k for k in model if k.startswith("dis_")] + \
             [k for k in model if k != "fcos" and not k.startswith("dis_")]
-        sizes = {k: FlatGroup.numel(model[k]) for k in order}
+        sizes = {k: FlatGroup.numel(model[k], NO_GRAD_PARAMS.get(k, ())) for k in order}
         pad = lambda n: (n + 63) // 64 * 64  # keep every sub-model's base 256-byte aligned (float4 kernels)
         dev0 = next(next(iter(model.values())).parameters()).device
         self.grad_arena = torch.zeros(sum(pad(n) for n in sizes.values()), device=dev0)
@@ -238,9 +270,14 @@ class Trainer:
         for k in order:
             self.arena_range[k] = (off, off + pad(sizes[k]))
             off += pad(sizes[k])
-        self.groups = {k: FlatGroup(model[k], base_lr,
-                                    flat_g=self.grad_arena[self.arena_range[k][0]:self.arena_range[k][0] + sizes[k]])
-                       for k in order}
+        self.groups, self.sched = {}, {}
+        for k in order:
+            sv = settings["solver"]["dis" if k.startswith("dis_") else k]
+            self.groups[k] = FlatGroup(model[k], sv["lr"] if base_lr is None else base_lr, sv["bias_lr_factor"], sv["wd"],
+                                       sv["wd_bias"], sv["momentum"], skip=NO_GRAD_PARAMS.get(k, ()),
+                                       flat_g=self.grad_arena[self.arena_range[k][0]:self.arena_range[k][0] + sizes[k]])
+            self.sched[k] = dict(warmup_iters=sv["warmup_iters"], factor=sv["warmup_factor"], steps=sv["steps"],
+                                 gamma=sv["gamma"], method=sv["warmup_method"])
         self.iteration = 0
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.comm_stream = torch.cuda.Stream() if self.distributed else None
@@ -307,6 +344,20 @@ class Trainer:
         if self.tgt_stream is not None:
             main.wait_stream(self.tgt_stream)
 
+    def _optimizer_step(self):
+        """optimizer.step() + scheduler.step() of every sub-model (reference engine/trainer.py:418-424)."""
+        for k, g in self.groups.items():
+            g.step(warmup_factor(self.iteration, **self.sched[k]))
+        self.iteration += 1
+        # parameters changed in place (same data_ptr): the cached bf16 hi/lo weight planes are stale from here on,
+        # whoever runs next -- the next step, an in-loop validation or inference()
+        ops.invalidate_weight_planes()
+
+    def lr_of(self, sub_model, bias=False):
+        """learning rate the NEXT step applies (what scheduler.get_last_lr() reports in the reference)."""
+        g = self.groups[sub_model]
+        return g.lr * (g.bias_lr_factor if bias else 1.0) * warmup_factor(self.iteration, **self.sched[sub_model])
+
     def save_checkpoint(self, save_dir, name):
         """reference DetectronCheckpointer.save (utils/checkpoint.py:141-301): the model state_dicts plus
         optimizer_<sub-model> (torch.optim.SGD layout) and the iteration, so training resumes where it stopped."""
@@ -316,18 +367,37 @@ class Trainer:
         return checkpoint.save(self.model, save_dir, name, iteration=self.iteration,
                                proto_counter=mh.counter_rnn.counter, **extra)
 
-    def load_checkpoint(self, path, load_dis=True):
+    def load_checkpoint(self, path, load_dis=True, load_opt_sch=True):
+        """reference DetectronCheckpointer.load(f, load_dis, load_opt_sch) (utils/checkpoint.py:303-415).  A file written
+        by the reference holds the model state_dicts plus ``optimizer_dis_P*_CON`` / ``scheduler_dis_P*_CON`` only
+        (save() writes no optimizer for backbone / fcos / middle head and drops its keyword arguments, :201-295); files
+        written by save_checkpoint here add ``optimizer_<sub-model>`` for every sub-model, ``iteration`` and the
+        paradigm counter.  Optimizer entries found are loaded; without an ``iteration`` entry the schedulers'
+        ``last_epoch`` (= optimizer steps taken) restores it.  load_opt_sch=False: weights only, like the reference's
+        own call (tools/train_net_da.py:552).  Returns the entries not consumed."""
         from . import checkpoint
+        ops.invalidate_weight_planes()
         rest = checkpoint.load(self.model, path, load_dis=load_dis)
         # load_state_dict copies into the parameters in place, so they stay views of the flat buffers
+        sched_epochs = []
         for k, g in self.groups.items():
             sd = rest.pop("optimizer_" + k, None)
-            if sd is not None and (load_dis or not k.startswith("dis_")):
+            sc = rest.pop("scheduler_" + k, None)
+            if not load_opt_sch or (k.startswith("dis_") and not load_dis):
+                continue
+            if sd is not None:
                 g.load_optimizer_state_dict(sd)
-        self.iteration = int(rest.pop("iteration", self.iteration))
+            if sc is not None and "last_epoch" in sc:
+                sched_epochs.append(int(sc["last_epoch"]))
+        it = rest.pop("iteration", None)
         pc = rest.pop("proto_counter", None)
-        if pc is not None:
-            self.model["middle_head"].counter_rnn.counter = pc
+        if load_opt_sch:
+            if it is not None:
+                self.iteration = int(it)
+            elif sched_epochs:
+                self.iteration = max(sched_epochs)
+            if pc is not None:
+                self.model["middle_head"].counter_rnn.counter = pc
         return rest
 
     def step_paired(self, il_s, targets_s, il_t, forward_target=False):
@@ -338,7 +408,7 @@ class Trainer:
         loss (label 0) on the two halves of a level.  The reference's three backward calls (trainer.py:299,343,377)
         accumulate into the same .grad, so ONE backward of the summed losses leaves identical gradients."""
         model, lam = self.model, self.con_dis_lambda
-        ops.SPLIT_EPOCH = (id(self), self.iteration)
+        ops.begin_weight_epoch()
         fcos_mod.reset_target_plan()
         for m in model.values():
             m.train()
@@ -380,7 +450,7 @@ class Trainer:
             main.wait_stream(side)
         if fstream is not None:
             main.wait_stream(fstream)
-        early = [k for k in self.groups if k.startswith("dis_") or k == "fcos"]
+        dis_keys = [k for k in self.groups if k.startswith("dis_")]
         if self.distributed:
             # the backward reaches `feats` (and `maps`) only after every consumer -- the five discriminators and the
             # FCOS head -- has back-propagated: their gradient buffers (114 of the 199 MB) are final then and are
@@ -390,7 +460,8 @@ class Trainer:
             def _heads_done(grad):
                 pending["n"] -= 1
                 if pending["n"] == 0:
-                    self._allreduce_async(early, after_side_streams=True)
+                    self._allreduce_async(["fcos"], after_side_streams=True)
+                    self._allreduce_async(dis_keys)
                 return grad
 
             feats.register_hook(_heads_done)
@@ -399,17 +470,15 @@ class Trainer:
         self._join_streams()
         losses["zero_gt"] = feats.new_zeros(())
         if self.distributed and pending["n"] > 0:  # a hook did not fire (no gradient path): reduce the heads now
-            self._allreduce_async(early)
-        self._allreduce_async([k for k in self.groups if k not in early])
+            self._allreduce_async(["fcos"])
+            self._allreduce_async(dis_keys)
+        self._allreduce_async([k for k in self.groups if k != "fcos" and k not in dis_keys])
         if self.distributed:
             for w in self._pending:
                 w.wait()
             self._pending = []
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        fac = warmup_factor(self.iteration)
-        for g in self.groups.values():
-            g.step(fac)
-        self.iteration += 1
+        self._optimizer_step()
         return losses
 
     def step(self, images_s, targets_s, images_t, forward_target=False):
@@ -419,7 +488,7 @@ class Trainer:
             if il_s.tensors.shape == il_t.tensors.shape:
                 return self.step_paired(il_s, targets_s, il_t, forward_target)
         model, lam = self.model, self.con_dis_lambda
-        ops.SPLIT_EPOCH = (id(self), self.iteration)  # parameters change once per iteration: reuse their bf16 planes
+        ops.begin_weight_epoch()  # parameters change once per iteration: reuse their bf16 planes within it
         fcos_mod.reset_target_plan()
         for m in model.values():
             m.train()
@@ -463,16 +532,16 @@ class Trainer:
         sum(v for k, v in ld.items() if k != "zero_gt").backward()
         self._join_streams()
         out.update(ld)
-        self._allreduce_async([k for k in self.groups if k != "fcos"])
+        # same three ranges in the same order as step_paired ([fcos], [discriminators], [middle head + backbone]): ranks
+        # holding differently shaped batches may take different schedules without mismatching a collective
+        self._allreduce_async([k for k in self.groups if k.startswith("dis_")])
+        self._allreduce_async([k for k in self.groups if k != "fcos" and not k.startswith("dis_")])
         if self.distributed:
             for w in self._pending:
                 w.wait()
             self._pending = []
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-        f = warmup_factor(self.iteration)
-        for g in self.groups.values():
-            g.step(f)
-        self.iteration += 1
+        self._optimizer_step()
         return out
 
 
@@ -481,4 +550,5 @@ def inference(model, images):
     """reference engine/inference.py:15-37 on one batch: list of (boxes, scores, labels) per image."""
     for m in model.values():
         m.eval()
+    ops.invalidate_weight_planes()  # weights may have been updated / loaded since the planes were cached
     return forward_detector(model, images, None)

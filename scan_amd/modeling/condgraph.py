@@ -321,6 +321,16 @@ class GRAPHModule(nn.Module):
 
 
 def build_condgraph(cfg=None, in_channels=256, num_classes=9, transfer_cfg=("NODES", "ADJ")):
-    """transfer_cfg = MODEL.MIDDLE_HEAD.TRANSFER_CFG: ('NODES', 'ADJ') in the C2F yaml, the default (None,)
-    (reference config/defaults.py:694) in the Sim10k / KITTI yamls."""
-    return GRAPHModule(in_channels, num_classes, transfer_cfg=transfer_cfg)
+    """reference rpn/rpn.py:215 build_middle_head(cfg, in_channels).  cfg: a config.settings dict (MODEL.MIDDLE_HEAD.*
+    and MODEL.FCOS.NUM_CLASSES as the reference's GRAPHModule.__init__ reads them, condgraph.py:127-253) or None for
+    the keyword arguments.  transfer_cfg = MODEL.MIDDLE_HEAD.TRANSFER_CFG: ('NODES', 'ADJ') in the C2F yaml, the
+    default (None,) (reference config/defaults.py:694) in the Sim10k / KITTI yamls."""
+    if cfg is None:
+        return GRAPHModule(in_channels, num_classes, transfer_cfg=transfer_cfg)
+    if cfg["num_convs_in"] != 2 or cfg["num_convs_out"] != 1:
+        raise ValueError("MODEL.MIDDLE_HEAD.NUM_CONVS_IN/OUT other than 2/1 are not built")
+    m = GRAPHModule(in_channels, cfg["num_classes"], proto_iter=cfg["proto_iter"], transfer_cfg=cfg["transfer_cfg"],
+                    dbscan_eps=cfg["dbscan_eps"], dbscan_thr=cfg["dbscan_thr"])
+    m.lamda1, m.lamda2 = cfg["gcn_loss_weight"], cfg["act_loss_weight"]  # condgraph.py:160-163
+    m.lamda3, m.lamda4 = cfg["con_loss_weight"], cfg["gcn_loss_weight_tg"]
+    return m

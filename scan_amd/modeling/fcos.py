@@ -311,11 +311,18 @@ class FCOSPostProcessor:
 class FCOSModule(nn.Module):
     """model["fcos"] (reference fcos.py:117-258)."""
 
-    def __init__(self, num_classes=9, mode="precision"):
+    def __init__(self, num_classes=9, mode="precision", cfg=None):
         super().__init__()
-        self.head = FCOSHead(num_classes)
-        self.loss_evaluator = FCOSLossComputation()
-        self.box_selector_test = FCOSPostProcessor(num_classes=num_classes, mode=mode)
+        c = cfg or {}
+        if c.get("num_convs_cls", 4) != c.get("num_convs_reg", 4):
+            raise ValueError("MODEL.FCOS.NUM_CONVS_CLS != NUM_CONVS_REG is not built")
+        self.head = FCOSHead(num_classes, c.get("num_convs_cls", 4), c.get("prior_prob", 0.01))
+        self.loss_evaluator = FCOSLossComputation(c.get("loss_gamma", 2.0), c.get("loss_alpha", 0.25))
+        # reference rpn/fcos/inference.py:197-217 make_fcos_postprocessor
+        self.box_selector_test = FCOSPostProcessor(
+            pre_nms_thresh=c.get("inference_th", 0.05), pre_nms_top_n=c.get("pre_nms_top_n", 1000),
+            nms_thresh=c.get("nms_th", 0.6), fpn_post_nms_top_n=c.get("detections_per_img", 100), min_size=0,
+            num_classes=num_classes, mode=mode)
         self.mode = mode
 
     def forward(self, image_sizes, rows, shape, targets=None, act_maps=None):
@@ -336,4 +343,7 @@ class FCOSModule(nn.Module):
 
 
 def build_fcos(cfg=None, num_classes=9, mode="precision"):
+    """reference rpn/rpn.py:201 build_rpn(cfg, in_channels) for FCOS_ON; cfg: a config.settings dict or None."""
+    if cfg is not None:
+        return FCOSModule(cfg["num_classes"], cfg["test_mode"], cfg)
     return FCOSModule(num_classes, mode)

@@ -172,6 +172,25 @@ def _round8(c):
 # start of every iteration and the planes of flat-buffer parameters are reused by the source / target passes.
 SPLIT_EPOCH = None
 _split_cache = {}
+_epoch_counter = [0]
+
+
+def begin_weight_epoch():
+    """Start of a span in which parameters do not change (one training iteration): the bf16 planes split inside it are
+    reused by every launch that reads the same weight (forward, data gradient, source / target passes)."""
+    global SPLIT_EPOCH
+    _epoch_counter[0] += 1
+    SPLIT_EPOCH = _epoch_counter[0]
+    _split_cache.clear()
+
+
+def invalidate_weight_planes():
+    """Parameters are about to change or have changed in place (optimizer step, state_dict / checkpoint load): drop
+    every cached plane and stop caching until the next begin_weight_epoch().  In-place updates keep data_ptr, so a
+    stale entry would otherwise be served to e.g. inference() after training."""
+    global SPLIT_EPOCH
+    SPLIT_EPOCH = None
+    _split_cache.clear()
 
 
 # GroupNorm sums produced by a conv epilogue, handed to the groupnorm_relu call that consumes that conv's output

@@ -216,3 +216,36 @@ def synth_targets(n, h, w, num_fg=8, boxes_per_img=12, seed0=4321):
         labels = rs.randint(1, num_fg + 1, boxes_per_img).astype(np.int64)
         out.append((torch.from_numpy(boxes), torch.from_numpy(labels)))
     return out
+
+
+# ----------------------------------------------------------------------------- fixture inputs shared by the golden
+# generator (oracle/make_golden.py, run against the reference) and the parity tests
+TRAJ_ABSENT = (1, 5)  # trajectory iteration 1 holds no box of class 5 (rewritten to 6): the 'exists' mask path
+
+
+def traj_batch(it, H, W, N, K):
+    """inputs of trajectory iteration `it` (a different batch every iteration)."""
+    imgs_s = synth_images(N, H, W, 1234 + 17 * it)
+    imgs_t = synth_images(N, H, W, 2234 + 17 * it)
+    tg = synth_targets(N, H, W, K - 1, 12, 4321 + 17 * it)
+    if it == TRAJ_ABSENT[0]:
+        tg = [(b, torch.where(l == TRAJ_ABSENT[1], l + 1, l)) for b, l in tg]
+    return imgs_s, tg, imgs_t
+
+
+# procedural head biases moved so that every test mode yields detections: sigmoid(cls) passes INFERENCE_TH and
+# neighbouring locations predict boxes that overlap above NMS_TH (fixtures inference2_*)
+INF2_SHIFT = {"cls_bias": 3.0, "bbox_bias": 1.0}
+
+
+def shifted_state_dicts(K, conv_body="VGG-16-FPN-RETINANET"):
+    sds = all_state_dicts(K, conv_body)
+    sds["fcos"]["head.cls_logits.bias"] = sds["fcos"]["head.cls_logits.bias"] + INF2_SHIFT["cls_bias"]
+    sds["fcos"]["head.bbox_pred.bias"] = sds["fcos"]["head.bbox_pred.bias"] + INF2_SHIFT["bbox_bias"]
+    return sds
+
+
+def const_of(name):
+    """per-tensor constant of the reference-written checkpoint fixture (tests/golden/refckpt_*.pth.gz: constant
+    tensors gzip to kilobytes and still tell tensors apart)."""
+    return ((zlib.crc32(name.encode()) % 2000) - 1000) / 4096.0

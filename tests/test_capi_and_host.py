@@ -295,3 +295,65 @@ def test_optimizer_state_round_trip():
     assert torch.equal(g2.flat_m, g.flat_m) and g2.first is False
     with pytest.raises(ValueError):
         engine.FlatGroup(model2["middle_head"], 0.0025).load_optimizer_state_dict(sd)
+
+
+def test_reference_written_checkpoint_loads(gold_dir, tmp_path):
+    """tests/golden/refckpt_c2f.pth.gz was written by the REFERENCE's DetectronCheckpointer.save
+    (utils/checkpoint.py:141-301) for the full C2F model dict with per-tensor constant values, after three optimizer /
+    scheduler steps (oracle/make_golden.py gen_ckpt).  It holds the eight model state_dicts plus optimizer_ /
+    scheduler_ entries for the discriminators only and no iteration.  Loading it must fill every parameter and
+    buffer, restore the discriminators' momentum and take the iteration from the schedulers."""
+    import gzip
+    import json
+    import shutil
+    from scan_amd import checkpoint, engine, synth
+    path = str(tmp_path / "model_0000003.pth")
+    with gzip.open(os.path.join(gold_dir, "refckpt_c2f.pth.gz"), "rb") as fi, open(path, "wb") as fo:
+        shutil.copyfileobj(fi, fo)
+    man = json.load(open(os.path.join(gold_dir, "refckpt_c2f.manifest.json")))
+    assert "iteration" not in man["top_level_keys"] and "optimizer_backbone" not in man["top_level_keys"]
+    model = engine.build_model(9, device="cpu")
+    # same keys, shapes and dtypes as the file the reference wrote
+    mine = checkpoint.state_to_save(model)
+    for key in (k for k in man["top_level_keys"] if k.startswith("model_") or k == "middle_head"):
+        assert set(mine[key].keys()) == set(man[key].keys()), key
+        for n, (shape, dtype, _) in man[key].items():
+            assert list(mine[key][n].shape) == shape and str(mine[key][n].dtype) == dtype, (key, n)
+    trainer = engine.Trainer(model)
+    rest = trainer.load_checkpoint(path)
+    assert not rest, list(rest)
+    # expected values: the constant of every tensor, moved by three SGD steps with the constant gradient the generator
+    # set (solver/build.py:7-43 groups, constant warm-up factor 1/3) -- replayed here on scalars
+    def replay(p0, g, lr, wd, steps=3, mom=0.9):
+        p, buf = torch.tensor(p0, dtype=torch.float32), None
+        g = torch.tensor(g, dtype=torch.float32)
+        for _ in range(steps):
+            d = g + wd * p
+            buf = d.clone() if buf is None else buf * mom + d
+            p = p - lr * buf
+        return float(p), float(buf)
+
+    expect_m = {}
+    for mk, m in model.items():
+        sv = engine.CONFIGS["c2f"]["solver"]["dis" if mk.startswith("dis_") else mk]
+        trainable = {n for n, q in m.named_parameters() if q.requires_grad}
+        for k, v in m.state_dict().items():
+            c = synth.const_of(mk + "/" + k)
+            if k in trainable and not k.startswith("cond_2"):
+                bias = "bias" in k
+                c, expect_m[(mk, k)] = replay(c, synth.const_of("grad/" + mk + "/" + k),
+                                              sv["lr"] * (sv["bias_lr_factor"] if bias else 1.0) * sv["warmup_factor"],
+                                              sv["wd_bias"] if bias else sv["wd"])
+            assert bool((v == v.reshape(-1)[0]).all()), (mk, k)
+            assert abs(float(v.reshape(-1)[0]) - c) <= 1e-6 * max(abs(c), 1e-3), (mk, k, float(v.reshape(-1)[0]), c)
+    assert trainer.iteration == 3  # scheduler_dis_*['last_epoch']
+    # momentum of the discriminators comes back; the reference file carries no optimizer for the other sub-models
+    g = trainer.groups["dis_P3_CON"]
+    assert not g.first and trainer.groups["backbone"].first
+    for name, p, m in g._logical():
+        e = expect_m[("dis_P3_CON", name)]
+        assert abs(float(m.reshape(-1)[0]) - e) <= 1e-6 * max(abs(e), 1e-3) and bool((m == m.reshape(-1)[0]).all()), name
+    # weights-only load (the reference's own call, load_opt_sch=False) leaves optimizer and iteration alone
+    tr2 = engine.Trainer(engine.build_model(9, device="cpu"))
+    tr2.load_checkpoint(path, load_opt_sch=False)
+    assert tr2.iteration == 0 and tr2.groups["dis_P3_CON"].first

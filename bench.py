@@ -6,17 +6,28 @@
 One "step" = one full domain-adaptation iteration (reference fcos_core/engine/trainer.py:266-424:
 source forward + losses, 5 CKA discriminators on source, target forward, 5 CKA discriminators on
 target, three backward passes, SGD step of all 8 sub-models) on a per-GPU batch of 2 source + 2
-target frames (BASELINE.json configs[1]).  N > 1: one process per GPU (torch.distributed, RCCL),
-same per-GPU batch (weak scaling), one gradient all-reduce per sub-model flat buffer.
+target frames (BASELINE.json configs[1]).
+
+N > 1: one process per GPU (torch.distributed, RCCL over xGMI).  Started by `torch.distributed.run`
+(RANK / WORLD_SIZE in the environment) this process is one rank; started plainly with `--gpus N`
+it is only a LAUNCHER: it checks that N devices are visible, starts `python -m torch.distributed.run
+--nproc-per-node N bench.py ...` as a child BEFORE touching the GPU and exits with its code.
+`--scaling weak` (default): `--batch` source (= target) frames per GPU.  `--scaling strong`: a fixed
+GLOBAL batch (`--global-batch`, default 16 = BASELINE.json configs[2]) split over the ranks like the
+reference's loaders do (data/build.py:181-188).  Collectives per step: three gradient all-reduces over
+contiguous arena ranges on a side stream, the 9x257 paradigm all-reduce, one loss-scalar reduce.
 
 Prints ONE JSON line on rank 0.  `value` = source/target image PAIRS per second over all GPUs
-(frames/s = 2x, in config); `roofline` = fp32-MFMA implicit-GEMM conv kernels timed live with HIP
-events on their stream during the timed steps; `cpu_baseline` = the torch-CPU restatement
-(oracle/scan_ref.py, a port of the reference's CPU path) on this host's cores, on a bounded sample.
+(frames/s = 2x, in config); `roofline` = the conv kernel with the largest share, timed live with HIP
+events on its stream; `roofline_pointwise` = HBM GB/s of the pointwise kernels (tools/pointwise_roofline.py);
+`cpu_baseline` = the torch-CPU restatement (oracle/scan_ref.py, a port of the reference's CPU path) on this
+host's cores: 1 warm-up + 3 timed iterations at the best thread count of a short sweep.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -79,32 +90,80 @@ def peak_for(kernel_name):
     return PEAK_BF16X3_TFLOPS if "bf16x3" in kernel_name else PEAK_FP32_MFMA_TFLOPS
 
 
-def cpu_baseline(h, w):
-    """oracle port timed on the host cores: 1 (src,tgt) pair, one DA iteration."""
+def cpu_baseline(h, w, timed=3):
+    """oracle port timed on the host cores: one (src, tgt) pair per iteration, full DA iteration + SGD.
+    Thread count: best of a short sweep on quarter-size frames (torch-CPU conv backward stops scaling, then
+    collapses, past a few dozen threads), then 1 warm-up + `timed` timed full-size iterations."""
+    import platform
     import torch
     from oracle import scan_ref
     from scan_amd import synth
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    # torch-CPU conv backward degrades badly past a few dozen threads (256 threads: 80x slower than 8 here);
-    # use what it scales to and report that number as `cores`
-    cores = min(cores, 16)
-    torch.set_num_threads(cores)
     sds = synth.all_state_dicts(9)
-    P = {k: scan_ref.params(v, frozen_prefixes=("body.features.0.", "body.features.2.", "body.features.5.",
-                                                "body.features.7.")) for k, v in sds.items()}
-    st = scan_ref.PrototypeState(sds["middle_head"]["prototype"])
-    imgs_s, imgs_t = synth.synth_images(1, h, w, 1234), synth.synth_images(1, h, w, 2234)
-    tg = synth.synth_targets(1, h, w, 8, 12, 4321)
-    bufs = {}
-    t0 = time.time()
-    scan_ref.da_iteration(P, st, imgs_s, tg, imgs_t)
-    scan_ref.sgd_step(P, bufs)
-    dt = time.time() - t0
-    return dt, cores
+    frozen = ("body.features.0.", "body.features.2.", "body.features.5.", "body.features.7.")
+
+    def one(hh, ww, P, st, bufs):
+        imgs_s, imgs_t = synth.synth_images(1, hh, ww, 1234), synth.synth_images(1, hh, ww, 2234)
+        tg = synth.synth_targets(1, hh, ww, 8, 12, 4321)
+        t0 = time.time()
+        for pd in P.values():
+            for v in pd.values():
+                v.grad = None
+        scan_ref.da_iteration(P, st, imgs_s, tg, imgs_t)
+        scan_ref.sgd_step(P, bufs)
+        return time.time() - t0
+
+    def fresh():
+        return ({k: scan_ref.params(v, frozen_prefixes=frozen) for k, v in sds.items()},
+                scan_ref.PrototypeState(sds["middle_head"]["prototype"]), {})
+
+    physical = avail // 2 if avail >= 4 else avail  # SMT siblings do not help the conv kernels
+    sweep = {}
+    for n in sorted({c for c in (8, 16, 32, 64, physical) if 1 <= c <= avail}):
+        torch.set_num_threads(n)
+        P, st, bufs = fresh()
+        one(h // 4, w // 4, P, st, bufs)  # warm-up (thread pool, allocator)
+        sweep[n] = one(h // 4, w // 4, P, st, bufs)
+        if sweep[n] > 4 * min(sweep.values()):
+            break  # past the collapse: larger counts only get worse
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
+    P, st, bufs = fresh()
+    one(h, w, P, st, bufs)  # warm-up
+    times = [one(h, w, P, st, bufs) for _ in range(timed)]
+    cpu_model = platform.processor() or ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return {"times_s": [round(t, 2) for t in times], "best_s": min(times), "cores": cores, "visible_threads": avail,
+            "cpu_model": cpu_model, "sweep_quarter_size_s": {str(k): round(v, 2) for k, v in sweep.items()}}
+
+
+def _free_port():
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        return s_.getsockname()[1]
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a torch.distributed.run environment: become the launcher.  Nothing here
+    initialises the GPU (device_count() does not), the ranks are fresh child processes."""
+    import torch
+    n_vis = torch.cuda.device_count()
+    if n_vis < a.gpus and not a.launch_check:
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- refusing to measure fewer ranks than asked for"
+                         % (a.gpus, n_vis))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -114,7 +173,15 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
-    ap.add_argument("--batch", type=int, default=2, help="source (= target) frames per GPU per step")
+    ap.add_argument("--batch", type=int, default=2, help="source (= target) frames per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak")
+    ap.add_argument("--global-batch", type=int, default=16,
+                    help="--scaling strong: global source (= target) frames per step, split over the ranks "
+                         "(SOLVER.IMS_PER_BATCH semantics, reference data/build.py:181-188)")
+    ap.add_argument("--no-pointwise", action="store_true", help="skip the pointwise HBM roofline leg")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="test hook for the launcher (tests/test_launcher.py, runs without GPUs): the ranks only "
+                         "rendezvous over gloo, all-reduce their rank and rank 0 prints the world size it saw")
     ap.add_argument("--model", choices=("c2f", "s2c", "k2c", "k2c_r50"), default="c2f",
                     help="which shipped yaml's model (engine.CONFIGS); the headline metric is c2f")
     ap.add_argument("--forward-target", action="store_true",
@@ -126,29 +193,51 @@ def main():
                          "figures and the rocprof summaries under profiles/ are taken with")
     a = ap.parse_args()
 
+    launched = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # started by torch.distributed.run
+    if not launched and a.gpus > 1:
+        raise SystemExit(launch_ranks(a))
+    if a.launch_check:
+        import torch
+        import torch.distributed as dist
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world != a.gpus:
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.tensor([float(dist.get_rank())])
+            dist.all_reduce(t)
+            assert float(t) == world * (world - 1) / 2
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps({"launch_check": True, "n_gpus": world,
+                              "ranks_in_process_group": dist.get_world_size() if world > 1 else 1}), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    launched = "RANK" in os.environ and "MASTER_PORT" in os.environ  # started by torch.distributed.run
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from scan_amd import engine, ops, synth
+    from scan_amd import comm, engine, ops, synth
     mcfg = engine.CONFIGS[a.model]
-    body = mcfg.get("conv_body", "VGG-16-FPN-RETINANET")
-    model = engine.build_model(mcfg["num_classes"], mcfg["test_mode"], device=dev, transfer_cfg=mcfg["transfer_cfg"],
-                               conv_body=body)
+    body = mcfg["conv_body"]
+    model = engine.build_model(device=dev, settings=mcfg)
     engine.load_procedural_weights(model, mcfg["num_classes"], body)
     # under torch.distributed.run the data-parallel path (flat-buffer all-reduce on the side stream, paradigm
     # all-reduce) is exercised even with a single rank
-    trainer = engine.Trainer(model, distributed=True if dist.is_initialized() else None)
+    trainer = engine.Trainer(model, settings=mcfg, distributed=True if dist.is_initialized() else None)
 
     def set_serial(flag):
         trainer.overlap_target = not flag
@@ -160,7 +249,8 @@ def main():
 
     if a.serial_streams:
         set_serial(True)
-    H, W, B = a.height, a.width, a.batch
+    H, W = a.height, a.width
+    B = a.batch if a.scaling == "weak" else comm.images_per_gpu(a.global_batch, world)
     # frames go through the collator's zero padding to /32 (structures.to_image_list), e.g. 1333x2666 -> 1344x2688
     imgs_s = engine.to_image_list([t.to(dev) for t in synth.synth_image_list([(H, W)] * B, 1234 + 100 * rank)], 32)
     imgs_t = engine.to_image_list([t.to(dev) for t in synth.synth_image_list([(H, W)] * B, 2234 + 100 * rank)], 32)
@@ -172,12 +262,18 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        losses = trainer.step(imgs_s, tg, imgs_t, forward_target=a.forward_target)
+        if world > 1:  # the reference reduces the loss scalars to rank 0 for its meters (engine/trainer.py:76-98)
+            comm.reduce_loss_dict(losses)
+        return losses
+
     for _ in range(a.warmup):
-        trainer.step(imgs_s, tg, imgs_t, forward_target=a.forward_target)
+        step()
     barrier()
     t0 = time.time()
     for _ in range(a.steps):
-        losses = trainer.step(imgs_s, tg, imgs_t, forward_target=a.forward_target)
+        losses = step()
     barrier()
     dt = time.time() - t0
     # per-kernel roofline figures: HIP events around every conv launch on its stream.  With the side-stream overlap
@@ -220,26 +316,43 @@ def main():
                                              "launches": v["launches"],
                                              "share_of_serial_step": round(v["total_ms"] / (dtr * 1e3), 3)}
                                          for k, v in ksum.items()}}
+        pointwise = None
+        if not a.no_pointwise and world == 1:
+            from tools import pointwise_roofline
+            del trainer, model, imgs_s, imgs_t
+            torch.cuda.empty_cache()
+            recs = pointwise_roofline.measure(dev, reps=5, K=9)
+            pointwise = {"bound": "hbm", "peak": pointwise_roofline.PEAK_HBM_GBS, "unit": "GB/s",
+                         "sizes": {"cfg5": pointwise_roofline.M_CFG5, "microbench": pointwise_roofline.M_BIG},
+                         "note": "algorithmic bytes / HIP-event time per launch; cfg5-size working sets under 256 MB "
+                                 "can be served by the last-level cache (fits_llc)",
+                         "kernels": [{k: r[k] for k in ("kernel", "M", "bytes", "us", "GBps", "frac", "fits_llc")}
+                                     for r in recs]}
         cpu = None
         if not a.no_cpu_baseline and a.model == "c2f" and world == 1:  # rank 0 at N=1 only
-            sh, sw = H, W  # one full-size pair: ~10 s on 16 host threads
-            cdt, cores = cpu_baseline(sh, sw)
-            scale = (sh * sw) / float(H * W)
-            cpu = {"value": round(scale / cdt, 5), "unit": "pairs/s", "cores": cores, "kind": "port",
-                   "sample": "1 (src,tgt) pair of %dx%d frames, one full DA iteration + SGD (the GPU step does 2 pairs); "
-                             "%.1f s of CPU work" % (sh, sw, cdt)}
+            cb = cpu_baseline(H, W)
+            cpu = {"value": round(1.0 / cb["best_s"], 5), "unit": "pairs/s", "cores": cb["cores"], "kind": "port",
+                   "cpu_model": cb["cpu_model"], "visible_threads": cb["visible_threads"],
+                   "iterations_s": cb["times_s"], "thread_sweep_quarter_size_s": cb["sweep_quarter_size_s"],
+                   "sample": "1 (src,tgt) pair of %dx%d frames per iteration, full DA iteration + SGD (the GPU step does "
+                             "%d pairs); 1 warm-up + %d timed iterations, best %.1f s"
+                             % (H, W, B, len(cb["times_s"]), cb["best_s"])}
         line = {
-            "metric": "train images/sec (whole node), VGG16 C2F 1024x2048", "value": round(value, 4),
+            "metric": "train images/sec (whole node), %s %s %dx%d" % (
+                "VGG16" if body.startswith("VGG") else body.split("-FPN")[0], a.model.split("_")[0].upper(), H, W),
+            "value": round(value, 4),
             "unit": "image pairs/s (1 source + 1 target frame per pair)", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "SCAN %s %s DA iteration, %d src + %d tgt frames/GPU at %dx%d, "
                                    "forward_target=%s, procedural weights" % (a.model.upper(), body, B, B, H, W, a.forward_target),
                        "arithmetic": "fp32 storage and accumulation; 3x3 convs split each fp32 operand hi+lo into "
                                      "2 x bf16 and issue 3 bf16 MFMAs per product (1.7e-6 rel on the losses vs fp32)",
                        "global_batch_pairs": B * world, "frames_per_s": round(2 * value, 4), "parallelism": "dp%d" % world,
+                       "ranks_in_process_group": dist.get_world_size() if dist.is_initialized() else 1,
+                       "collective_backend": dist.get_backend() if dist.is_initialized() else None,
                        "losses_finite": finite},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_pointwise": pointwise, "cpu_baseline": cpu,
         }
         # RCCL prints a version banner through C stdio, which is still buffered here when stdout is a pipe: push it
         # out first so the JSON line is the LAST line on stdout

@@ -552,3 +552,22 @@ def inference(model, images):
         m.eval()
     ops.invalidate_weight_planes()  # weights may have been updated / loaded since the planes were cached
     return forward_detector(model, images, None)
+
+
+@torch.no_grad()
+def inference_distributed(model, batches):
+    """reference engine/inference.py:62-120 inference(): every rank runs compute_on_dataset (:15-37) over ITS shard --
+    ``batches`` yields (images, image_ids) -- then the predictions of all ranks are accumulated on rank 0
+    (_accumulate_predictions_from_multiple_gpus, :40-58) with comm.gather_detections.  Returns on rank 0 the list of
+    (boxes, scores, labels) ordered by image id (CPU tensors), None on the other ranks."""
+    from . import comm
+    results, ids = [], []
+    dev = next(next(iter(model.values())).parameters()).device
+    for images, image_ids in batches:
+        out = inference(model, images)
+        results.extend(out)
+        ids.extend(int(i) for i in image_ids)
+    merged = comm.gather_detections(results, ids, device=dev)
+    if merged is None:
+        return None
+    return [merged[i] for i in sorted(merged)]

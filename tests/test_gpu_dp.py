@@ -17,9 +17,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS, H, W = 2, 128, 128
 
 
-def _run(rank, world, same_shard):
+def _run(rank, world, same_shard, dev_index=0):
     from scan_amd import engine, synth
-    dev = torch.device("cuda", 0)
+    dev = torch.device("cuda", dev_index)
+    torch.cuda.set_device(dev)
     model = engine.build_model(9, device=dev, attn_dropout=0.0)
     engine.load_procedural_weights(model)
     trainer = engine.Trainer(model, distributed=True if world > 1 else None)
@@ -37,22 +38,28 @@ def _run(rank, world, same_shard):
     return out
 
 
-def _worker(rank, world, port, same_shard, outdir):
+def _worker(rank, world, port, same_shard, outdir, backend="gloo"):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if backend == "nccl":  # one GPU per rank, RCCL carries the collectives (side-stream all-reduce for real)
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.save(_run(rank, world, same_shard), os.path.join(outdir, "rank%d.pt" % rank))
+        torch.save(_run(rank, world, same_shard, rank if backend == "nccl" else 0),
+                   os.path.join(outdir, "rank%d.pt" % rank))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def _spawn(same_shard, outdir):
+def _spawn(same_shard, outdir, backend="gloo"):
     ctx = mp.get_context("spawn")
-    port = 29600 + os.getpid() % 2000 + (1 if same_shard else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, same_shard, str(outdir))) for r in range(2)]
+    port = 29600 + os.getpid() % 2000 + (1 if same_shard else 0) + (2 if backend == "nccl" else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, same_shard, str(outdir), backend)) for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -74,3 +81,19 @@ def test_two_ranks_same_shard_equal_single_process(device, tmp_path):
         assert torch.equal(a[k], b[k]), k
         # two runs of one schedule differ by ~7e-7 (float atomics; test_gpu_model.py::test_stream_overlap_is_race_free)
         assert torch.allclose(a[k], ref[k], rtol=1e-4, atol=5e-6), (k, (a[k] - ref[k]).abs().max().item())
+
+
+@pytest.mark.parametrize("same_shard", [False, True])
+def test_two_ranks_rccl(device, tmp_path, same_shard):
+    """the same two checks with one GPU per rank and backend "nccl" (= RCCL): the gradient all-reduces really run on
+    the side stream while the backbone back-propagates, and the wgrad kernels that bypass AccumulateGrad must be
+    ordered before them.  Needs two visible GPUs; skipped on the 1-GPU boxes."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device)")
+    a, b = _spawn(same_shard, tmp_path, backend="nccl")
+    for k in a:
+        assert torch.equal(a[k], b[k]), "rank 0 and rank 1 diverged in %s" % k
+    if same_shard:
+        ref = _run(0, 1, True)
+        for k in ref:
+            assert torch.allclose(a[k], ref[k], rtol=1e-4, atol=5e-6), (k, (a[k] - ref[k]).abs().max().item())

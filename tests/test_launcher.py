@@ -1,0 +1,98 @@
+"""CPU tests of what N > 1 adds outside the kernels: bench.py's launcher (`--gpus N` must start N ranks or fail) and the
+collectives of scan_amd/comm.py (loss-scalar reduce, detection gather, global batch split) on two gloo ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), env=env, capture_output=True,
+                          text=True, timeout=600)
+
+
+def test_launcher_starts_the_ranks_it_was_asked_for():
+    r = _bench("--gpus", "2", "--launch-check")
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 2, "ranks_in_process_group": 2}
+
+
+def test_launcher_refuses_fewer_devices_than_ranks():
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible")
+    r = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode != 0 and "refusing to measure fewer ranks" in (r.stderr + r.stdout)
+
+
+def test_world_size_must_match_gpus_flag():
+    env = dict(os.environ, PYTHONPATH=ROOT, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT="29999")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scan_amd import comm
+    losses = {"loss_cls_gs": torch.tensor(1.0 + rank), "act_loss_gs": torch.tensor(10.0 * (rank + 1)),
+              "zero_gt": torch.tensor(0.0)}
+    red = comm.reduce_loss_dict(losses)
+    # rank r holds images 2r, 2r+1; image 2r+1 has no detection on rank 1
+    res, ids = [], [2 * rank, 2 * rank + 1]
+    for j, iid in enumerate(ids):
+        k = 0 if (rank == 1 and j == 1) else 3 + iid
+        res.append((torch.full((k, 4), float(iid)), torch.full((k,), 0.5 + 0.01 * iid), torch.full((k,), iid + 1, dtype=torch.int64)))
+    merged = comm.gather_detections(res, ids)
+    out = {"red": {k: float(v) for k, v in red.items()}, "per_gpu": comm.images_per_gpu(16)}
+    if merged is not None:
+        out["merged"] = {i: (b.tolist(), s.tolist(), l.tolist()) for i, (b, s, l) in merged.items()}
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_loss_reduce_and_detection_gather_two_ranks():
+    """reference engine/trainer.py:76-98 (rank 0 gets the average) and utils/comm.py:48-88 + engine/inference.py:40-58
+    (rank 0 gets every rank's predictions keyed by image id, the others None)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0]["red"] == {"act_loss_gs": 15.0, "loss_cls_gs": 1.5, "zero_gt": 0.0}
+    assert res[0]["per_gpu"] == res[1]["per_gpu"] == 8
+    assert "merged" not in res[1]
+    m = res[0]["merged"]
+    assert sorted(m) == [0, 1, 2, 3]
+    assert len(m[0][0]) == 3 and len(m[1][0]) == 4 and len(m[2][0]) == 5 and len(m[3][0]) == 0
+    assert m[2][0][0] == [2.0] * 4 and m[2][2] == [3] * 5 and abs(m[1][1][0] - 0.51) < 1e-6
+
+
+def test_single_process_comm_is_passthrough():
+    from scan_amd import comm
+    d = {"a": torch.tensor(2.0)}
+    assert comm.reduce_loss_dict(d) is d and comm.get_world_size() == 1 and comm.is_main_process()
+    out = comm.gather_detections([(torch.zeros(2, 4), torch.ones(2), torch.ones(2, dtype=torch.int64))], [7])
+    assert list(out) == [7] and out[7][0].shape == (2, 4)
+    with pytest.raises(ValueError):
+        comm.images_per_gpu(16, 3)

@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""HBM roofline of the pointwise / reduction kernels of the SCAN hot path (north star: "rocprof HBM GB/s
+for the pointwise kernels against CDNA4 peak").
+
+Every kernel is launched through the C ABI on pre-allocated device buffers and timed with HIP events on the launch
+stream, at two sizes: M = 2^24 rows (the microbenchmark SURVEY 8d prescribes; working sets far beyond the 256 MB
+last-level cache) and M = 601,608 rows = the 8 frames per GPU of BASELINE.json configs[4] (1333x2666 padded to
+1344x2688: 75,201 locations per frame).  achieved = ALGORITHMIC bytes (the formula is printed with every record: what
+a perfectly fused kernel must read and write once) / average launch time; peak = 8 TB/s (MI355X_MICROARCH.md).
+
+    python tools/pointwise_roofline.py [--out profiles/r02_pointwise_roofline.json] [--small]
+
+bench.py imports measure() for the `roofline_pointwise` object of its JSON line; `rocprofv3 --kernel-trace --stats`
+of this script gives the matching per-kernel averages (profiles/r02_pointwise_kernel_stats.csv).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBS = 8000.0
+M_CFG5 = 8 * 75201  # 8 frames/GPU at 1344x2688: levels 168x336, 84x168, 42x84, 21x42, 11x21
+M_BIG = 1 << 24
+
+
+def _time(fn, reps, torch):
+    for _ in range(2):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record(torch.cuda.current_stream())
+    for _ in range(reps):
+        fn()
+    e.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) * 1e3 / reps  # us per launch
+
+
+def measure(dev, sizes=(M_CFG5, M_BIG), reps=10, K=9, only=None):
+    import torch
+    from scan_amd import ops
+    from scan_amd._lib import call, query
+    C = K - 1
+    P = ops._ptr
+    out = []
+
+    def st():
+        return ops._stream()
+
+    def rec(name, M, nbytes, formula, fn, unit="row"):
+        if only and name not in only:
+            return
+        us = _time(fn, reps, torch)
+        gbs = nbytes / us * 1e-3
+        out.append({"kernel": name, "M": int(M), "bytes": int(nbytes), "bytes_per_%s" % unit: round(nbytes / M, 2),
+                    "formula": formula, "us": round(us, 2), "GBps": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4),
+                    "fits_llc": bool(nbytes < 256e6)})
+
+    g = torch.Generator(device=dev).manual_seed(0)
+    for M in sizes:
+        # ---- sigmoid focal loss (a13): logits [M,C], targets int32 [M]
+        x = (torch.randn((M, C), device=dev, generator=g) * 3 - 2)
+        t = torch.randint(-1, C + 1, (M,), device=dev, generator=g, dtype=torch.int32)
+        s1 = torch.zeros(1, device=dev)
+        d = torch.empty_like(x)
+        rec("sigmoid_focal_fwd_sum", M, 4 * (M * C + M), "4(MC+M): logits + targets read, sum in registers",
+            lambda: call("scan_sigmoid_focal_loss_forward", P(x), P(t), M, C, 2.0, 0.25, None, P(s1), st()))
+        rec("sigmoid_focal_fwd_elem", M, 4 * (2 * M * C + M), "4(2MC+M): + element-wise losses written (the _C entry point)",
+            lambda: call("scan_sigmoid_focal_loss_forward", P(x), P(t), M, C, 2.0, 0.25, P(d), None, st()))
+        rec("sigmoid_focal_bwd", M, 4 * (2 * M * C + M), "4(2MC+M): logits + targets read, d_logits written (scalar upstream grad)",
+            lambda: call("scan_sigmoid_focal_loss_backward", P(x), P(t), None, 0.5, M, C, 2.0, 0.25, P(d), st()))
+        # ---- softmax focal act loss (a9): logits [M,K], labels int64 [M]
+        z = torch.randn((M, K), device=dev, generator=g) * 2
+        lab = torch.randint(0, K, (M,), device=dev, generator=g)
+        dz = torch.empty_like(z)
+        rec("softmax_focal_fwd", M, M * (4 * K + 8), "M(4K+8): logits + int64 labels read",
+            lambda: call("scan_softmax_focal_forward", P(z), P(lab), M, K, 2.0, P(s1), st()))
+        rec("softmax_focal_bwd", M, M * (8 * K + 8), "M(8K+8): + d_logits written",
+            lambda: call("scan_softmax_focal_backward", P(z), P(lab), M, K, 2.0, 1.0 / M, P(dz), st()))
+        # ---- CKA class-weighted BCE (a15): logits [M,C], act maps [M,K]
+        act = torch.softmax(z, 1).contiguous()
+        o2 = torch.zeros(2 * C, device=dev)
+        gd = torch.rand(C, device=dev)
+        rec("cka_bce_fwd", M, 4 * M * (C + K), "4M(C+K): logits + act maps read",
+            lambda: call("scan_cka_bce_forward", P(x), P(act), M, C, 1.0, P(o2), st()))
+        rec("cka_bce_bwd", M, 4 * M * (2 * C + K), "4M(2C+K): + d_logits written",
+            lambda: call("scan_cka_bce_backward", P(x), P(act), M, C, 1.0, P(gd), P(d), st()))
+        del x, t, d, z, lab, dz, act
+        # ---- IoU loss (a14) / centerness BCE on P positives (P = M here: the kernels do not care)
+        pr = torch.rand((M, 4), device=dev, generator=g) * 60 + 0.5
+        tg = torch.rand((M, 4), device=dev, generator=g) * 60 + 0.5
+        w = torch.rand((M,), device=dev, generator=g)
+        o = torch.zeros(2, device=dev)
+        dp = torch.empty_like(pr)
+        gn = torch.ones(1, device=dev)
+        rec("iou_loss_fwd", M, 36 * M, "36P: pred + target (16 B each) + weight read", unit="positive",
+            fn=lambda: call("scan_iou_loss_forward", P(pr), P(tg), P(w), M, P(o), st()))
+        rec("iou_loss_bwd", M, 52 * M, "52P: + d_pred written", unit="positive",
+            fn=lambda: call("scan_iou_loss_backward", P(pr), P(tg), P(w), M, P(gn), P(dp), st()))
+        rec("bce_logits_fwd", M, 8 * M, "8P: logits + targets read", unit="positive",
+            fn=lambda: call("scan_bce_logits_forward", P(w), P(w), 0.0, None, 0, M, P(o), st()))
+        del pr, tg, dp
+        # ---- GRL / SGD on flat buffers
+        n = M * 16
+        a = torch.randn(n, device=dev, generator=g)
+        b = torch.empty_like(a)
+        rec("grl_scale", n, 8 * n, "8 B/element: read + write", unit="element",
+            fn=lambda: call("scan_scale", P(a), -0.02, P(b), n, st()))
+        m_ = torch.zeros_like(a)
+        rec("sgd_momentum", n, 20 * n, "20 B/parameter: p, g, m read; p, m written", unit="element",
+            fn=lambda: call("scan_sgd_momentum", P(a), P(b), P(m_), n, 1e-9, 1e-4, 0.9, 0, st()))
+        del a, b, m_
+        # ---- dynamic conv + softmax (a4): feat [M,256], kernels [K,256]
+        feat = torch.randn((M, 256), device=dev, generator=g)
+        kern = torch.randn((K, 256), device=dev, generator=g) * 0.05
+        lg = torch.empty((M, K), device=dev)
+        pb = torch.empty((M, K), device=dev)
+        rec("dynconv_softmax_fwd", M, M * (1024 + 8 * K), "M(1024+8K): features read, logits + probabilities written",
+            lambda: call("scan_dynconv_softmax_forward", P(feat), P(kern), M, 256, K, P(lg), P(pb), st()))
+        dl = torch.randn((M, K), device=dev, generator=g)
+        dpb = torch.randn((M, K), device=dev, generator=g)
+        dfe = torch.empty_like(feat)
+        dk = torch.empty_like(kern)
+        ws = torch.empty((query("scan_dynconv_ws_floats", M, 256, K),), device=dev)
+        rec("dynconv_softmax_bwd", M, M * (2048 + 12 * K), "M(2048+12K): features, probs, d_logits, d_probs read; d_features written",
+            lambda: call("scan_dynconv_softmax_backward", P(feat), P(kern), P(pb), P(dl), P(dpb), M, 256, K, P(dfe),
+                         P(dk), P(ws), st()))
+        del lg, pb, dl, dpb, dk, ws
+        # ---- GroupNorm(32)+ReLU on a one-level pyramid of 8 images (a3/a11/a15 towers)
+        n_img = 8
+        hw = M // n_img
+        h = 1
+        while h * h * 2 < hw:
+            h += 1
+        wd_ = hw // h
+        Mg = n_img * h * wd_
+        shape = ops.PyramidShape(n_img, [(h, wd_)])
+        gam, bet = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev)
+        stats = torch.empty((n_img * 64,), device=dev)
+        wsg = torch.empty((query("scan_groupnorm_ws_floats", shape.ref(), 256, 32) // 2 + 1,), dtype=torch.float64, device=dev)
+        xg, yg = feat[:Mg], dfe[:Mg]
+        rec("groupnorm_stats", Mg, 1024 * Mg, "1024M: x read (towers get the sums from the conv epilogue instead)",
+            lambda: call("scan_groupnorm_stats", P(xg), shape.ref(), 256, 32, 1e-5, P(stats), P(wsg), st()))
+        rec("groupnorm_relu_apply", Mg, 2048 * Mg, "2048M: x read, y written",
+            lambda: call("scan_groupnorm_relu_forward", P(xg), shape.ref(), 256, 32, P(stats), P(gam), P(bet), 1, P(yg), st()))
+        dyg = torch.randn((Mg, 256), device=dev, generator=g)
+        dxg = torch.empty_like(dyg)
+        dg_, db_ = torch.empty(256, device=dev), torch.empty(256, device=dev)
+        rec("groupnorm_relu_bwd", Mg, 5120 * Mg, "5120M: reduce pass reads x, dy; apply pass reads x, dy, writes dx",
+            lambda: call("scan_groupnorm_relu_backward", P(xg), P(bet), P(dyg), shape.ref(), 256, 32, P(stats), P(gam), 1,
+                         P(dxg), P(dg_), P(db_), 0, P(wsg), st()))
+        del feat, dfe, dyg, dxg
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="")
+    ap.add_argument("--small", action="store_true", help="only the configs[4] size")
+    ap.add_argument("--reps", type=int, default=10)
+    a = ap.parse_args()
+    import torch
+    dev = torch.device("cuda:0")
+    res = measure(dev, (M_CFG5,) if a.small else (M_CFG5, M_BIG), a.reps)
+    for r in res:
+        print("%-26s M=%9d %8.1f us %8.1f GB/s  frac %.3f%s" % (r["kernel"], r["M"], r["us"], r["GBps"], r["frac"],
+                                                               "  (fits LLC)" if r["fits_llc"] else ""))
+    if a.out:
+        with open(a.out, "w") as f:
+            json.dump({"peak_GBps": PEAK_HBM_GBS, "records": res}, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()

@@ -40,6 +40,12 @@ typedef struct {
 const char* scan_last_error(void);
 int scan_abi_version(void);
 
+/* Tuning knob for A/B measurements and tests (no reference counterpart): scan_tune(key, value) sets an integer
+ * launch-selection parameter and returns its previous value, -1 for an unknown key.
+ *   "conv_bn256"  1 (default): 3x3 convs whose output channels are a multiple of 256 use 256-channel tiles
+ *                 when the launch keeps >= 2 workgroups per CU; 0: always 128-channel tiles (same results). */
+int scan_tune(const char* key, int value);
+
 /* ---- SigmoidFocalLoss  (replaces _C.sigmoid_focalloss_forward / _backward,
  *      csrc/SigmoidFocalLoss.h:10-41, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-187) ----
  * logits [M,C] fp32, targets [M] int32 (0 = bg, c = class c, <0 = ignore).

@@ -1,6 +1,7 @@
 // Error channel + ABI version of libscan_hip.so.
 #include <stdarg.h>
 #include <stdio.h>
+#include <string.h>
 
 #include "../../include/scan_hip.h"
 
@@ -15,3 +16,16 @@ extern "C" void scan_set_error(const char* fmt, ...) {
 
 extern "C" const char* scan_last_error(void) { return g_err; }
 extern "C" int scan_abi_version(void) { return 1; }
+
+// launch-selection knobs (scan_tune): defined next to the launch code that reads them
+extern int g_scan_conv_bn256;
+
+extern "C" int scan_tune(const char* key, int value) {
+  if (key == nullptr) return -1;
+  int* slot = nullptr;
+  if (strcmp(key, "conv_bn256") == 0) slot = &g_scan_conv_bn256;
+  if (slot == nullptr) return -1;
+  const int old = *slot;
+  *slot = value;
+  return old;
+}

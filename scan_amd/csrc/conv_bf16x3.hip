@@ -73,10 +73,10 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
   constexpr int PWK = TW + 2 * HALO;
   constexpr int NPATCH = PH * PWK;                // halo pixels: 180 (TH 8) or 324 (TH 16); 256 for the 1x1
   constexpr int WAVES = NT / 64;
-  constexpr int WN_WAVES = BN / 64;               // 2 (BN=128) or 1 (BN=64)
+  constexpr int WN_WAVES = BN >= 128 ? 2 : 1;     // 2 (BN=128 / 256) or 1 (BN=64)
   constexpr int WM_WAVES = WAVES / WN_WAVES;
   constexpr int TM = (TH * TW / 32) / WM_WAVES;   // 32-pixel MFMA tiles per wave
-  constexpr int TN = 2;                           // 32-channel MFMA tiles per wave
+  constexpr int TN = BN / (32 * WN_WAVES);        // 32-channel MFMA tiles per wave: 2, or 4 for BN=256
   constexpr int ASLOTS = (NPATCH * 8 + NT - 1) / NT;  // float4 of the halo patch per thread per chunk
   constexpr int BSEG = BN * 4 * 2 / NT;           // 16-byte weight segments per thread per (chunk, tap)
 
@@ -181,7 +181,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
     const int p = (wm * TM + tm) * 32 + lr;  // pixel within the 8x16 tile
     a_off[tm] = (p >> 4) * PPITCH + (p & 15) * LROW + 8 * lh;
   }
-  const int b_off = (wn * 64 + lr) * LROW + 8 * lh;
+  const int b_off = (wn * 32 * TN + lr) * LROW + 8 * lh;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -210,6 +210,30 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
       const int shift = ky * PPITCH + kx * LROW;
       const __bf16* bh = Bs + (buf * 2 + 0) * BN * LROW + b_off;
       const __bf16* bl = Bs + (buf * 2 + 1) * BN * LROW + b_off;
+      if constexpr (TN > 2) {
+        // 128 accumulator registers: keep only one channel tile's weight fragments live at a time
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          bf16x8 ah[TM], al[TM];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) {
+            ah[tm] = *reinterpret_cast<const bf16x8*>(Ah + a_off[tm] + shift + 16 * s);
+            al[tm] = *reinterpret_cast<const bf16x8*>(Al + a_off[tm] + shift + 16 * s);
+          }
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) {
+            const bf16x8 bhv = *reinterpret_cast<const bf16x8*>(bh + tn * 32 * LROW + 16 * s);
+            const bf16x8 blv = *reinterpret_cast<const bf16x8*>(bl + tn * 32 * LROW + 16 * s);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bhv, acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], blv, acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bhv, acc[tm][tn], 0, 0, 0);
+            }
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int s = 0; s < 2; ++s) {
         bf16x8 ah[TM], al[TM], bhv[TN], blv[TN];
@@ -238,7 +262,7 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
   // ---- epilogue.  C/D map of 32x32: col = lane&31 (channel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
-    const int o = n0 + wn * 64 + tn * 32 + lr;
+    const int o = n0 + wn * 32 * TN + tn * 32 + lr;
     const float bv = (bias != nullptr && o < Nout) ? bias[o] : 0.f;
     float gs = 0.f, gq = 0.f;
     if (relu & 2) {
@@ -333,6 +357,10 @@ __global__ void weight_split_kernel(const float* __restrict__ w, int O, int T, i
   }
 }
 
+// tuning switch (tests / A-B measurements): 0 keeps every launch on the 128-channel instance
+int g_scan_conv_bn256 = 1;
+#define g_bn256 g_scan_conv_bn256
+
 static void make_tiles(const scan_pyramid_t* d, TileTab* tt, int TH) {
   tt->tile_off[0] = 0;
   for (int l = 0; l < SCAN_MAX_LEVELS; ++l) {
@@ -376,11 +404,29 @@ static int conv3x3_bf16x3_launch(const float* x, const scan_pyramid_t* d, int32_
   const __bf16* h = reinterpret_cast<const __bf16*>(wh);
   const __bf16* l = reinterpret_cast<const __bf16*>(wl);
   if (Nout > 64) {
-    // 16 x 16 pixel tiles, 512 threads (8 waves = 4 x 2 of 64 px x 64 ch): one weight tile feeds 256 pixels.
+    // 16 x 16 pixel tiles, 512 threads (8 waves = 4 x 2).  BN = 128: each wave 64 px x 64 ch.
     // (A/B on one device, tower layer: 8x16/256 thr x2 per CU 305 TF, this 332 TF, a 3-deep software-pipelined
     //  variant of it 330 TF -- not kept.)
+    // BN = 256 (each wave 64 px x 128 ch, 128 accumulator registers): the halo patch is staged and split once
+    // per 256 output channels instead of once per 128, and each barrier interval carries twice the MFMA work.  Used
+    // when the output channels fill 256-wide tiles and the launch still has >= 2 workgroups per CU.
     make_tiles(d, &tt, 16);
     const int tiles = tt.tile_off[d->n_levels];
+    const bool wide = g_bn256 && Nout % 256 == 0 && (int64_t)tiles * (Nout / 256) >= 512;
+    if (wide) {
+      const int n_tiles = Nout / 256;
+      const size_t sh = (size_t)(2 * 18 * PPITCH + 4 * 256 * LROW) * sizeof(__bf16);
+      static bool done = false;
+      if (!done) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_bf16x3_kernel<256, 16, 512>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        done = true;
+      }
+      hipLaunchKernelGGL((conv3x3_bf16x3_kernel<256, 16, 512>), dim3(tiles * n_tiles), dim3(512), sh, st, x, *d, Cs, h, l,
+                         Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *d, 0, gn_ws);
+      SCAN_LAUNCH_CHECK("conv3x3_bf16x3");
+      return 0;
+    }
     const int n_tiles = (Nout + 127) / 128;
     const size_t sh = (size_t)(2 * 18 * PPITCH + 4 * 128 * LROW) * sizeof(__bf16);
     static bool done = false;

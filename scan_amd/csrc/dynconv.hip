@@ -66,7 +66,11 @@ __global__ __launch_bounds__(256) void dynconv_fwd_kernel(const float* __restric
   }
 }
 
-// backward: lane -> 4 channels, wave -> rows.  part[block][K][256] partial d_kernels.
+// backward: lane -> 4 channels, wave -> FOUR consecutive rows per iteration.  part[block][K][256] partial d_kernels.
+// The K softmax-backward coefficients of a row are computed ONCE by K lanes (16-lane group r handles row r: three
+// coalesced 36-byte segment loads per wave instead of 27 same-address loads per lane and row), reduced with four
+// xor-shuffles and broadcast to the wave as scalars (v_readlane -> SGPR operands of the FMAs).  Four rows in flight
+// per wave hide the HBM latency the one-row-per-iteration version was bound by (1.1 -> ? TB/s, see profiles/).
 template <int K>
 __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const float* __restrict__ feat,
                                                           const float* __restrict__ kernels,
@@ -76,6 +80,7 @@ __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const float* __restric
                                                           float* __restrict__ d_feat, float* __restrict__ part) {
   __shared__ float red[4][K][DC_C];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int gr = lane >> 4, gk = lane & 15;
   float4 w[K], dwacc[K];
 #pragma unroll
   for (int k = 0; k < K; ++k) {
@@ -84,33 +89,41 @@ __global__ __launch_bounds__(256) void dynconv_bwd_kernel(const float* __restric
   }
   const int64_t wave_id = (int64_t)blockIdx.x * 4 + wid;
   const int64_t n_waves = (int64_t)gridDim.x * 4;
-  for (int64_t row = wave_id; row < M; row += n_waves) {
-    float dz[K];
-    float dot = 0.f;
-    if (d_probs != nullptr) {
+  const int64_t chunks = (M + 3) >> 2;
+  for (int64_t ch = wave_id; ch < chunks; ch += n_waves) {
+    const int64_t row0 = ch << 2;
+    float4 f[4];
 #pragma unroll
-      for (int k = 0; k < K; ++k) dot += probs[row * K + k] * d_probs[row * K + k];
-    }
+    for (int r = 0; r < 4; ++r)
+      f[r] = (row0 + r < M) ? *reinterpret_cast<const float4*>(feat + (row0 + r) * DC_C + 4 * lane)
+                            : make_float4(0, 0, 0, 0);
+    const int64_t myrow = row0 + gr;
+    const bool act = gk < K && myrow < M;
+    const int64_t idx = myrow * K + gk;
+    const float pl = (act && d_probs != nullptr) ? probs[idx] : 0.f;
+    const float dp = (act && d_probs != nullptr) ? d_probs[idx] : 0.f;
+    const float dl = (act && d_logits_in != nullptr) ? d_logits_in[idx] : 0.f;
+    float dot = pl * dp;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      float v = (d_logits_in != nullptr) ? d_logits_in[row * K + k] : 0.f;
-      if (d_probs != nullptr) v += probs[row * K + k] * (d_probs[row * K + k] - dot);
-      dz[k] = v;
-    }
-    const float4 f = *reinterpret_cast<const float4*>(feat + row * DC_C + 4 * lane);
-    float4 o = make_float4(0, 0, 0, 0);
+    for (int off = 1; off < 16; off <<= 1) dot += __shfl_xor(dot, off, 64);
+    const float dzv = dl + pl * (dp - dot);
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      o.x += dz[k] * w[k].x;
-      o.y += dz[k] * w[k].y;
-      o.z += dz[k] * w[k].z;
-      o.w += dz[k] * w[k].w;
-      dwacc[k].x += dz[k] * f.x;
-      dwacc[k].y += dz[k] * f.y;
-      dwacc[k].z += dz[k] * f.z;
-      dwacc[k].w += dz[k] * f.w;
+    for (int r = 0; r < 4; ++r) {
+      float4 o = make_float4(0, 0, 0, 0);
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        const float dz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(dzv), r * 16 + k));
+        o.x += dz * w[k].x;
+        o.y += dz * w[k].y;
+        o.z += dz * w[k].z;
+        o.w += dz * w[k].w;
+        dwacc[k].x += dz * f[r].x;
+        dwacc[k].y += dz * f[r].y;
+        dwacc[k].z += dz * f[r].z;
+        dwacc[k].w += dz * f[r].w;
+      }
+      if (row0 + r < M) *reinterpret_cast<float4*>(d_feat + (row0 + r) * DC_C + 4 * lane) = o;
     }
-    *reinterpret_cast<float4*>(d_feat + row * DC_C + 4 * lane) = o;
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) *reinterpret_cast<float4*>(&red[wid][k][4 * lane]) = dwacc[k];

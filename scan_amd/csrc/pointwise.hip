@@ -8,26 +8,75 @@
 
 // ------------------------------------------------------------------ sigmoid focal loss
 // follows the reference's stable CUDA formula, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-101
-__device__ __forceinline__ float focal_fwd_elem(float x, int t, int d, float gamma, float alpha) {
-  const float c1 = (t == d + 1) ? 1.f : 0.f;
-  const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
-  const float p = 1.f / (1.f + expf(-x));
-  const float term1 = powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
-  const float ge = (x >= 0.f) ? 1.f : 0.f;
-  const float term2 = powf(p, gamma) * (-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge)));
-  return -c1 * term1 * alpha - c2 * term2 * (1.f - alpha);
+// Shared pieces: p = sigmoid(x) and expf(x - 2x[x>=0]) = expf(-|x|) are evaluated once; gamma == 2 (the shipped
+// MODEL.FCOS.LOSS_GAMMA) squares instead of calling powf; the positive-class term is only evaluated by lanes that
+// need it (a wave with no positive label skips it entirely).
+template <bool G2>
+__device__ __forceinline__ float focal_pow(float b, float gamma) {
+  return G2 ? b * b : powf(b, gamma);
 }
-__device__ __forceinline__ float focal_bwd_elem(float x, int t, int d, float gamma, float alpha) {
-  const float c1 = (t == d + 1) ? 1.f : 0.f;
-  const float c2 = (t >= 0 && t != d + 1) ? 1.f : 0.f;
+template <bool G2>
+__device__ __forceinline__ float focal_fwd_elem(float x, int t, int d, float gamma, float alpha) {
+  if (t < 0) return 0.f;
   const float p = 1.f / (1.f + expf(-x));
-  const float term1 = powf(1.f - p, gamma) * (1.f - p - (p * gamma * logf(fmaxf(p, FLT_MIN))));
+  if (t == d + 1) {
+    const float term1 = focal_pow<G2>(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
+    return -term1 * alpha;
+  }
+  const float ge = (x >= 0.f) ? 1.f : 0.f;
+  const float term2 = focal_pow<G2>(p, gamma) * (-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge)));
+  return -term2 * (1.f - alpha);
+}
+template <bool G2>
+__device__ __forceinline__ float focal_bwd_elem(float x, int t, int d, float gamma, float alpha) {
+  if (t < 0) return 0.f;
+  const float p = 1.f / (1.f + expf(-x));
+  if (t == d + 1) {
+    const float term1 = focal_pow<G2>(1.f - p, gamma) * (1.f - p - (p * gamma * logf(fmaxf(p, FLT_MIN))));
+    return -term1 * alpha;
+  }
   const float ge = (x >= 0.f) ? 1.f : 0.f;
   const float term2 =
-      powf(p, gamma) * ((-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge))) * (1.f - p) * gamma - p);
-  return -c1 * term1 * alpha - c2 * term2 * (1.f - alpha);
+      focal_pow<G2>(p, gamma) * ((-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge))) * (1.f - p) * gamma - p);
+  return -term2 * (1.f - alpha);
 }
 
+// row (label index) and class of the 4 consecutive elements starting at i0 = 4q.  CT = compile-time class count of the
+// two shipped configurations (8: Cityscapes, one label per two float4; 1: Sim10k / KITTI, one label per element),
+// 0 = any C (one integer division per float4 instead of the 64-bit division per element this kernel used to pay).
+template <int CT>
+__device__ __forceinline__ void focal_rowcol(int64_t q, int C, const int* __restrict__ targets, int64_t total,
+                                             int (&t)[4], int (&d)[4]) {
+  if (CT == 8) {
+    const int tt = targets[q >> 1];
+    const int d0 = (int)(q & 1) * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t[e] = tt;
+      d[e] = d0 + e;
+    }
+  } else if (CT == 1) {
+    const int4 tt = reinterpret_cast<const int4*>(targets)[q];
+    t[0] = tt.x; t[1] = tt.y; t[2] = tt.z; t[3] = tt.w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) d[e] = 0;
+  } else {
+    const int64_t i0 = q << 2;
+    int64_t n = i0 / C;
+    int dd = (int)(i0 - n * C);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      t[e] = (i0 + e < total) ? targets[n] : -1;
+      d[e] = dd;
+      if (++dd == C) {
+        dd = 0;
+        ++n;
+      }
+    }
+  }
+}
+
+template <int CT, bool G2>
 __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict__ logits,
                                                         const int* __restrict__ targets, int64_t total, int C,
                                                         float gamma, float alpha, float* __restrict__ losses,
@@ -46,16 +95,12 @@ __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict_
 #pragma unroll
       for (int e = 0; e < 4; ++e) x[e] = (i0 + e < total) ? logits[i0 + e] : 0.f;
     }
+    int t[4], d[4];
+    focal_rowcol<CT>(q, C, targets, total, t, d);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int64_t i = i0 + e;
-      l[e] = 0.f;
-      if (i < total) {
-        const int64_t n = i / C;
-        const int d = (int)(i - n * C);
-        l[e] = focal_fwd_elem(x[e], targets[n], d, gamma, alpha);
-        acc += l[e];
-      }
+      l[e] = (i0 + e < total) ? focal_fwd_elem<G2>(x[e], t[e], d[e], gamma, alpha) : 0.f;
+      acc += l[e];
     }
     if (losses != nullptr) {
       if (vec) {
@@ -73,18 +118,71 @@ __global__ __launch_bounds__(256) void focal_fwd_kernel(const float* __restrict_
   }
 }
 
+template <int CT, bool G2>
 __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict__ logits,
                                                         const int* __restrict__ targets,
                                                         const float* __restrict__ d_losses, float d_scale,
                                                         int64_t total, int C, float gamma, float alpha,
                                                         float* __restrict__ d_logits) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t n = i / C;
-    const int d = (int)(i - n * C);
-    const float g = focal_bwd_elem(logits[i], targets[n], d, gamma, alpha);
-    d_logits[i] = g * (d_losses != nullptr ? d_losses[i] : d_scale);
+  const int64_t n4 = (total + 3) >> 2;
+  const bool vec = (total & 3) == 0;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = q << 2;
+    float x[4], up[4], g[4];
+    if (vec) {
+      const float4 v = reinterpret_cast<const float4*>(logits)[q];
+      x[0] = v.x; x[1] = v.y; x[2] = v.z; x[3] = v.w;
+      if (d_losses != nullptr) {
+        const float4 u = reinterpret_cast<const float4*>(d_losses)[q];
+        up[0] = u.x; up[1] = u.y; up[2] = u.z; up[3] = u.w;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        x[e] = (i0 + e < total) ? logits[i0 + e] : 0.f;
+        if (d_losses != nullptr) up[e] = (i0 + e < total) ? d_losses[i0 + e] : 0.f;
+      }
+    }
+    int t[4], d[4];
+    focal_rowcol<CT>(q, C, targets, total, t, d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      g[e] = ((i0 + e < total) ? focal_bwd_elem<G2>(x[e], t[e], d[e], gamma, alpha) : 0.f) *
+             (d_losses != nullptr ? up[e] : d_scale);
+    if (vec) {
+      reinterpret_cast<float4*>(d_logits)[q] = make_float4(g[0], g[1], g[2], g[3]);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i0 + e < total) d_logits[i0 + e] = g[e];
+    }
   }
 }
+
+// loss reductions end in one float atomic per block on ONE address: keep the block count low (same-address atomics
+// serialise at ~13 ns each: 2048 blocks cost ~55 us whatever the tensor size) and give each thread more elements
+static inline int grid_reduce(int64_t work_items, int block) {
+  int64_t g = (work_items + (int64_t)block * 8 - 1) / ((int64_t)block * 8);
+  if (g < 1) g = 1;
+  if (g > 512) g = 512;
+  return (int)g;
+}
+
+#define FOCAL_DISPATCH(KERNEL, GRID, ...)                                                                           \
+  do {                                                                                                              \
+    const bool g2 = gamma == 2.0f;                                                                                  \
+    const bool al = (total & 3) == 0;                                                                               \
+    if (C == 8 && al) {                                                                                             \
+      if (g2) hipLaunchKernelGGL((KERNEL<8, true>), dim3(GRID), dim3(256), 0, as_stream(stream), __VA_ARGS__);      \
+      else hipLaunchKernelGGL((KERNEL<8, false>), dim3(GRID), dim3(256), 0, as_stream(stream), __VA_ARGS__);        \
+    } else if (C == 1 && al && (reinterpret_cast<uintptr_t>(targets) & 15) == 0) {                                  \
+      if (g2) hipLaunchKernelGGL((KERNEL<1, true>), dim3(GRID), dim3(256), 0, as_stream(stream), __VA_ARGS__);      \
+      else hipLaunchKernelGGL((KERNEL<1, false>), dim3(GRID), dim3(256), 0, as_stream(stream), __VA_ARGS__);        \
+    } else {                                                                                                        \
+      if (g2) hipLaunchKernelGGL((KERNEL<0, true>), dim3(GRID), dim3(256), 0, as_stream(stream), __VA_ARGS__);      \
+      else hipLaunchKernelGGL((KERNEL<0, false>), dim3(GRID), dim3(256), 0, as_stream(stream), __VA_ARGS__);        \
+    }                                                                                                               \
+  } while (0)
 
 extern "C" int scan_sigmoid_focal_loss_forward(const float* logits, const int32_t* targets, int64_t M, int32_t C,
                                                float gamma, float alpha, float* losses, float* loss_sum,
@@ -94,8 +192,8 @@ extern "C" int scan_sigmoid_focal_loss_forward(const float* logits, const int32_
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && targets, "sigmoid_focal_loss_forward: null input");
   const int64_t total = M * C;
-  hipLaunchKernelGGL(focal_fwd_kernel, dim3(grid_for((total + 3) / 4, 256)), dim3(256), 0, as_stream(stream), logits,
-                     targets, total, C, gamma, alpha, losses, loss_sum);
+  const int grid = loss_sum ? grid_reduce((total + 3) / 4, 256) : grid_for((total + 3) / 4, 256);
+  FOCAL_DISPATCH(focal_fwd_kernel, grid, logits, targets, total, C, gamma, alpha, losses, loss_sum);
   SCAN_LAUNCH_CHECK("focal_fwd");
   return 0;
 }
@@ -107,8 +205,8 @@ extern "C" int scan_sigmoid_focal_loss_backward(const float* logits, const int32
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && targets && d_logits, "sigmoid_focal_loss_backward: null pointer");
   const int64_t total = M * C;
-  hipLaunchKernelGGL(focal_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), logits, targets,
-                     d_losses, d_scale, total, C, gamma, alpha, d_logits);
+  const int grid = grid_for((total + 3) / 4, 256);
+  FOCAL_DISPATCH(focal_bwd_kernel, grid, logits, targets, d_losses, d_scale, total, C, gamma, alpha, d_logits);
   SCAN_LAUNCH_CHECK("focal_bwd");
   return 0;
 }
@@ -180,7 +278,7 @@ extern "C" int scan_iou_loss_forward(const float* pred, const float* target, con
   SCAN_CHECK_ARG(P >= 0 && out2, "iou_loss_forward: bad arguments");
   if (P == 0) return 0;
   SCAN_CHECK_ARG(pred && target, "iou_loss_forward: null input");
-  hipLaunchKernelGGL(iou_fwd_kernel, dim3(grid_for(P, 256)), dim3(256), 0, as_stream(stream), pred, target, weight, P,
+  hipLaunchKernelGGL(iou_fwd_kernel, dim3(grid_reduce(P, 256)), dim3(256), 0, as_stream(stream), pred, target, weight, P,
                      out2);
   SCAN_LAUNCH_CHECK("iou_fwd");
   return 0;
@@ -240,7 +338,7 @@ extern "C" int scan_bce_logits_forward(const float* logits, const float* targets
   SCAN_CHECK_ARG(M >= 0 && out2, "bce_logits_forward: bad arguments");
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits, "bce_logits_forward: null input");
-  hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), logits, targets,
+  hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_reduce(M, 256)), dim3(256), 0, as_stream(stream), logits, targets,
                      const_target, weight, w_stride, M, out2);
   SCAN_LAUNCH_CHECK("bce_fwd");
   return 0;
@@ -291,6 +389,43 @@ __global__ __launch_bounds__(256) void cka_fwd_kernel(const float* __restrict__ 
   }
 }
 
+// Cf == 8 (Cityscapes): a thread owns one float4 of logits = half a row, i.e. ALWAYS the same four classes (the grid
+// stride is even), so its eight partial sums stay in registers; the act-map row (9 floats, unaligned) is read by the two
+// lanes of a row as 4 + 4 scalars of one contiguous wave-wide segment.  Even / odd lanes are reduced separately.
+__global__ __launch_bounds__(256) void cka_fwd8_kernel(const float* __restrict__ logits, const float* __restrict__ act,
+                                                       int64_t M, float t, float* __restrict__ out) {
+  __shared__ float red[4][16];
+  float num[4] = {0.f, 0.f, 0.f, 0.f}, den[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t n4 = M * 2;
+  for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (int64_t)gridDim.x * blockDim.x) {
+    const float4 v = reinterpret_cast<const float4*>(logits)[q];
+    const float* a = act + (q >> 1) * 9 + 1 + (q & 1) * 4;
+    const float x[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float w = a[e];
+      const float l = fmaxf(x[e], 0.f) - x[e] * t + log1pf(expf(-fabsf(x[e])));
+      num[e] += l * w;
+      den[e] += w;
+    }
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+#pragma unroll
+    for (int off = 32; off >= 2; off >>= 1) {  // keeps lane parity: lane 0 <- even lanes, lane 1 <- odd lanes
+      num[e] += __shfl_down(num[e], off, 64);
+      den[e] += __shfl_down(den[e], off, 64);
+    }
+    if (lane < 2) {
+      red[wid][2 * (lane * 4 + e)] = num[e];       // class c = (lane & 1) * 4 + e
+      red[wid][2 * (lane * 4 + e) + 1] = den[e];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) atomicAdd(out + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
 __global__ __launch_bounds__(256) void cka_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ act,
                                                       int64_t M, int Cf, float t, const float* __restrict__ g,
                                                       float* __restrict__ d_logits) {
@@ -309,8 +444,13 @@ extern "C" int scan_cka_bce_forward(const float* logits, const float* act, int64
   SCAN_CHECK_ARG(M >= 0 && Cf > 0 && Cf <= CKA_MAXC && out, "cka_bce_forward: bad arguments (Cf=%d)", Cf);
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && act, "cka_bce_forward: null input");
-  hipLaunchKernelGGL(cka_fwd_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), logits, act, M, Cf,
-                     target, out);
+  if (Cf == 8 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
+    int g = grid_reduce(M * 2, 256);
+    hipLaunchKernelGGL(cka_fwd8_kernel, dim3(g), dim3(256), 0, as_stream(stream), logits, act, M, target, out);
+  } else {
+    hipLaunchKernelGGL(cka_fwd_kernel, dim3(grid_reduce(M, 256)), dim3(256), 0, as_stream(stream), logits, act, M, Cf,
+                       target, out);
+  }
   SCAN_LAUNCH_CHECK("cka_fwd");
   return 0;
 }
@@ -350,46 +490,72 @@ extern "C" int scan_scale(const float* x, float alpha, float* y, int64_t n, void
 // ------------------------------------------------------------------ softmax focal loss (alpha = 1)
 // layers/sigmoid_focal_loss_wbg.py:38-64:  p = softmax(z)[label] clamped at 1e-15; -(1-p)^g log p
 #define SFL_MAXK 16
-__global__ __launch_bounds__(256) void sfl_fwd_kernel(const float* __restrict__ logits,
-                                                      const int64_t* __restrict__ labels, int64_t M, int K,
-                                                      float gamma, float* __restrict__ loss_sum) {
+// Rows are K floats (36 B at K = 9): a lane reading its own row touches a new cache line every 3-4 lanes.  A block
+// therefore moves its 256 rows as ONE contiguous 256*K-float segment with coalesced dword accesses through LDS and each
+// lane then walks its row in LDS (stride K floats: conflict-free for odd K).
+template <bool BWD>
+__global__ __launch_bounds__(256) void sfl_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                  int64_t M, int K, float gamma, float d_scale,
+                                                  float* __restrict__ loss_sum, float* __restrict__ d_logits) {
+  __shared__ float rows[256 * SFL_MAXK];
   __shared__ float red[4];
+  const bool g2 = gamma == 2.0f;
   float acc = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
-    const float* z = logits + i * K;
-    float mx = z[0];
-    for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
-    float den = 0.f;
-    for (int k = 0; k < K; ++k) den += expf(z[k] - mx);
-    const int lab = (int)labels[i];
-    float p = expf(z[lab] - mx) / den;
-    p = fmaxf(p, 1e-15f);
-    acc += -powf(1.f - p, gamma) * logf(p);
-  }
-  const float s = block_sum_256(acc, red);
-  if (threadIdx.x == 0) atomicAdd(loss_sum, s);
-}
-
-__global__ __launch_bounds__(256) void sfl_bwd_kernel(const float* __restrict__ logits,
-                                                      const int64_t* __restrict__ labels, int64_t M, int K,
-                                                      float gamma, float d_scale, float* __restrict__ d_logits) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
-    const float* z = logits + i * K;
-    float e[SFL_MAXK];
-    float mx = z[0];
-    for (int k = 1; k < K; ++k) mx = fmaxf(mx, z[k]);
-    float den = 0.f;
-    for (int k = 0; k < K; ++k) {
-      e[k] = expf(z[k] - mx);
-      den += e[k];
+  const int64_t nblk = (M + 255) / 256;
+  for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int64_t r0 = b * 256;
+    const int nrow = (int)((M - r0 < 256) ? (M - r0) : 256);
+    const int nf = nrow * K;
+    const float* src = logits + r0 * K;
+    for (int j = threadIdx.x; j < nf; j += 256) rows[j] = src[j];
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < nrow) {
+      const float* z = rows + t * K;
+      float e[SFL_MAXK];
+      float mx = z[0];
+#pragma unroll
+      for (int k = 1; k < SFL_MAXK; ++k)
+        if (k < K) mx = fmaxf(mx, z[k]);
+      float den = 0.f;
+#pragma unroll
+      for (int k = 0; k < SFL_MAXK; ++k) {
+        e[k] = (k < K) ? expf(z[k] - mx) : 0.f;
+        den += e[k];
+      }
+      const int lab = (int)labels[r0 + t];
+      float el = 0.f;
+#pragma unroll
+      for (int k = 0; k < SFL_MAXK; ++k) el = (k == lab) ? e[k] : el;
+      if (!BWD) {
+        float p = el / den;
+        p = fmaxf(p, 1e-15f);
+        const float om = 1.f - p;
+        acc += -(g2 ? om * om : powf(om, gamma)) * logf(p);
+      } else {
+        const float inv = 1.f / den;
+        const float p = el * inv;
+        float dLdp = 0.f;  // clamp(min=1e-15) has zero gradient below the clamp
+        if (p >= 1e-15f) {
+          const float om = 1.f - p;
+          dLdp = g2 ? (2.f * om * logf(p) - om * om / p) : (gamma * powf(om, gamma - 1.f) * logf(p) - powf(om, gamma) / p);
+        }
+        const float c = dLdp * p * d_scale;
+#pragma unroll
+        for (int k = 0; k < SFL_MAXK; ++k)
+          if (k < K) rows[t * K + k] = c * ((k == lab ? 1.f : 0.f) - e[k] * inv);
+      }
     }
-    const int lab = (int)labels[i];
-    const float inv = 1.f / den;
-    const float p = e[lab] * inv;
-    float dLdp = 0.f;  // clamp(min=1e-15) has zero gradient below the clamp
-    if (p >= 1e-15f) dLdp = gamma * powf(1.f - p, gamma - 1.f) * logf(p) - powf(1.f - p, gamma) / p;
-    const float c = dLdp * p * d_scale;
-    for (int k = 0; k < K; ++k) d_logits[i * K + k] = c * ((k == lab ? 1.f : 0.f) - e[k] * inv);
+    __syncthreads();
+    if (BWD) {
+      float* dst = d_logits + r0 * K;
+      for (int j = threadIdx.x; j < nf; j += 256) dst[j] = rows[j];
+      __syncthreads();
+    }
+  }
+  if (!BWD) {
+    const float sum = block_sum_256(acc, red);
+    if (threadIdx.x == 0) atomicAdd(loss_sum, sum);
   }
 }
 
@@ -398,8 +564,10 @@ extern "C" int scan_softmax_focal_forward(const float* logits, const int64_t* la
   SCAN_CHECK_ARG(M >= 0 && K > 0 && K <= SFL_MAXK && loss_sum, "softmax_focal_forward: bad arguments (K=%d)", K);
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && labels, "softmax_focal_forward: null input");
-  hipLaunchKernelGGL(sfl_fwd_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), logits, labels, M, K,
-                     gamma, loss_sum);
+  int64_t g = (M + 255) / 256;
+  if (g > 1024) g = 1024;
+  hipLaunchKernelGGL(sfl_kernel<false>, dim3((int)g), dim3(256), 0, as_stream(stream), logits, labels, M, K, gamma, 0.f,
+                     loss_sum, (float*)nullptr);
   SCAN_LAUNCH_CHECK("sfl_fwd");
   return 0;
 }
@@ -409,8 +577,10 @@ extern "C" int scan_softmax_focal_backward(const float* logits, const int64_t* l
   SCAN_CHECK_ARG(M >= 0 && K > 0 && K <= SFL_MAXK, "softmax_focal_backward: bad arguments (K=%d)", K);
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && labels && d_logits, "softmax_focal_backward: null pointer");
-  hipLaunchKernelGGL(sfl_bwd_kernel, dim3(grid_for(M, 256)), dim3(256), 0, as_stream(stream), logits, labels, M, K,
-                     gamma, d_scale, d_logits);
+  int64_t g = (M + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(sfl_kernel<true>, dim3((int)g), dim3(256), 0, as_stream(stream), logits, labels, M, K, gamma,
+                     d_scale, (float*)nullptr, d_logits);
   SCAN_LAUNCH_CHECK("sfl_bwd");
   return 0;
 }

@@ -1,0 +1,89 @@
+#!/usr/bin/env python
+"""A/B timing of the 3x3 conv kernels on the layer shapes of the bench workload (4 frames of 1024x2048 in the paired
+step), with HIP events on the launch stream, variants selected through scan_tune.  Each variant's output is compared
+with the first one's (they must agree bit for bit: the K order per output element is the same).
+
+    python tools/conv_bench.py [--reps 5] [--variants conv_bn256=0,conv_bn256=1]
+"""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from scan_amd import _lib, ops  # noqa: E402
+
+# (name, n_images, level sizes, Cin, Cout)
+SHAPES = [
+    ("towers 256->256, P3..P7, 4 frames", 4, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)], 256, 256),
+    ("towers 256->256, P3..P7, 2 frames (FCOS)", 2, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)], 256, 256),
+    ("conv3_x 256->256 @256x512, 4 frames", 4, [(256, 512)], 256, 256),
+    ("conv4_x 512->512 @128x256, 4 frames", 4, [(128, 256)], 512, 512),
+    ("conv5_x 512->512 @64x128, 4 frames", 4, [(64, 128)], 512, 512),
+    ("conv2_2 128->128 @512x1024, 4 frames", 4, [(512, 1024)], 128, 128),
+    ("dis P3 264->1024, 4 frames", 4, [(128, 256)], 264, 1024),
+    ("head_out 268->256 pyramid, 4 frames", 4, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)], 268, 256),
+]
+
+
+def run(shape_def, reps, dev):
+    name, n, sizes, cin, cout = shape_def
+    shape = ops.PyramidShape(n, sizes)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((shape.rows, ops.pad4(cin)), device=dev, generator=g)
+    w = (torch.randn((cout, cin, 3, 3), device=dev, generator=g) * 0.05).contiguous(memory_format=torch.channels_last)
+    b = torch.randn((cout,), device=dev, generator=g)
+    flops = 2.0 * shape.rows * cout * 9 * cin
+
+    def fwd():
+        with torch.no_grad():
+            return ops.conv2d(x, w, b, shape, 3, 1)
+
+    fwd()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        y = fwd()
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / reps
+    return y, us, flops / us * 1e-6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--variants", default="conv_bn256=0,conv_bn256=1")
+    a = ap.parse_args()
+    dev = torch.device("cuda:0")
+    variants = [v.split("=") for v in a.variants.split(",")]
+    for sd in SHAPES:
+        ref = None
+        line = "%-44s" % sd[0]
+        best = {}
+        for rnd in range(a.rounds):  # A B A B ...: clock / cache state drifts show up as round-to-round spread
+            for key, val in variants:
+                old = _lib.query("scan_tune", key.encode(), int(val))
+                assert old >= 0, key
+                y, us, tf = run(sd, a.reps, dev)
+                _lib.query("scan_tune", key.encode(), old)
+                if ref is None:
+                    ref = y
+                same = torch.equal(ref, y)
+                b = best.setdefault((key, val), [])
+                b.append(us)
+                if not same:
+                    line += " MISMATCH(%s=%s) %.3g" % (key, val, (ref - y).abs().max().item())
+        flops = 2.0 * ops.PyramidShape(sd[1], sd[2]).rows * sd[4] * 9 * sd[3]
+        for (key, val), us in best.items():
+            line += "  %s=%s: %s us -> %6.1f TF" % (key, val, "/".join("%.0f" % u for u in us), flops / min(us) * 1e-6)
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    main()

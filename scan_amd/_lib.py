@@ -10,7 +10,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscan_hip.so")
+# SCAN_HIP_LIB: an alternative build of the same library (timing experiments, see csrc/Makefile); default = the product
+LIB_PATH = os.environ.get("SCAN_HIP_LIB") or os.path.join(_HERE, "libscan_hip.so")
 
 MAX_LEVELS = 5
 NMS_MAX = 8192

@@ -23,7 +23,25 @@
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#ifdef SCAN_EXP_MFMA16
+// TIMING EXPERIMENT ONLY (wrong results): every v_mfma_f32_32x32x16_bf16 is replaced by two v_mfma_f32_16x16x32_bf16 on
+// 4-register slices of the same accumulator -- same MFMA cycles, same LDS traffic, same registers -- to see what clock
+// the chip holds with the 16x16 shape (MI355X_MICROARCH.md, DVFS give-back item 7) before rewriting the fragment layout.
+__device__ __forceinline__ f32x16 mma_exp(bf16x8 a, bf16x8 b, f32x16 c) {
+  f32x4v p0 = __builtin_shufflevector(c, c, 0, 1, 2, 3), p1 = __builtin_shufflevector(c, c, 4, 5, 6, 7);
+  p0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, p0, 0, 0, 0);
+  p1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, p1, 0, 0, 0);
+  c[0] = p0[0]; c[1] = p0[1]; c[2] = p0[2]; c[3] = p0[3];
+  c[4] = p1[0]; c[5] = p1[1]; c[6] = p1[2]; c[7] = p1[3];
+  return c;
+}
+#define SCAN_MMA(a, b, c) mma_exp(a, b, c)
+#else
+#define SCAN_MMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define TW 16
@@ -226,9 +244,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
             const bf16x8 blv = *reinterpret_cast<const bf16x8*>(bl + tn * 32 * LROW + 16 * s);
 #pragma unroll
             for (int tm = 0; tm < TM; ++tm) {
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bhv, acc[tm][tn], 0, 0, 0);
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], blv, acc[tm][tn], 0, 0, 0);
-              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bhv, acc[tm][tn], 0, 0, 0);
+              acc[tm][tn] = SCAN_MMA(al[tm], bhv, acc[tm][tn]);
+              acc[tm][tn] = SCAN_MMA(ah[tm], blv, acc[tm][tn]);
+              acc[tm][tn] = SCAN_MMA(ah[tm], bhv, acc[tm][tn]);
             }
           }
         }
@@ -251,9 +269,9 @@ __global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
         for (int tm = 0; tm < TM; ++tm)
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn) {
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bhv[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], blv[tn], acc[tm][tn], 0, 0, 0);
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bhv[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = SCAN_MMA(al[tm], bhv[tn], acc[tm][tn]);
+            acc[tm][tn] = SCAN_MMA(ah[tm], blv[tn], acc[tm][tn]);
+            acc[tm][tn] = SCAN_MMA(ah[tm], bhv[tn], acc[tm][tn]);
           }
       }
     }

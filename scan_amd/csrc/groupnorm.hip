@@ -8,40 +8,55 @@
 #include "common.h"
 
 #define GN_C 256
-#define GN_RPB 128  // rows per block (4 waves x 32 rows)
+#define GN_RPB 256  // rows per block (4 waves x 64 rows, four rows in flight per wave)
+#define GN_REP 8    // replicas of the per-channel fp64 sums (block b adds into replica b % 8: 8x fewer adders per address)
 
-// blockIdx.y = level*N + image, blockIdx.x = row chunk inside that image
+// Compact 1-D grid: block -> (level, image, row chunk) through a per-level prefix table, so small levels do not
+// launch empty blocks (a 2-D grid sized by the largest level wasted 3 of 4 blocks on a five-level pyramid).
+struct GnTab {
+  int blk_off[SCAN_MAX_LEVELS + 1];  // first block of each level
+  int per_img[SCAN_MAX_LEVELS];      // blocks per image on that level
+};
 struct GnBlock {
   int64_t row0;  // first pyramid row of this block
-  int rows;      // rows in this block (0 => nothing to do)
+  int rows;      // rows in this block
   int il;        // image-level index
   int hw;
 };
-__device__ __forceinline__ GnBlock gn_block(const scan_pyramid_t& d) {
+__device__ __forceinline__ GnBlock gn_block(const scan_pyramid_t& d, const GnTab& t) {
   GnBlock b;
-  b.il = blockIdx.y;
-  const int lvl = b.il / d.n_images, n = b.il - lvl * d.n_images;
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+    if (i < d.n_levels && (int)blockIdx.x >= t.blk_off[i]) lvl = i;
+  const int r = blockIdx.x - t.blk_off[lvl];
+  const int n = r / t.per_img[lvl], chunk = r - n * t.per_img[lvl];
+  b.il = lvl * d.n_images + n;
   b.hw = d.h[lvl] * d.w[lvl];
-  const int64_t start = (int64_t)blockIdx.x * GN_RPB;
-  b.rows = 0;
-  b.row0 = 0;
-  if (start < b.hw) {
-    b.rows = (int)((b.hw - start) < GN_RPB ? (b.hw - start) : GN_RPB);
-    b.row0 = d.row_off[lvl] + (int64_t)n * b.hw + start;
-  }
+  const int64_t start = (int64_t)chunk * GN_RPB;
+  b.rows = (int)((b.hw - start) < GN_RPB ? (b.hw - start) : GN_RPB);
+  b.row0 = d.row_off[lvl] + (int64_t)n * b.hw + start;
   return b;
 }
 
-__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, scan_pyramid_t d, int G,
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__ x, scan_pyramid_t d, GnTab tab, int G,
                                                        double* __restrict__ ws) {
   __shared__ double red[4][32][2];
-  const GnBlock b = gn_block(d);
+  const GnBlock b = gn_block(d, tab);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   double s = 0.0, q = 0.0;
-  for (int r = wid; r < b.rows; r += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(x + (b.row0 + r) * GN_C + 4 * lane);
-    s += (double)((v.x + v.y) + (v.z + v.w));
-    q += (double)((v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w));
+  const float* base = x + b.row0 * GN_C + 4 * lane;
+  for (int r = wid; r < b.rows; r += 16) {  // rows r, r+4, r+8, r+12 of this wave: four loads in flight
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      v[u] = (r + 4 * u < b.rows) ? *reinterpret_cast<const float4*>(base + (int64_t)(r + 4 * u) * GN_C)
+                                  : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      s += (double)((v[u].x + v[u].y) + (v[u].z + v[u].w));
+      q += (double)((v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w));
+    }
   }
   // 8 channels per group = 2 adjacent lanes
   s += __shfl_xor(s, 1, 64);
@@ -51,7 +66,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const float* __restrict__
     red[wid][lane >> 1][1] = q;
   }
   __syncthreads();
-  if (threadIdx.x < 32 && b.rows > 0) {
+  if (threadIdx.x < 32) {
     const int g = threadIdx.x;
     const double ss = red[0][g][0] + red[1][g][0] + red[2][g][0] + red[3][g][0];
     const double qq = red[0][g][1] + red[1][g][1] + red[2][g][1] + red[3][g][1];
@@ -80,44 +95,66 @@ __global__ void gn_stats_final_kernel(const double* __restrict__ ws, scan_pyrami
   stats[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, scan_pyramid_t d, int G,
+__device__ __forceinline__ float4 gn_affine4(const float4 v, float mean, float rstd, const float4 ga, const float4 be) {
+  float4 o;
+  o.x = gn_affine(v.x, mean, rstd, ga.x, be.x);
+  o.y = gn_affine(v.y, mean, rstd, ga.y, be.y);
+  o.z = gn_affine(v.z, mean, rstd, ga.z, be.z);
+  o.w = gn_affine(v.w, mean, rstd, ga.w, be.w);
+  return o;
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, scan_pyramid_t d, GnTab tab, int G,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int relu,
                                                        float* __restrict__ y) {
-  const GnBlock b = gn_block(d);
+  const GnBlock b = gn_block(d, tab);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 1;
   const float mean = stats[((int64_t)b.il * G + g) * 2], rstd = stats[((int64_t)b.il * G + g) * 2 + 1];
   const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * lane);
   const float4 be = *reinterpret_cast<const float4*>(beta + 4 * lane);
-  for (int r = wid; r < b.rows; r += 4) {
-    const int64_t off = (b.row0 + r) * GN_C + 4 * lane;
-    const float4 v = *reinterpret_cast<const float4*>(x + off);
-    float4 o;
-    o.x = gn_affine(v.x, mean, rstd, ga.x, be.x);
-    o.y = gn_affine(v.y, mean, rstd, ga.y, be.y);
-    o.z = gn_affine(v.z, mean, rstd, ga.z, be.z);
-    o.w = gn_affine(v.w, mean, rstd, ga.w, be.w);
-    if (relu) {
-      o.x = fmaxf(o.x, 0.f);
-      o.y = fmaxf(o.y, 0.f);
-      o.z = fmaxf(o.z, 0.f);
-      o.w = fmaxf(o.w, 0.f);
+  const int64_t base = b.row0 * GN_C + 4 * lane;
+  for (int r = wid; r < b.rows; r += 16) {
+    float4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (r + 4 * u < b.rows) v[u] = *reinterpret_cast<const float4*>(x + base + (int64_t)(r + 4 * u) * GN_C);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + 4 * u < b.rows) {
+        float4 o = gn_affine4(v[u], mean, rstd, ga, be);
+        if (relu) {
+          o.x = fmaxf(o.x, 0.f);
+          o.y = fmaxf(o.y, 0.f);
+          o.z = fmaxf(o.z, 0.f);
+          o.w = fmaxf(o.w, 0.f);
+        }
+        *reinterpret_cast<float4*>(y + base + (int64_t)(r + 4 * u) * GN_C) = o;
+      }
     }
-    *reinterpret_cast<float4*>(y + off) = o;
   }
 }
 
 // backward pass 1: group sums S1 = sum dyh*gamma, S2 = sum dyh*gamma*xhat; channel sums dgamma, dbeta
+__device__ __forceinline__ float4 gn_masked(const float4 xv, float4 gv, float mean, float rstd, const float4 ga,
+                                            const float4 be) {
+  gv.x = gn_affine(xv.x, mean, rstd, ga.x, be.x) > 0.f ? gv.x : 0.f;
+  gv.y = gn_affine(xv.y, mean, rstd, ga.y, be.y) > 0.f ? gv.y : 0.f;
+  gv.z = gn_affine(xv.z, mean, rstd, ga.z, be.z) > 0.f ? gv.z : 0.f;
+  gv.w = gn_affine(xv.w, mean, rstd, ga.w, be.w) > 0.f ? gv.w : 0.f;
+  return gv;
+}
+
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ beta,
-                                                            const float* __restrict__ dy, scan_pyramid_t d, int G,
-                                                            const float* __restrict__ stats,
+                                                            const float* __restrict__ dy, scan_pyramid_t d, GnTab tab,
+                                                            int G, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, int relu,
                                                             double* __restrict__ ws_g, double* __restrict__ ws_c) {
   __shared__ double redg[4][32][2];
-  __shared__ double redc[4][GN_C][2];
-  const GnBlock b = gn_block(d);
+  __shared__ float redc[4][GN_C][2];
+  const GnBlock b = gn_block(d, tab);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 1;
   const float mean = stats[((int64_t)b.il * G + g) * 2], rstd = stats[((int64_t)b.il * G + g) * 2 + 1];
@@ -125,29 +162,33 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   const float4 be = relu ? *reinterpret_cast<const float4*>(beta + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
   double s1 = 0, s2 = 0;
   float dg[4] = {0, 0, 0, 0}, db[4] = {0, 0, 0, 0};
-  for (int r = wid; r < b.rows; r += 4) {
-    const int64_t off = (b.row0 + r) * GN_C + 4 * lane;
-    const float4 xv = *reinterpret_cast<const float4*>(x + off);
-    float4 gv = *reinterpret_cast<const float4*>(dy + off);
-    if (relu) {
-      gv.x = gn_affine(xv.x, mean, rstd, ga.x, be.x) > 0.f ? gv.x : 0.f;
-      gv.y = gn_affine(xv.y, mean, rstd, ga.y, be.y) > 0.f ? gv.y : 0.f;
-      gv.z = gn_affine(xv.z, mean, rstd, ga.z, be.z) > 0.f ? gv.z : 0.f;
-      gv.w = gn_affine(xv.w, mean, rstd, ga.w, be.w) > 0.f ? gv.w : 0.f;
+  const int64_t base = b.row0 * GN_C + 4 * lane;
+  for (int r = wid; r < b.rows; r += 16) {
+    float4 xv[4], gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool ok = r + 4 * u < b.rows;
+      const int64_t off = base + (int64_t)(r + 4 * u) * GN_C;
+      xv[u] = ok ? *reinterpret_cast<const float4*>(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gv[u] = ok ? *reinterpret_cast<const float4*>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    const float h0 = (xv.x - mean) * rstd, h1 = (xv.y - mean) * rstd, h2 = (xv.z - mean) * rstd,
-                h3 = (xv.w - mean) * rstd;
-    dg[0] += gv.x * h0;
-    dg[1] += gv.y * h1;
-    dg[2] += gv.z * h2;
-    dg[3] += gv.w * h3;
-    db[0] += gv.x;
-    db[1] += gv.y;
-    db[2] += gv.z;
-    db[3] += gv.w;
-    const float a0 = gv.x * ga.x, a1 = gv.y * ga.y, a2 = gv.z * ga.z, a3 = gv.w * ga.w;
-    s1 += (double)((a0 + a1) + (a2 + a3));
-    s2 += (double)((a0 * h0 + a1 * h1) + (a2 * h2 + a3 * h3));
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float4 gg = relu ? gn_masked(xv[u], gv[u], mean, rstd, ga, be) : gv[u];
+      const float h0 = (xv[u].x - mean) * rstd, h1 = (xv[u].y - mean) * rstd, h2 = (xv[u].z - mean) * rstd,
+                  h3 = (xv[u].w - mean) * rstd;
+      dg[0] += gg.x * h0;
+      dg[1] += gg.y * h1;
+      dg[2] += gg.z * h2;
+      dg[3] += gg.w * h3;
+      db[0] += gg.x;
+      db[1] += gg.y;
+      db[2] += gg.z;
+      db[3] += gg.w;
+      const float a0 = gg.x * ga.x, a1 = gg.y * ga.y, a2 = gg.z * ga.z, a3 = gg.w * ga.w;
+      s1 += (double)((a0 + a1) + (a2 + a3));
+      s2 += (double)((a0 * h0 + a1 * h1) + (a2 * h2 + a3 * h3));
+    }
   }
   s1 += __shfl_xor(s1, 1, 64);
   s2 += __shfl_xor(s2, 1, 64);
@@ -157,28 +198,27 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
   }
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    redc[wid][4 * lane + e][0] = (double)dg[e];
-    redc[wid][4 * lane + e][1] = (double)db[e];
+    redc[wid][4 * lane + e][0] = dg[e];
+    redc[wid][4 * lane + e][1] = db[e];
   }
   __syncthreads();
-  if (b.rows > 0) {
-    if (threadIdx.x < 32) {
-      const int gg = threadIdx.x;
-      atomicAdd(&ws_g[((int64_t)b.il * G + gg) * 2 + 0], redg[0][gg][0] + redg[1][gg][0] + redg[2][gg][0] + redg[3][gg][0]);
-      atomicAdd(&ws_g[((int64_t)b.il * G + gg) * 2 + 1], redg[0][gg][1] + redg[1][gg][1] + redg[2][gg][1] + redg[3][gg][1]);
-    }
-    const int c = threadIdx.x;  // 256 threads == 256 channels
-    atomicAdd(&ws_c[2 * c + 0], redc[0][c][0] + redc[1][c][0] + redc[2][c][0] + redc[3][c][0]);
-    atomicAdd(&ws_c[2 * c + 1], redc[0][c][1] + redc[1][c][1] + redc[2][c][1] + redc[3][c][1]);
+  if (threadIdx.x < 32) {
+    const int gg = threadIdx.x;
+    atomicAdd(&ws_g[((int64_t)b.il * G + gg) * 2 + 0], redg[0][gg][0] + redg[1][gg][0] + redg[2][gg][0] + redg[3][gg][0]);
+    atomicAdd(&ws_g[((int64_t)b.il * G + gg) * 2 + 1], redg[0][gg][1] + redg[1][gg][1] + redg[2][gg][1] + redg[3][gg][1]);
   }
+  const int c = threadIdx.x;  // 256 threads == 256 channels
+  double* rep = ws_c + (int64_t)(blockIdx.x % GN_REP) * 2 * GN_C;
+  atomicAdd(&rep[2 * c + 0], ((double)redc[0][c][0] + (double)redc[1][c][0]) + ((double)redc[2][c][0] + (double)redc[3][c][0]));
+  atomicAdd(&rep[2 * c + 1], ((double)redc[0][c][1] + (double)redc[1][c][1]) + ((double)redc[2][c][1] + (double)redc[3][c][1]));
 }
 
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ beta,
-                                                           const float* __restrict__ dy, scan_pyramid_t d, int G,
-                                                           const float* __restrict__ stats,
+                                                           const float* __restrict__ dy, scan_pyramid_t d, GnTab tab,
+                                                           int G, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, int relu,
                                                            const double* __restrict__ ws_g, float* __restrict__ dx) {
-  const GnBlock b = gn_block(d);
+  const GnBlock b = gn_block(d, tab);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 1;
   const float mean = stats[((int64_t)b.il * G + g) * 2], rstd = stats[((int64_t)b.il * G + g) * 2 + 1];
@@ -187,29 +227,42 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
   const float S2 = (float)ws_g[((int64_t)b.il * G + g) * 2 + 1] * inv_cnt;
   const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * lane);
   const float4 be = relu ? *reinterpret_cast<const float4*>(beta + 4 * lane) : make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int r = wid; r < b.rows; r += 4) {
-    const int64_t off = (b.row0 + r) * GN_C + 4 * lane;
-    const float4 xv = *reinterpret_cast<const float4*>(x + off);
-    float4 gv = *reinterpret_cast<const float4*>(dy + off);
-    if (relu) {
-      gv.x = gn_affine(xv.x, mean, rstd, ga.x, be.x) > 0.f ? gv.x : 0.f;
-      gv.y = gn_affine(xv.y, mean, rstd, ga.y, be.y) > 0.f ? gv.y : 0.f;
-      gv.z = gn_affine(xv.z, mean, rstd, ga.z, be.z) > 0.f ? gv.z : 0.f;
-      gv.w = gn_affine(xv.w, mean, rstd, ga.w, be.w) > 0.f ? gv.w : 0.f;
+  const int64_t base = b.row0 * GN_C + 4 * lane;
+  for (int r = wid; r < b.rows; r += 16) {
+    float4 xv[4], gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + 4 * u < b.rows) {
+        const int64_t off = base + (int64_t)(r + 4 * u) * GN_C;
+        xv[u] = *reinterpret_cast<const float4*>(x + off);
+        gv[u] = *reinterpret_cast<const float4*>(dy + off);
+      }
     }
-    float4 o;
-    o.x = rstd * (gv.x * ga.x - (S1 + (xv.x - mean) * rstd * S2));
-    o.y = rstd * (gv.y * ga.y - (S1 + (xv.y - mean) * rstd * S2));
-    o.z = rstd * (gv.z * ga.z - (S1 + (xv.z - mean) * rstd * S2));
-    o.w = rstd * (gv.w * ga.w - (S1 + (xv.w - mean) * rstd * S2));
-    *reinterpret_cast<float4*>(dx + off) = o;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (r + 4 * u < b.rows) {
+        const float4 gg = relu ? gn_masked(xv[u], gv[u], mean, rstd, ga, be) : gv[u];
+        float4 o;
+        o.x = rstd * (gg.x * ga.x - (S1 + (xv[u].x - mean) * rstd * S2));
+        o.y = rstd * (gg.y * ga.y - (S1 + (xv[u].y - mean) * rstd * S2));
+        o.z = rstd * (gg.z * ga.z - (S1 + (xv[u].z - mean) * rstd * S2));
+        o.w = rstd * (gg.w * ga.w - (S1 + (xv[u].w - mean) * rstd * S2));
+        *reinterpret_cast<float4*>(dx + base + (int64_t)(r + 4 * u) * GN_C) = o;
+      }
+    }
   }
 }
 
 __global__ void gn_bwd_param_final_kernel(const double* __restrict__ ws_c, float* __restrict__ dgamma,
                                           float* __restrict__ dbeta, int accumulate) {
   const int c = threadIdx.x;
-  const float a = (float)ws_c[2 * c], b = (float)ws_c[2 * c + 1];
+  double sa = 0.0, sb = 0.0;
+#pragma unroll
+  for (int r = 0; r < GN_REP; ++r) {
+    sa += ws_c[(int64_t)r * 2 * GN_C + 2 * c];
+    sb += ws_c[(int64_t)r * 2 * GN_C + 2 * c + 1];
+  }
+  const float a = (float)sa, b = (float)sb;
   dgamma[c] = accumulate ? dgamma[c] + a : a;
   dbeta[c] = accumulate ? dbeta[c] + b : b;
 }
@@ -219,15 +272,22 @@ static int gn_check(const scan_pyramid_t* d, int C, int G, const char* who) {
   SCAN_CHECK_ARG(C == GN_C && G == 32, "%s: only C=256, G=32 is built (got C=%d G=%d)", who, C, G);
   return 0;
 }
-static dim3 gn_grid(const scan_pyramid_t* d) {
-  int maxhw = 1;
-  for (int l = 0; l < d->n_levels; ++l)
-    if (d->h[l] * d->w[l] > maxhw) maxhw = d->h[l] * d->w[l];
-  return dim3((maxhw + GN_RPB - 1) / GN_RPB, d->n_levels * d->n_images);
+static int gn_tab(const scan_pyramid_t* d, GnTab* t) {
+  t->blk_off[0] = 0;
+  for (int l = 0; l < SCAN_MAX_LEVELS; ++l) {
+    if (l < d->n_levels) {
+      t->per_img[l] = (d->h[l] * d->w[l] + GN_RPB - 1) / GN_RPB;
+      t->blk_off[l + 1] = t->blk_off[l] + d->n_images * t->per_img[l];
+    } else {
+      t->per_img[l] = 1;
+      t->blk_off[l + 1] = t->blk_off[l];
+    }
+  }
+  return t->blk_off[d->n_levels];
 }
 
 extern "C" int64_t scan_groupnorm_ws_floats(const scan_pyramid_t* d, int32_t C, int32_t G) {
-  return 2 * ((int64_t)d->n_levels * d->n_images * G * 2 + (int64_t)C * 2);
+  return 2 * ((int64_t)d->n_levels * d->n_images * G * 2 + (int64_t)C * 2 * GN_REP);
 }
 
 extern "C" int scan_groupnorm_stats(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G, float eps,
@@ -241,7 +301,9 @@ extern "C" int scan_groupnorm_stats(const float* x, const scan_pyramid_t* d, int
     scan_set_error("groupnorm_stats: memset failed");
     return -2;
   }
-  hipLaunchKernelGGL(gn_stats_kernel, gn_grid(d), dim3(256), 0, st, x, *d, G, wsd);
+  GnTab tab;
+  const int nblk = gn_tab(d, &tab);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nblk), dim3(256), 0, st, x, *d, tab, G, wsd);
   SCAN_LAUNCH_CHECK("gn_stats");
   hipLaunchKernelGGL(gn_stats_final_kernel, dim3((total + 255) / 256), dim3(256), 0, st, wsd, *d, G, eps, stats);
   SCAN_LAUNCH_CHECK("gn_stats_final");
@@ -265,7 +327,9 @@ extern "C" int scan_groupnorm_relu_forward(const float* x, const scan_pyramid_t*
                                            float* y, void* stream) {
   if (gn_check(d, C, G, "groupnorm_relu_forward")) return -1;
   SCAN_CHECK_ARG(x && stats && gamma && beta && y, "groupnorm_relu_forward: null pointer");
-  hipLaunchKernelGGL(gn_apply_kernel, gn_grid(d), dim3(256), 0, as_stream(stream), x, *d, G, stats, gamma, beta, relu, y);
+  GnTab tab;
+  const int nblk = gn_tab(d, &tab);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), x, *d, tab, G, stats, gamma, beta, relu, y);
   SCAN_LAUNCH_CHECK("gn_apply");
   return 0;
 }
@@ -281,13 +345,15 @@ extern "C" int scan_groupnorm_relu_backward(const float* x, const float* beta, c
   double* ws_g = reinterpret_cast<double*>(ws);
   const int64_t ng = (int64_t)d->n_levels * d->n_images * G * 2;
   double* ws_c = ws_g + ng;
-  if (hipMemsetAsync(ws_g, 0, sizeof(double) * (ng + 2 * C), st) != hipSuccess) {
+  if (hipMemsetAsync(ws_g, 0, sizeof(double) * (ng + 2 * C * GN_REP), st) != hipSuccess) {
     scan_set_error("groupnorm_relu_backward: memset failed");
     return -2;
   }
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, gn_grid(d), dim3(256), 0, st, x, beta, dy, *d, G, stats, gamma, relu, ws_g, ws_c);
+  GnTab tab;
+  const int nblk = gn_tab(d, &tab);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, x, beta, dy, *d, tab, G, stats, gamma, relu, ws_g, ws_c);
   SCAN_LAUNCH_CHECK("gn_bwd_reduce");
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, gn_grid(d), dim3(256), 0, st, x, beta, dy, *d, G, stats, gamma, relu, ws_g, dx);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, x, beta, dy, *d, tab, G, stats, gamma, relu, ws_g, dx);
   SCAN_LAUNCH_CHECK("gn_bwd_apply");
   hipLaunchKernelGGL(gn_bwd_param_final_kernel, dim3(1), dim3(GN_C), 0, st, ws_c, dgamma, dbeta, accumulate);
   SCAN_LAUNCH_CHECK("gn_bwd_param_final");

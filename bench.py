@@ -57,26 +57,26 @@ def pmc_traffic(kernel_name):
 
 
 # timer record name (scan_amd/ops.py) -> kernel symbol as rocprofv3 lists it: forward and data-gradient launches of
-# a conv are the SAME kernel (dgrad = forward on dY with flipped/transposed weights)
-SYMBOL = {"conv3x3_bf16x3_fwd_bn128": "conv3x3_bf16x3_kernel<128,16,512,3>",
-          "conv3x3_bf16x3_dgrad_bn128": "conv3x3_bf16x3_kernel<128,16,512,3>",
-          "conv3x3_bf16x3_fwd_bn64": "conv3x3_bf16x3_kernel<64,8,256,3>",
-          "conv3x3_bf16x3_dgrad_bn64": "conv3x3_bf16x3_kernel<64,8,256,3>",
-          "conv1x1_bf16x3_fwd_bn128": "conv3x3_bf16x3_kernel<128,16,512,1>",
-          "conv1x1_bf16x3_dgrad_bn128": "conv3x3_bf16x3_kernel<128,16,512,1>",
-          "conv1x1_bf16x3_fwd_bn64": "conv3x3_bf16x3_kernel<64,8,256,1>",
-          "conv1x1_bf16x3_dgrad_bn64": "conv3x3_bf16x3_kernel<64,8,256,1>",
-          "conv1x1_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel<1,S>",
-          "conv3x3_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel<3,1>",
-          "conv_smallcin_bf16x3": "conv_smallcin_kernel",
-          "conv_igemm_fwd": "conv_igemm_kernel<0,4>", "conv_igemm_dgrad": "conv_igemm_kernel<1,4>",
-          "conv_wgrad": "conv_wgrad_kernel"}
+# a conv are the SAME kernel (dgrad = forward on dY with flipped/transposed weights); the _bnNNN suffix is the
+# output-channel tile of the instance the launch took (scan_conv3x3_bf16x3_instance)
+def symbol_of(name):
+    import re
+    m = re.match(r"conv(3x3|1x1)_bf16x3_(fwd|dgrad)_bn(\d+)$", name)
+    if m:
+        bn = int(m.group(3))
+        th, nt = (8, 256) if bn == 64 else (16, 512)
+        return "conv_bf16x3_v2_kernel<%d,%d,%d,%d>" % (bn, th, nt, 3 if m.group(1) == "3x3" else 1)
+    return {"conv1x1_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel<1,S>",
+            "conv3x3_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel<3,1>",
+            "conv_smallcin_bf16x3": "conv_smallcin_kernel",
+            "conv_igemm_fwd": "conv_igemm_kernel<0,4>", "conv_igemm_dgrad": "conv_igemm_kernel<1,4>",
+            "conv_wgrad": "conv_wgrad_kernel"}.get(name, name)
 
 
 def by_symbol(ksum):
     out = {}
     for name, r in ksum.items():
-        g = out.setdefault(SYMBOL.get(name, name), {"launches": 0, "total_ms": 0.0, "flops": 0.0})
+        g = out.setdefault(symbol_of(name), {"launches": 0, "total_ms": 0.0, "flops": 0.0})
         g["launches"] += r["launches"]
         g["total_ms"] += r["total_ms"]
         g["flops"] += r["flops"]

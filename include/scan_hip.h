@@ -43,8 +43,14 @@ int scan_abi_version(void);
 /* Tuning knob for A/B measurements and tests (no reference counterpart): scan_tune(key, value) sets an integer
  * launch-selection parameter and returns its previous value, -1 for an unknown key.
  *   "conv_bn256"  1 (default): 3x3 convs whose output channels are a multiple of 256 use 256-channel tiles
- *                 when the launch keeps >= 2 workgroups per CU; 0: always 128-channel tiles (same results). */
+ *                 when the launch keeps >= 2 workgroups per CU; 0: always 128-channel tiles (same results).
+ *   "conv_v2"     1 (default): bf16x3 forward / data-gradient convs run on the v_mfma_f32_16x16x32_bf16 kernel;
+ *                 0: on the v_mfma_f32_32x32x16_bf16 kernel (same arithmetic, different summation order inside a
+ *                 32-channel chunk). */
 int scan_tune(const char* key, int value);
+
+/* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels. */
+int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout);
 
 /* ---- SigmoidFocalLoss  (replaces _C.sigmoid_focalloss_forward / _backward,
  *      csrc/SigmoidFocalLoss.h:10-41, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-187) ----

@@ -378,6 +378,19 @@ __global__ void weight_split_kernel(const float* __restrict__ w, int O, int T, i
 // tuning switch (tests / A-B measurements): 0 keeps every launch on the 128-channel instance
 int g_scan_conv_bn256 = 1;
 #define g_bn256 g_scan_conv_bn256
+// 1 (default): forward / data-gradient launches go to the 16x16x32-MFMA kernel (conv_bf16x3_v2.hip); 0: the 32x32x16
+// kernel of this file (kept for A/B measurements and as the reference the second kernel is tested against)
+int g_scan_conv_v2 = 1;
+int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                             int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns,
+                             int32_t relu, void* stream, double* gn_ws);
+int conv1x1_bf16x3_v2_launch(const float* x, const scan_pyramid_t* xd, int32_t Cs, const void* wh, const void* wl,
+                             int32_t Csw, const float* bias, const float* mask, float* y, const scan_pyramid_t* yd,
+                             int32_t Nout, int32_t Ns, int32_t relu, int32_t map, void* stream);
+static inline bool v2_ok(const void* y, const void* mask, int32_t Ns) {
+  return g_scan_conv_v2 && (Ns & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+         (reinterpret_cast<uintptr_t>(mask) & 15) == 0;
+}
 
 static void make_tiles(const scan_pyramid_t* d, TileTab* tt, int TH) {
   tt->tile_off[0] = 0;
@@ -417,6 +430,7 @@ static int conv3x3_bf16x3_launch(const float* x, const scan_pyramid_t* d, int32_
   SCAN_CHECK_ARG(Csw % 8 == 0 && Csw >= Cs, "conv3x3_bf16x3: Csw=%d must be a multiple of 8 and >= Cs", Csw);
   SCAN_CHECK_ARG(Nout > 0 && Ns >= Nout, "conv3x3_bf16x3: Nout=%d Ns=%d", Nout, Ns);
   SCAN_CHECK_ARG(x && wh && wl && y, "conv3x3_bf16x3: null pointer");
+  if (v2_ok(y, mask, Ns)) return conv3x3_bf16x3_v2_launch(x, d, Cs, wh, wl, Csw, bias, mask, y, Nout, Ns, relu, stream, gn_ws);
   TileTab tt;
   hipStream_t st = as_stream(stream);
   const __bf16* h = reinterpret_cast<const __bf16*>(wh);
@@ -521,6 +535,8 @@ extern "C" int scan_conv1x1_bf16x3(const float* x, const scan_pyramid_t* xd, int
                        (map != 2 || ((yd->h[l] - 1) / 2 + 1 == xd->h[l] && (yd->w[l] - 1) / 2 + 1 == xd->w[l])),
                    "conv1x1_bf16x3: level %d sizes do not match map %d", l, map);
   }
+  if (v2_ok(y, mask, Ns))
+    return conv1x1_bf16x3_v2_launch(x, xd, Cs, wh, wl, Csw, bias, mask, y, yd, Nout, Ns, relu, map, stream);
   TileTab tt;
   hipStream_t st = as_stream(stream);
   const __bf16* h = reinterpret_cast<const __bf16*>(wh);

@@ -1,0 +1,398 @@
+// 3x3 / stride-1 (and 1x1) convolution, forward and data gradient, bf16x3 arithmetic (see conv_bf16x3.hip for the
+// operand split) -- second generation of the kernel, built on v_mfma_f32_16x16x32_bf16.
+//
+// Why another kernel.  Same MFMA cycles, same LDS bytes, same registers as the 32x32x16 version, but on MI355X the chip
+// holds a visibly higher clock on the 16x16x32 shape in an MFMA-dense loop (MI355X_MICROARCH.md "DVFS give-back" item
+// 7): a timing build that only swapped the instruction (profiles/r02_mfma_shape_experiment.txt) ran the big layers
+// 10-12 % faster in the same process.  The tile geometry changes with the shape:
+//
+//   MFMA roles      A operand = weights (16 output channels x 32 input channels), B operand = pixels (32 channels x 16
+//                   pixels of ONE tile row), so a lane's four accumulator registers are four CONSECUTIVE output
+//                   channels of one pixel: the epilogue stores (and the dgrad ReLU-mask loads) are 16-byte accesses,
+//                   four times fewer store instructions than the channel-per-lane layout of the 32x32 kernel
+//   workgroup       16 x 16 output pixels x BN channels (BN = 128: 64 accumulator registers per lane, 256: 128),
+//                   8 waves = 4 (pixel rows) x 2 (channels); 8 x 16 pixels x 64 channels with 4 waves for Cout <= 64
+//   K loop          32-channel chunks = exactly one MFMA k-step; per chunk the (TH+2) x 18 x 32 halo patch is read
+//                   once as fp32, split to bf16 hi / lo into LDS and reused by all nine taps
+//   LDS image       64 bytes per pixel (weight row) and plane, NO padding: the four 16-byte k-groups of a row are
+//                   stored at slot kg ^ (2 * ((idx >> 2) & 1)), idx = patch column (weight row).  Checked exhaustively
+//                   for the 16-lane groups of ds_read_b128 and every tap shift kx: conflict-free.  The patch shrinks
+//                   from 55 KB to 41 KB, the double-buffered weight tile from 40 to 32 KB (BN = 128).
+//
+// dgrad = the same kernel on dY with flipped / transposed weight planes (scan_weight_split mode 1).  Epilogue variants
+// as before: bias, ReLU, ReLU mask of a deferred ReLU (dgrad), fused 2x2 max-pool (frozen stages), GroupNorm sums.
+#include "common.h"
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+#define V2_TW 16
+#define V2_CK 32  // channels per K chunk = one k-step of v_mfma_f32_16x16x32_bf16
+
+struct TileTab2 {
+  int tile_off[SCAN_MAX_LEVELS + 1];
+  int tiles_x[SCAN_MAX_LEVELS];
+  int tiles_y[SCAN_MAX_LEVELS];
+};
+
+__device__ __forceinline__ int xcd_remap_v2(int orig, int nwg) {
+  const int q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+  const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + orig / 8;
+}
+
+__device__ __forceinline__ void split4_v2(const float4 v, bf16x4& hi, bf16x4& lo) {
+  hi[0] = (__bf16)v.x;
+  hi[1] = (__bf16)v.y;
+  hi[2] = (__bf16)v.z;
+  hi[3] = (__bf16)v.w;
+  lo[0] = (__bf16)(v.x - (float)hi[0]);
+  lo[1] = (__bf16)(v.y - (float)hi[1]);
+  lo[2] = (__bf16)(v.z - (float)hi[2]);
+  lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+// 16-byte slot swizzle of a 64-byte row: k-group kg of row idx lives at slot kg ^ swz(idx)
+__device__ __forceinline__ int swz(int idx) { return (idx >> 1) & 2; }
+
+// BN: output channels per workgroup; TH: tile rows (tile = TH x 16 pixels); NT: threads; KS: 3 or 1.
+// KS = 1 also serves the stride-2 1x1 convs through MAP (0: same pyramid; 1: source = 2 * output, forward of a stride-2
+// conv; 2: source = output / 2 on even coordinates, zero elsewhere: its data gradient), like the first kernel.
+template <int BN, int TH, int NT, int KS>
+__global__ __launch_bounds__(NT, 2) void conv_bf16x3_v2_kernel(
+    const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
+    const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
+    float* __restrict__ dst, int Nout, int Ns, int relu, TileTab2 tt, int n_tiles, scan_pyramid_t sd, int map,
+    double* __restrict__ gn_ws) {
+  constexpr int HALO = KS / 2, NTAPS = KS * KS;
+  constexpr int PH = TH + 2 * HALO;
+  constexpr int PWK = V2_TW + 2 * HALO;
+  constexpr int NPATCH = PH * PWK;
+  constexpr int WAVES = NT / 64;
+  constexpr int WN_WAVES = BN >= 128 ? 2 : 1;
+  constexpr int WM_WAVES = WAVES / WN_WAVES;
+  constexpr int TM = TH / WM_WAVES;             // 16-pixel tile rows per wave (4, or 2 for the 8-row tile)
+  constexpr int TN = BN / (16 * WN_WAVES);      // 16-channel tiles per wave (4, or 8 for BN = 256)
+  constexpr int ASLOTS = (NPATCH * 8 + NT - 1) / NT;  // float4 of the halo patch per thread per chunk
+  constexpr int BSEG = BN * 4 * 2 / NT;               // 16-byte weight segments per thread per (chunk, tap)
+  static_assert(TM * WM_WAVES == TH && (TM % 2) == 0, "tile rows must split evenly (and pair up for the fused pool)");
+
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem_raw);  // [NPATCH][32]
+  __bf16* Al = Ah + NPATCH * 32;                     // [NPATCH][32]
+  __bf16* Bs = Al + NPATCH * 32;                     // [2 buf][2 plane][BN][32]
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int bid = xcd_remap_v2(blockIdx.x, gridDim.x);
+  const int n_tile = bid % n_tiles;
+  const int tile = bid / n_tiles;
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+    if (i < d.n_levels && tile >= tt.tile_off[i]) lvl = i;
+  const int H = d.h[lvl], W = d.w[lvl];
+  int t = tile - tt.tile_off[lvl];
+  const int per_img = tt.tiles_x[lvl] * tt.tiles_y[lvl];
+  const int img = t / per_img;
+  t -= img * per_img;
+  const int ty0 = (t / tt.tiles_x[lvl]) * TH, tx0 = (t % tt.tiles_x[lvl]) * V2_TW;
+  const int64_t rowbase = d.row_off[lvl] + (int64_t)img * H * W;
+  const int n0 = n_tile * BN;
+  const int nchunks = (Cs + V2_CK - 1) / V2_CK;
+
+  // ---- halo patch staging: NPATCH pixels x 8 float4, ASLOTS per thread, prefetched one chunk ahead in registers
+  float4 ra[ASLOTS];
+  auto load_a = [&](int cc) {
+    const int c0 = cc * V2_CK;
+#pragma unroll
+    for (int i = 0; i < ASLOTS; ++i) {
+      const int slot = tid + NT * i;
+      const int q = slot >> 3, c = c0 + 4 * (slot & 7);
+      const int py = q / PWK, px = q - py * PWK;
+      const int y = ty0 - HALO + py, x = tx0 - HALO + px;
+      bool ok = (slot < NPATCH * 8) && y >= 0 && y < H && x >= 0 && x < W && c < Cs;
+      int64_t row = rowbase + (int64_t)y * W + x;
+      if (KS == 1 && map != 0) {
+        const int Hs = sd.h[lvl], Ws = sd.w[lvl];
+        int sy, sx;
+        if (map == 1) {
+          sy = 2 * y;
+          sx = 2 * x;
+        } else {
+          ok = ok && ((y | x) & 1) == 0;
+          sy = y >> 1;
+          sx = x >> 1;
+        }
+        ok = ok && sy < Hs && sx < Ws;
+        row = sd.row_off[lvl] + ((int64_t)img * Hs + sy) * Ws + sx;
+      }
+      ra[i] = ok ? *reinterpret_cast<const float4*>(src + row * Cs + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto store_a = [&]() {
+#pragma unroll
+    for (int i = 0; i < ASLOTS; ++i) {
+      const int slot = tid + NT * i;
+      if (slot < NPATCH * 8) {
+        const int q = slot >> 3, c4 = slot & 7;
+        const int px = q % PWK;
+        bf16x4 hi, lo;
+        split4_v2(ra[i], hi, lo);
+        const int off = q * 32 + (((c4 >> 1) ^ swz(px)) << 3) + ((c4 & 1) << 2);
+        *reinterpret_cast<bf16x4*>(Ah + off) = hi;
+        *reinterpret_cast<bf16x4*>(Al + off) = lo;
+      }
+    }
+  };
+  // ---- weight tile staging: BN rows x 4 segments x 2 planes per (chunk, tap), double-buffered in LDS
+  uint4 rb[BSEG];
+  auto load_b = [&](int cc, int tap) {
+#pragma unroll
+    for (int i = 0; i < BSEG; ++i) {
+      const int slot = tid + NT * i;
+      const int plane = slot / (BN * 4);
+      const int rem = slot - plane * BN * 4;
+      const int row = rem >> 2, seg = rem & 3;
+      const int o = n0 + row, c = cc * V2_CK + 8 * seg;
+      const __bf16* base = plane ? wl : wh;
+      rb[i] = (o < Nout && c < Csw) ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * NTAPS + tap) * Csw + c)
+                                    : make_uint4(0u, 0u, 0u, 0u);
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < BSEG; ++i) {
+      const int slot = tid + NT * i;
+      const int plane = slot / (BN * 4);
+      const int rem = slot - plane * BN * 4;
+      const int row = rem >> 2, seg = rem & 3;
+      *reinterpret_cast<uint4*>(Bs + ((buf * 2 + plane) * BN + row) * 32 + ((seg ^ swz(row)) << 3)) = rb[i];
+    }
+  };
+
+  // ---- MFMA roles
+  const int wm = wid / WN_WAVES, wn = wid % WN_WAVES;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int w_row0 = wn * 16 * TN + lr;                                   // this lane's weight row in channel tile 0
+  const int w_off = w_row0 * 32 + ((kg ^ swz(w_row0)) << 3);             // + tn * 16 * 32 (swz(row) has period 8)
+
+  f32x4v acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  load_a(0);
+  load_b(0, 0);
+  for (int cc = 0; cc < nchunks; ++cc) {
+    __syncthreads();  // every wave is done reading the previous chunk's patch
+    store_a();
+    if (cc + 1 < nchunks) load_a(cc + 1);
+#pragma unroll 1
+    for (int tap = 0; tap < NTAPS; ++tap) {
+      const int buf = (cc * NTAPS + tap) & 1;
+      store_b(buf);
+      if (tap < NTAPS - 1)
+        load_b(cc, tap + 1);
+      else if (cc + 1 < nchunks)
+        load_b(cc + 1, 0);
+      __syncthreads();
+      const int ky = tap / KS, kx = tap - KS * ky;
+      const int pxs = lr + kx;  // patch column of this lane's pixel
+      const int p_off = ((wm * TM + ky) * PWK + pxs) * 32 + ((kg ^ swz(pxs)) << 3);
+      const __bf16* bh = Bs + (buf * 2 + 0) * BN * 32 + w_off;
+      const __bf16* bl = Bs + (buf * 2 + 1) * BN * 32 + w_off;
+      bf16x8 ph[TM], pl[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        ph[tm] = *reinterpret_cast<const bf16x8*>(Ah + p_off + tm * PWK * 32);
+        pl[tm] = *reinterpret_cast<const bf16x8*>(Al + p_off + tm * PWK * 32);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const bf16x8 whv = *reinterpret_cast<const bf16x8*>(bh + tn * 16 * 32);
+        const bf16x8 wlv = *reinterpret_cast<const bf16x8*>(bl + tn * 16 * 32);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, pl[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlv, ph[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, ph[tm], acc[tm][tn], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- epilogue.  C/D map of 16x16: column = lane & 15 = pixel x of tile row tm, row = 4 * (lane >> 4) + reg = output
+  // channel inside channel tile tn: one lane owns four consecutive channels of one pixel
+  const int x = tx0 + lr;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+    const int o4 = n0 + wn * 16 * TN + tn * 16 + 4 * kg;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias != nullptr) {
+      bv.x = o4 + 0 < Nout ? bias[o4 + 0] : 0.f;
+      bv.y = o4 + 1 < Nout ? bias[o4 + 1] : 0.f;
+      bv.z = o4 + 2 < Nout ? bias[o4 + 2] : 0.f;
+      bv.w = o4 + 3 < Nout ? bias[o4 + 3] : 0.f;
+    }
+    if (relu & 2) {
+      // fused 2x2 / stride-2 max-pool (frozen VGG stages): rows y, y+1 are accumulator tiles tm, tm+1 of this lane,
+      // columns x, x+1 are lanes l, l^1 -- one DPP exchange, then the even lanes write the pooled pixel
+      const int Hp = H >> 1, Wp = W >> 1;
+#pragma unroll
+      for (int tm = 0; tm < TM; tm += 2) {
+        const int y = ty0 + wm * TM + tm;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float m = fmaxf(acc[tm][tn][r], acc[tm + 1][tn][r]);
+          v[r] = fmaxf(m, __shfl_xor(m, 1, 64));
+        }
+        if ((lr & 1) == 0 && y < H && x < W && o4 < Nout) {
+          float4 o = make_float4(v[0] + bv.x, v[1] + bv.y, v[2] + bv.z, v[3] + bv.w);
+          if (relu & 1) {
+            o.x = fmaxf(o.x, 0.f);
+            o.y = fmaxf(o.y, 0.f);
+            o.z = fmaxf(o.z, 0.f);
+            o.w = fmaxf(o.w, 0.f);
+          }
+          *reinterpret_cast<float4*>(dst + ((int64_t)img * Hp * Wp + (int64_t)(y >> 1) * Wp + (x >> 1)) * Ns + o4) = o;
+        }
+      }
+      continue;
+    }
+    // the ReLU mask of a data gradient: fetch this channel tile's masks first so the loads overlap
+    float4 mk[TM];
+    if (mask != nullptr) {
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int y = ty0 + wm * TM + tm;
+        const bool ok = y < H && x < W && o4 < Nout;
+        mk[tm] = ok ? *reinterpret_cast<const float4*>(mask + (rowbase + (int64_t)y * W + x) * Ns + o4)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float gs = 0.f, gq = 0.f;
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+      const int y = ty0 + wm * TM + tm;
+      if (y < H && x < W && o4 < Nout) {
+        float4 o = make_float4(acc[tm][tn][0] + bv.x, acc[tm][tn][1] + bv.y, acc[tm][tn][2] + bv.z,
+                               acc[tm][tn][3] + bv.w);
+        if (relu & 1) {
+          o.x = fmaxf(o.x, 0.f);
+          o.y = fmaxf(o.y, 0.f);
+          o.z = fmaxf(o.z, 0.f);
+          o.w = fmaxf(o.w, 0.f);
+        }
+        if (mask != nullptr) {
+          o.x = (mk[tm].x > 0.f) ? o.x : 0.f;
+          o.y = (mk[tm].y > 0.f) ? o.y : 0.f;
+          o.z = (mk[tm].z > 0.f) ? o.z : 0.f;
+          o.w = (mk[tm].w > 0.f) ? o.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(dst + (rowbase + (int64_t)y * W + x) * Ns + o4) = o;
+        gs += (o.x + o.y) + (o.z + o.w);
+        gq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+      }
+    }
+    if (gn_ws != nullptr) {
+      // GroupNorm(32) sums of the 256-channel output: a group = 8 channels = the lane-group pair kg, kg ^ 1; reduce
+      // over the 16 pixels (lanes) and that pair, one fp64 atomic pair per group and wave
+      double ds = (double)gs, dq = (double)gq;
+#pragma unroll
+      for (int sh = 1; sh <= 16; sh <<= 1) {
+        ds += __shfl_xor(ds, sh, 64);
+        dq += __shfl_xor(dq, sh, 64);
+      }
+      if (lr == 0 && (kg & 1) == 0 && o4 < Nout) {
+        const int64_t slot = ((int64_t)(lvl * d.n_images + img) * 32 + (o4 >> 3)) * 2;
+        atomicAdd(&gn_ws[slot], ds);
+        atomicAdd(&gn_ws[slot + 1], dq);
+      }
+    }
+  }
+}
+
+static void make_tiles_v2(const scan_pyramid_t* d, TileTab2* tt, int TH) {
+  tt->tile_off[0] = 0;
+  for (int l = 0; l < SCAN_MAX_LEVELS; ++l) {
+    if (l < d->n_levels) {
+      tt->tiles_x[l] = (d->w[l] + V2_TW - 1) / V2_TW;
+      tt->tiles_y[l] = (d->h[l] + TH - 1) / TH;
+      tt->tile_off[l + 1] = tt->tile_off[l] + d->n_images * tt->tiles_x[l] * tt->tiles_y[l];
+    } else {
+      tt->tiles_x[l] = tt->tiles_y[l] = 1;
+      tt->tile_off[l + 1] = tt->tile_off[l];
+    }
+  }
+}
+
+template <int BN, int TH, int NT, int KS>
+static void launch_v2(const float* x, const scan_pyramid_t* od, int32_t Cs, const __bf16* h, const __bf16* l, int32_t Csw,
+                      const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns, int32_t relu,
+                      hipStream_t st, double* gn_ws, const scan_pyramid_t* sd, int map) {
+  constexpr int HALO = KS / 2;
+  TileTab2 tt;
+  make_tiles_v2(od, &tt, TH);
+  const int tiles = tt.tile_off[od->n_levels];
+  const int n_tiles = (Nout + BN - 1) / BN;
+  const size_t sh = (size_t)(2 * (TH + 2 * HALO) * (V2_TW + 2 * HALO) * 32 + 4 * BN * 32) * sizeof(__bf16);
+  static bool done = false;
+  if (!done) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_v2_kernel<BN, TH, NT, KS>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    done = true;
+  }
+  hipLaunchKernelGGL((conv_bf16x3_v2_kernel<BN, TH, NT, KS>), dim3(tiles * n_tiles), dim3(NT), sh, st, x, *od, Cs, h, l,
+                     Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *sd, map, gn_ws);
+}
+
+// Instance choice for an output pyramid and channel count: 64 (8x16-pixel tiles, 256 threads), 128 or 256 (16x16-pixel
+// tiles, 512 threads; 256 when the channels fill 256-wide tiles and the launch keeps >= 2 workgroups per CU).
+extern int g_scan_conv_bn256;
+static int v2_instance(const scan_pyramid_t* od, int32_t Nout) {
+  if (Nout <= 64) return 64;
+  TileTab2 tt;
+  make_tiles_v2(od, &tt, 16);
+  const int64_t tiles = tt.tile_off[od->n_levels];
+  if (g_scan_conv_bn256 && Nout % 256 == 0 && tiles * (Nout / 256) >= 512) return 256;
+  return 128;
+}
+
+// entry points used by conv_bf16x3.hip's public functions when the "conv_v2" knob is on
+int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                             int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns,
+                             int32_t relu, void* stream, double* gn_ws) {
+  hipStream_t st = as_stream(stream);
+  const __bf16* h = reinterpret_cast<const __bf16*>(wh);
+  const __bf16* l = reinterpret_cast<const __bf16*>(wl);
+  switch (v2_instance(d, Nout)) {
+    case 64: launch_v2<64, 8, 256, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+    case 256: launch_v2<256, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+    default: launch_v2<128, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+  }
+  SCAN_LAUNCH_CHECK("conv3x3_bf16x3_v2");
+  return 0;
+}
+
+int conv1x1_bf16x3_v2_launch(const float* x, const scan_pyramid_t* xd, int32_t Cs, const void* wh, const void* wl,
+                             int32_t Csw, const float* bias, const float* mask, float* y, const scan_pyramid_t* yd,
+                             int32_t Nout, int32_t Ns, int32_t relu, int32_t map, void* stream) {
+  hipStream_t st = as_stream(stream);
+  const __bf16* h = reinterpret_cast<const __bf16*>(wh);
+  const __bf16* l = reinterpret_cast<const __bf16*>(wl);
+  if (Nout <= 64)
+    launch_v2<64, 8, 256, 1>(x, yd, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, nullptr, xd, map);
+  else
+    launch_v2<128, 16, 512, 1>(x, yd, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, nullptr, xd, map);
+  SCAN_LAUNCH_CHECK("conv1x1_bf16x3_v2");
+  return 0;
+}
+
+// which instance a 3x3 launch on pyramid d with Nout output channels takes (bench.py labels its timings with it)
+extern "C" int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout) { return d ? v2_instance(d, Nout) : -1; }

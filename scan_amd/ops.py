@@ -226,7 +226,11 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
             ev.record(torch.cuda.current_stream())
             _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
     y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
-    ev = kernel_timer.begin(name + ("_bn128" if nout > 64 else "_bn64"), flops)  # the two template instances
+    if kernel_timer.enabled:  # label the record with the template instance the launch takes (64 / 128 / 256 channels)
+        inst = query("scan_conv3x3_bf16x3_instance", (dst_shape or shape).ref(), nout) if T == 9 else (128 if nout > 64 else 64)
+        ev = kernel_timer.begin("%s_bn%d" % (name, inst), flops)
+    else:
+        ev = None
     if gn_sums:
         sums = torch.empty((shape.n_levels * shape.n_images * 32 * 2,), dtype=torch.float64, device=x.device)
         call("scan_conv3x3_gn_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(y), nout,

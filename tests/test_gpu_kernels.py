@@ -238,9 +238,18 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("mode", ["fp32", "bf16x3"])
+@pytest.fixture
+def conv_generation(request):
+    """scan_tune("conv_v2"): 1 = the 16x16x32-MFMA forward / dgrad kernel (default), 0 = the 32x32x16 one."""
+    from scan_amd import _lib
+    old = _lib.query("scan_tune", b"conv_v2", int(request.param))
+    yield request.param
+    _lib.query("scan_tune", b"conv_v2", old)
+
+
+@pytest.mark.parametrize("mode,conv_generation", [("fp32", 1), ("bf16x3", 1), ("bf16x3", 0)], indirect=["conv_generation"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv2d_fwd_bwd(device, case, mode, monkeypatch):
+def test_conv2d_fwd_bwd(device, case, mode, conv_generation, monkeypatch):
     from scan_amd import ops
     monkeypatch.setattr(ops, "CONV_MODE", mode)
     # bf16x3: operands carry 16 mantissa bits (hi + lo); products exact, fp32 accumulate
@@ -283,6 +292,47 @@ def test_conv2d_fwd_bwd(device, case, mode, monkeypatch):
     scale = max(1.0, float(wr.grad.abs().max()))
     np.testing.assert_allclose(wd.grad.cpu().numpy(), wr.grad.numpy(), rtol=1e-4, atol=tol * scale)
     np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(br.grad.abs().max())))
+
+
+def test_conv_instances_agree_full_size(device):
+    """the three ways a 256 -> 256 tower layer can run on 4 frames of 128x256 (P3 of the bench workload): 16x16x32
+    kernel with 256-channel tiles (the default for this launch), with 128-channel tiles (bit-identical: same K order
+    per output), and the 32x32x16 kernel (agrees to rounding) -- forward with GroupNorm sums, and the masked data
+    gradient."""
+    from scan_amd import _lib, ops
+    shape = ops.PyramidShape(4, [(128, 256)])
+    assert _lib.query("scan_conv3x3_bf16x3_instance", shape.ref(), 256) == 256
+    torch.manual_seed(3)
+    x = torch.randn(shape.rows, 256, device=device)
+    w = (torch.randn(256, 256, 3, 3, device=device) / 48).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(256, device=device)
+    gy = torch.randn(shape.rows, 256, device=device)
+
+    def run():
+        xx = x.clone().requires_grad_(True)
+        h = ops.conv2d(xx, w, b, shape, 3, 1, relu="deferred")          # deferred ReLU: consumer masks dx
+        y = ops.conv2d(h, w, b, shape, 3, 1, mask_dx=True, gn_sums=True)
+        sums = ops._gn_sums.pop(y.data_ptr()).clone()
+        y.backward(gy)
+        return y.detach(), sums, xx.grad.clone()
+
+    ref = run()
+    old = _lib.query("scan_tune", b"conv_bn256", 0)
+    try:
+        assert _lib.query("scan_conv3x3_bf16x3_instance", shape.ref(), 256) == 128
+        narrow = run()
+    finally:
+        _lib.query("scan_tune", b"conv_bn256", old)
+    assert torch.equal(ref[0], narrow[0]) and torch.equal(ref[2], narrow[2])
+    assert torch.allclose(ref[1], narrow[1], rtol=1e-12, atol=0)  # fp64 atomics: order may differ
+    old = _lib.query("scan_tune", b"conv_v2", 0)
+    try:
+        first = run()
+    finally:
+        _lib.query("scan_tune", b"conv_v2", old)
+    for a, c in zip(ref, first):
+        assert torch.allclose(a.double(), c.double(), rtol=1e-4, atol=1e-5 * float(c.abs().max())), \
+            (a.double() - c.double()).abs().max().item()
 
 
 def test_conv2d_linearity_full_size(device):

@@ -74,11 +74,11 @@ def main():
                 _lib.query("scan_tune", key.encode(), old)
                 if ref is None:
                     ref = y
-                same = torch.equal(ref, y)
                 b = best.setdefault((key, val), [])
                 b.append(us)
-                if not same:
-                    line += " MISMATCH(%s=%s) %.3g" % (key, val, (ref - y).abs().max().item())
+                if rnd == 0 and not torch.equal(ref, y):  # different kernels agree to rounding, not bit for bit
+                    line += " [%s=%s differs: max %.2e of %.2e]" % (key, val, (ref - y).abs().max().item(),
+                                                                     ref.abs().max().item())
         flops = 2.0 * ops.PyramidShape(sd[1], sd[2]).rows * sd[4] * 9 * sd[3]
         for (key, val), us in best.items():
             line += "  %s=%s: %s us -> %6.1f TF" % (key, val, "/".join("%.0f" % u for u in us), flops / min(us) * 1e-6)

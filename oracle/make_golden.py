@@ -527,6 +527,53 @@ def gen_ckpt(K=9, name="refckpt_c2f"):
     shutil.rmtree(tmp)
 
 
+# ----------------------------------------------------------------------------- input pipeline
+PIPE_CASES = [  # (name, source sizes (h, w) of the batch, flip, min_size, max_size)
+    ("up", [(97, 131), (80, 120)], 0.0, 160, 240),        # upsample, ragged batch
+    ("down_flip", [(150, 301), (128, 256)], 1.0, 100, 180),  # downsample (antialiased support), flipped, max-size bound
+    ("same", [(64, 96)], 0.0, 64, 333),                   # get_size returns the input size: no resize pass
+]
+
+
+def gen_pipeline():
+    """The reference's own Compose([Resize, RandomHorizontalFlip, ToTensor, Normalize]) (data/transforms/
+    transforms.py:9-90, built like data/transforms/build.py:5-44) + BatchCollator(32) (data/collate_batch.py:5-20) on
+    seeded uint8 images and BoxList targets.  torchvision is restated on the real PIL (ref_harness.setup)."""
+    rh.setup()
+    from PIL import Image
+    from fcos_core.data.transforms import transforms as T
+    from fcos_core.data.collate_batch import BatchCollator
+    cfg = rh.make_cfg([])
+    out = {}
+    for name, sizes, flip, min_size, max_size in PIPE_CASES:
+        tf = T.Compose([T.Resize(min_size, max_size), T.RandomHorizontalFlip(flip), T.ToTensor(),
+                        T.Normalize(mean=cfg.INPUT.PIXEL_MEAN, std=cfg.INPUT.PIXEL_STD, to_bgr255=cfg.INPUT.TO_BGR255)])
+        batch = []
+        for i, (h, w) in enumerate(sizes):
+            img = synth.synth_u8_image(h, w, 777 + i)
+            boxes, labels = synth.synth_targets(1, h, w, 8, 5, 888 + i)[0]
+            tgt = rh.make_targets([boxes], [labels], (h, w))[0]
+            resized_only = T.Resize(min_size, max_size)(Image.fromarray(img), tgt)[0]
+            out["%s_resized_%d" % (name, i)] = np.asarray(resized_only).copy()
+            timg, ttgt = tf(Image.fromarray(img), tgt)
+            out["%s_boxes_%d" % (name, i)] = ttgt.bbox.numpy()
+            out["%s_boxsize_%d" % (name, i)] = np.asarray(ttgt.size, np.int64)
+            batch.append((timg, ttgt, i))
+        il, tg, ids = BatchCollator(cfg.DATALOADER.SIZE_DIVISIBILITY)(batch)
+        out["%s_batch" % name] = il.tensors.numpy()
+        out["%s_image_sizes" % name] = np.asarray([list(s) for s in il.image_sizes], np.int64)
+        print("pipeline", name, [tuple(out["%s_resized_%d" % (name, i)].shape) for i in range(len(sizes))], "->",
+              tuple(il.tensors.shape))
+    # Resize.get_size over a sweep of (w, h, min, max): pure integer / float logic (transforms.py:34-55)
+    gs = []
+    for (w, h) in [(2048, 1024), (1914, 1052), (1242, 375), (500, 333), (333, 500), (640, 480), (800, 800), (1333, 800)]:
+        for mn, mx in [(800, 1333), (640, 1333), (600, 1000), (100, 180)]:
+            gs.append([w, h, mn, mx] + list(T.Resize(mn, mx).get_size((w, h))))
+    out["get_size_table"] = np.asarray(gs, np.int64)
+    np.savez_compressed(os.path.join(GOLD, "pipeline.npz"), **out)
+    print("pipeline.npz written, %d bytes" % os.path.getsize(os.path.join(GOLD, "pipeline.npz")))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -573,6 +620,8 @@ def main():
         gen_traj(a.check)
     if "step_mid" in todo:  # one mid-size frame with EVERY gradient digest: the bf16x3 allowances at real level sizes
         gen_step(a.check, H=512, W=1024, N=1, name="step_mid_512x1024")
+    if "pipeline" in todo:
+        gen_pipeline()
     if "cfg" in todo:
         gen_cfg()
     if "ckpt" in todo:

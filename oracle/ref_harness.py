@@ -138,6 +138,8 @@ def setup():
     yacs = _mod("yacs")
     yacs.config = _mod("yacs.config", CfgNode=CfgNode)
     _mod("ipdb")
+    if "cv2" not in sys.modules:  # imported by structures/segmentation_mask.py on the way to fcos_core.data.transforms; unused
+        _mod("cv2")
     six = _mod("torch._six", PY3=True, string_classes=(str,), int_classes=(int,))
     torch._six = six
 
@@ -151,7 +153,33 @@ def setup():
     pc.cocoeval = _mod("pycocotools.cocoeval", COCOeval=_Dummy)
     tv = _mod("torchvision")
     tv.transforms = _mod("torchvision.transforms")
-    tv.transforms.functional = _mod("torchvision.transforms.functional")
+    # torchvision is absent from this image.  The reference's transforms (data/transforms/transforms.py:27-90) call
+    # four of its functional ops on PIL images; their PIL code path (torchvision/transforms/functional.py +
+    # _functional_pil.py, unchanged across 0.2 ... 0.20) is restated here on the REAL PIL that is installed:
+    #   resize(img, (h, w))  -> img.resize((w, h), BILINEAR)       (the default interpolation)
+    #   hflip(img)           -> img.transpose(FLIP_LEFT_RIGHT)
+    #   to_tensor(img)       -> uint8 HWC -> float CHW, .div(255)
+    #   normalize(t, m, s)   -> (t - m[:, None, None]) / s[:, None, None]
+    def _tv_resize(img, size, interpolation=None):
+        from PIL import Image
+        return img.resize((int(size[1]), int(size[0])), Image.BILINEAR)
+
+    def _tv_hflip(img):
+        from PIL import Image
+        return img.transpose(Image.FLIP_LEFT_RIGHT)
+
+    def _tv_to_tensor(img):
+        import numpy as _np
+        a = torch.from_numpy(_np.asarray(img).copy())
+        return a.permute(2, 0, 1).contiguous().float().div(255)
+
+    def _tv_normalize(t, mean, std):
+        m = torch.as_tensor(mean, dtype=t.dtype)[:, None, None]
+        sd = torch.as_tensor(std, dtype=t.dtype)[:, None, None]
+        return (t - m) / sd
+
+    tv.transforms.functional = _mod("torchvision.transforms.functional", resize=_tv_resize, hflip=_tv_hflip,
+                                    to_tensor=_tv_to_tensor, normalize=_tv_normalize)
     tv.datasets = _mod("torchvision.datasets")
     tv.datasets.coco = _mod("torchvision.datasets.coco", CocoDetection=_Dummy)
     tv.datasets.CocoDetection = _Dummy

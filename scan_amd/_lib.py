@@ -105,6 +105,11 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
+        # SCAN_TUNE="key=value,key=value": launch-selection knobs for A/B measurements (scan_tune, include/scan_hip.h)
+        for kv in filter(None, os.environ.get("SCAN_TUNE", "").split(",")):
+            key, _, val = kv.partition("=")
+            if L.scan_tune(key.strip().encode(), int(val)) < 0:
+                raise RuntimeError("SCAN_TUNE: unknown key %r" % key)
         _lib = L
     return _lib
 

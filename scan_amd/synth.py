@@ -249,3 +249,14 @@ def const_of(name):
     """per-tensor constant of the reference-written checkpoint fixture (tests/golden/refckpt_*.pth.gz: constant
     tensors gzip to kilobytes and still tell tensors apart)."""
     return ((zlib.crc32(name.encode()) % 2000) - 1000) / 4096.0
+
+
+def synth_u8_image(h, w, seed):
+    """uint8 RGB test frame [h, w, 3] with structure at several scales (smooth gradients + blocks + noise), so that a
+    resize with wrong coefficients, bounds or rounding shows up in many pixels."""
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    base = np.stack([(xx * 255.0 / max(w - 1, 1)), (yy * 255.0 / max(h - 1, 1)), ((xx + yy) % 64) * 4.0], -1)
+    blocks = rs.randint(0, 256, (h // 8 + 1, w // 8 + 1, 3)).repeat(8, 0).repeat(8, 1)[:h, :w]
+    noise = rs.randint(0, 256, (h, w, 3))
+    return ((base + blocks + noise) / 3.0).astype(np.uint8)

@@ -308,13 +308,15 @@ def test_conv_instances_agree_full_size(device):
     b = torch.randn(256, device=device)
     gy = torch.randn(shape.rows, 256, device=device)
 
+    with torch.no_grad():
+        h0 = ops.conv2d(x, w, b, shape, 3, 1, relu=True)  # a ReLU output: the mask (h0 > 0) of the data gradient
+
     def run():
-        xx = x.clone().requires_grad_(True)
-        h = ops.conv2d(xx, w, b, shape, 3, 1, relu="deferred")          # deferred ReLU: consumer masks dx
-        y = ops.conv2d(h, w, b, shape, 3, 1, mask_dx=True, gn_sums=True)
+        hh = h0.clone().requires_grad_(True)
+        y = ops.conv2d(hh, w, b, shape, 3, 1, mask_dx=True, gn_sums=True)  # mask_dx: dx *= (hh > 0) in the epilogue
         sums = ops._gn_sums.pop(y.data_ptr()).clone()
         y.backward(gy)
-        return y.detach(), sums, xx.grad.clone()
+        return y.detach(), sums, hh.grad.clone()
 
     ref = run()
     old = _lib.query("scan_tune", b"conv_bn256", 0)

@@ -272,6 +272,26 @@ int scan_dbscan_finish(int64_t n, void* ws, uint8_t* in_cluster0, void* stream);
 int scan_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float wd, float momentum,
                       int32_t first_step, void* stream);
 
+/* ---- input pipeline: the step in front of the path ----
+ * scan_resize_bilinear_u8 replaces torchvision F.resize on a PIL image = PIL Image.resize(size, BILINEAR), as
+ * called by Resize.__call__ (reference data/transforms/transforms.py:57-61): Pillow's two-pass fixed-point resampler.
+ * src uint8 [H, W, 3] -> dst uint8 [OH, OW, 3] (device pointers); tmp = [H, OW, 3] intermediate (only when both
+ * sizes change).  xbounds/ybounds int32 [O][2] = (first input index, tap count), xcoef/ycoef int32 [O][k] fixed-point
+ * (22 fractional bits) triangle-filter weights -- the host computes them in double precision as Pillow's
+ * precompute_coeffs does (scan_amd/data.py: bilinear_tables); bit-exact against PIL. */
+int scan_resize_bilinear_u8(const uint8_t* src, int32_t H, int32_t W, uint8_t* tmp, uint8_t* dst, int32_t OH, int32_t OW,
+                            const int32_t* xbounds, const int32_t* xcoef, int32_t kx, const int32_t* ybounds,
+                            const int32_t* ycoef, int32_t ky, void* stream);
+
+/* ToTensor + Normalize(to_bgr255) (+ RandomHorizontalFlip's F.hflip) (transforms.py:64-90) + the collator's zero
+ * padding (data/collate_batch.py:5-20, structures/image_list.py:54-66) for ONE image: src uint8 [H, W, 3] RGB ->
+ * fp32 ((x / 255)[2,1,0] * 255 - mean) / std written into a zero-padded Hp x Wp slot.  layout 0: CHW planes
+ * [3, Hp, Wp] (the reference tensor); layout 1: NHWC rows [Hp * Wp, 4] (what the first convolution reads; channel 3
+ * is zero).  mean3 / std3 are HOST arrays of 3 floats (BGR order when to_bgr255).  Bit-exact vs torch-CPU. */
+int scan_normalize_image_u8(const uint8_t* src, int32_t H, int32_t W, int32_t flip, int32_t to_bgr255,
+                            const float* mean3, const float* std3, float* dst, int32_t Hp, int32_t Wp, int32_t layout,
+                            void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,10 @@ SIGNATURES = {
     "scan_dbscan_bfs_step": (ctypes.c_int, [c_i64, c_vp, c_i32, c_vp, c_vp]),
     "scan_dbscan_finish": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp]),
     "scan_sgd_momentum": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "scan_resize_bilinear_u8": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
+                                               c_i32, c_vp]),
+    "scan_normalize_image_u8": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_f32),
+                                               ctypes.POINTER(c_f32), c_vp, c_i32, c_i32, c_i32, c_vp]),
 }
 
 _lib = None

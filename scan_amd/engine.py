@@ -100,16 +100,17 @@ def forward_detector(model, images, targets=None, mode="source", forward_target=
     Eval: detections."""
     il = to_image_list(images)
     images = il.tensors
-    plan_here = bool(targets) and mode == "source" and model["middle_head"].training and images.is_cuda
+    in_rows = getattr(il, "rows", None)  # data.BatchCollator: the batch already in the first conv's NHWC4 layout
+    dev = in_rows.device if in_rows is not None else images.device
+    plan_here = bool(targets) and mode == "source" and model["middle_head"].training and dev.type == "cuda"
     if plan_here:
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(torch.cuda.current_stream())
-    rows, shape = model["backbone"](images)
+    rows, shape = model["backbone"](images, in_rows, getattr(il, "shape", None))
     if plan_here:
         # the backbone is queued (tens of ms of GPU work, ~1 ms of host time): derive everything that depends on
         # the ground truth alone on a side stream now, so its host round trips hide behind the convolutions
-        fcos_mod.target_plan(shape, targets, images.device, side_stream=_plan_stream(images.device),
-                             after=inputs_ready)
+        fcos_mod.target_plan(shape, targets, dev, side_stream=_plan_stream(dev), after=inputs_ready)
     losses = {}
     feats, loss_graph, loss_act, maps = model["middle_head"](rows, shape, targets=targets, mode=mode,
                                                              forward_target=forward_target)
@@ -224,6 +225,12 @@ class FlatGroup:
             ops.sgd_momentum_(self.flat_p[self.n_w:], self.flat_g[self.n_w:], self.flat_m[self.n_w:],
                               lr * self.bias_lr_factor, self.wd_bias, self.momentum, self.first)
         self.first = False
+
+
+def _padded_shape(il):
+    if getattr(il, "rows", None) is not None:
+        return (il.shape.n_images,) + tuple(il.shape.sizes[0])
+    return (il.tensors.shape[0],) + tuple(il.tensors.shape[-2:])
 
 
 def warmup_factor(iteration, warmup_iters=1000, factor=1.0 / 3, steps=(60000, 80000), gamma=0.1, method="constant"):
@@ -413,14 +420,19 @@ class Trainer:
         for m in model.values():
             m.train()
         self.grad_arena.zero_()
-        B = il_s.tensors.shape[0]
-        images = torch.cat([il_s.tensors, il_t.tensors], 0)
+        B = len(il_s.image_sizes)
         inputs_ready = torch.cuda.Event()
         inputs_ready.record(torch.cuda.current_stream())
-        rows, shape = model["backbone"](images)
+        if getattr(il_s, "rows", None) is not None and getattr(il_t, "rows", None) is not None:
+            in_rows = torch.cat([il_s.rows, il_t.rows], 0)
+            dev = in_rows.device
+            rows, shape = model["backbone"](None, in_rows, ops.PyramidShape(2 * B, il_s.shape.sizes))
+        else:
+            images = torch.cat([il_s.tensors, il_t.tensors], 0)
+            dev = images.device
+            rows, shape = model["backbone"](images)
         shape_src = ops.PyramidShape(B, shape.sizes)
-        fcos_mod.target_plan(shape_src, targets_s, images.device, side_stream=_plan_stream(images.device),
-                             after=inputs_ready)
+        fcos_mod.target_plan(shape_src, targets_s, dev, side_stream=_plan_stream(dev), after=inputs_ready)
         feats, node_loss, act_loss, maps, consistency = model["middle_head"].forward_pair(
             rows, shape, targets_s, B, forward_target=forward_target)
         losses = {"node_loss_gs": node_loss, "act_loss_gs": act_loss}
@@ -485,7 +497,7 @@ class Trainer:
         """One DA iteration; returns the loss dict (0-dim GPU tensors, reference key names)."""
         if self.paired and self.tgt_stream is not None:
             il_s, il_t = to_image_list(images_s), to_image_list(images_t)
-            if il_s.tensors.shape == il_t.tensors.shape:
+            if _padded_shape(il_s) == _padded_shape(il_t):
                 return self.step_paired(il_s, targets_s, il_t, forward_target)
         model, lam = self.model, self.con_dis_lambda
         ops.begin_weight_epoch()  # parameters change once per iteration: reuse their bf16 planes within it

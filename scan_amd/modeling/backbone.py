@@ -119,10 +119,13 @@ class VGG16FPN(nn.Module):
         self.body = VGGBody()
         self.fpn = FPN()
 
-    def forward(self, images):
-        if not images.is_cuda:
-            raise RuntimeError("scan_amd backbone runs only on the GPU (HIP); no CPU fallback")
-        rows, shape = ops.nchw_to_rows(images, 4)
+    def forward(self, images, rows=None, shape=None):
+        """images [N,3,H,W]; or rows [N*H*W, 4] + its one-level PyramidShape (data.BatchCollator writes the batch in
+        this layout directly: no NCHW -> NHWC pass)."""
+        if rows is None:
+            if not images.is_cuda:
+                raise RuntimeError("scan_amd backbone runs only on the GPU (HIP); no CPU fallback")
+            rows, shape = ops.nchw_to_rows(images, 4)
         outs = self.body(rows, shape)
         return self.fpn(outs[2], outs[3], outs[4])
 

@@ -46,7 +46,8 @@ int scan_abi_version(void);
  *                 when the launch keeps >= 2 workgroups per CU; 0: always 128-channel tiles (same results).
  *   "conv_v2"     1 (default): bf16x3 forward / data-gradient convs run on the v_mfma_f32_16x16x32_bf16 kernel;
  *                 0: on the v_mfma_f32_32x32x16_bf16 kernel (same arithmetic, different summation order inside a
- *                 32-channel chunk). */
+ *                 32-channel chunk).
+ *   "wgrad_v2"    1 (default) / 0: the same choice for the bf16x3 weight-gradient kernels. */
 int scan_tune(const char* key, int value);
 
 /* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels. */

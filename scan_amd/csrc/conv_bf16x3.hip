@@ -811,6 +811,236 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second generation of the weight-gradient kernel: the same workgroup decomposition (128 o x 128 c x 3 kx taps of one
+// ky, 64-pixel K chunks, deterministic split-K slabs) on v_mfma_f32_16x16x32_bf16 -- the shape on which the chip holds
+// the higher clock in MFMA-dense loops (see conv_bf16x3_v2.hip).  A k-step is now 32 pixels: lane (col = l & 15,
+// kg = l >> 4) of the A operand (dY^T, rows = 16 output channels) and of the B operand (X, columns = 16 input
+// channels) needs pixels 8 kg .. 8 kg + 7 of its column, i.e. two ds_read_b64_tr_b16 on rows 8 kg + q and 8 kg + 4 + q.
+// The two 16-lane groups of a half wave read rows 8 apart in the same 16 columns; with the 320-byte row pitch those
+// fall on the same banks, so the 32-byte column group of a row is XOR-ed with bit 3 of the row index (applied by the
+// staging writes and by every lane's read address).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wsw(int row, int col) {  // bf16 element offset of (row, col) in a swizzled stage plane
+  return row * WROW + ((((col >> 4) ^ ((row >> 3) & 1)) << 4) | (col & 15));
+}
+
+__device__ __forceinline__ bf16x8 tr_read8_v2(const __bf16* p0, const __bf16* p1) {
+  auto q0 = (__attribute__((address_space(3))) s16x4*)(p0);
+  auto q1 = (__attribute__((address_space(3))) s16x4*)(p1);
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16(q1);
+  s16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return __builtin_bit_cast(bf16x8, r);
+}
+
+// TO: live 16-row o tiles of this wave (4, 2 or 1)
+template <int TO, int KX>
+__device__ __forceinline__ void wgrad_mma_v2(const __bf16* Ah, const __bf16* Al, const __bf16* Bh, const __bf16* Bl,
+                                             int row_lane, int col4, int a_col, int b_col, f32x4v (&acc)[KX][4][2]) {
+#pragma unroll
+  for (int s = 0; s < WK / 32; ++s) {
+    // dY rows of this lane: r0 = 32 s + 8 kg + q and r0 + 4 (bit 3 of both = kg & 1: one swizzle per lane)
+    const int ra0 = 32 * s + row_lane, ra1 = ra0 + 4;
+    bf16x8 ah[TO], al[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+      const int c = a_col + 16 * t + col4;
+      const int o0 = wsw(ra0, c), o1 = wsw(ra1, c);
+      ah[t] = tr_read8_v2(Ah + o0, Ah + o1);
+      al[t] = tr_read8_v2(Al + o0, Al + o1);
+    }
+#pragma unroll
+    for (int kx = 0; kx < KX; ++kx) {
+      const int rb0 = ra0 + kx, rb1 = ra1 + kx;  // X row j <-> pixel x0 - HALO + j: tap kx is a row shift
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        const int c = b_col + 16 * tc + col4;
+        const int o0 = wsw(rb0, c), o1 = wsw(rb1, c);
+        const bf16x8 bh = tr_read8_v2(Bh + o0, Bh + o1);
+        const bf16x8 bl = tr_read8_v2(Bl + o0, Bl + o1);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[to], bh, acc[kx][to][tc], 0, 0, 0);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[to], bl, acc[kx][to][tc], 0, 0, 0);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[to], bh, acc[kx][to][tc], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int KX, int S>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
+    const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
+    float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
+    int chunks_per_split, int splits, scan_pyramid_t xd) {
+  constexpr int HALO = KX / 2, T = KX * KX;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  const int qq = L >> 3;
+  int tile = qq % n_tiles;
+  const int split = (qq / n_tiles) * 8 + xcd;
+  const int c_tile = tile % c_tiles;
+  tile /= c_tiles;
+  const int ky = tile % KX;
+  const int o_tile = tile / KX;
+  const int o0 = o_tile * 128, c0 = c_tile * 128;
+  const long long total_chunks = ct.chunk_off[d.n_levels];
+  const long long ch_begin = (long long)split * chunks_per_split;
+  long long ch_end = ch_begin + chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  const bool do_bias = (bias_slab != nullptr) && ky == HALO && c_tile == 0;
+
+  const int q4 = tid & 31, rr = tid >> 5;
+  float4 ra[WNA], rb[WNB(KX)];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_chunk = [&](long long ch) {
+    int lvl = 0;
+#pragma unroll
+    for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+      if (i < d.n_levels && ch >= ct.chunk_off[i]) lvl = i;
+    const int H = d.h[lvl], W = d.w[lvl];
+    const long long r = ch - ct.chunk_off[lvl];
+    const int seg = (int)(r % ct.segs[lvl]);
+    const long long row = r / ct.segs[lvl];  // n * H + y
+    const int y = (int)(row % H);
+    const int x0 = seg * WK;
+    const long long rowbase = d.row_off[lvl] + row * W;
+    const int o = o0 + 4 * q4, c = c0 + 4 * q4;
+#pragma unroll
+    for (int i = 0; i < WNA; ++i) {
+      const int k = rr + 16 * i;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x0 + k < W) {
+        const long long m = rowbase + x0 + k;
+        if ((Ns & 3) == 0 && o + 3 < Ns) {
+          ra[i] = *reinterpret_cast<const float4*>(dy + m * Ns + o);
+        } else {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int e = 0; e < 4; ++e)
+            if (o + e < Ns) t[e] = dy[m * Ns + o + e];
+          ra[i] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+    }
+    const int yy = y + ky - HALO;
+    const bool yok = yy >= 0 && yy < H && c < Cs;
+    const int Wx = (KX == 1) ? xd.w[lvl] : W;
+    const long long xrow = (KX == 1) ? xd.row_off[lvl] + ((row / H) * xd.h[lvl] + (long long)S * y) * Wx
+                                     : rowbase + (long long)(ky - 1) * W;
+#pragma unroll
+    for (int i = 0; i < WNB(KX); ++i) {
+      const int j = rr + 16 * i;
+      const int xx = x0 - HALO + j;
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < WK + KX - 1 && yok && xx >= 0 && xx < W)
+        rb[i] = *reinterpret_cast<const float4*>(x + (xrow + (long long)S * xx) * Cs + c);
+    }
+  };
+  auto store_chunk = [&]() {
+    __bf16* Ah = sm;
+    __bf16* Al = Ah + WK * WROW;
+    __bf16* Bh = Al + WK * WROW;
+    __bf16* Bl = Bh + (WK + KX - 1) * WROW;
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < WNA; ++i) {
+      const int off = wsw(rr + 16 * i, 4 * q4);
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(Ah + off) = hi;
+      *reinterpret_cast<bf16x4*>(Al + off) = lo;
+      if (do_bias) {
+        bsum.x += ra[i].x;
+        bsum.y += ra[i].y;
+        bsum.z += ra[i].z;
+        bsum.w += ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WNB(KX); ++i) {
+      const int j = rr + 16 * i;
+      if (j < WK + KX - 1) {
+        const int off = wsw(j, 4 * q4);
+        split4(rb[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(Bh + off) = hi;
+        *reinterpret_cast<bf16x4*>(Bl + off) = lo;
+      }
+    }
+  };
+
+  // 8 waves: 2 (o) x 4 (c); each wave 64 o x 32 c = 4 x 2 MFMA tiles of 16 x 16, for each of the KX taps
+  const int wm = wid & 1, wn = wid >> 1;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int row_lane = 8 * kg + (lr >> 2), col4 = 4 * (lane & 3);
+  const int a_col = wm * 64, b_col = wn * 32;
+  const bool c_act = c0 + b_col < Cs;
+  const int o_left = Nout - (o0 + a_col);  // live o rows of this wave
+
+  f32x4v acc[KX][4][2];
+#pragma unroll
+  for (int a = 0; a < KX; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  if (ch_begin < ch_end) load_chunk(ch_begin);
+  const __bf16* Ah = sm;
+  const __bf16* Al = Ah + WK * WROW;
+  const __bf16* Bh = Al + WK * WROW;
+  const __bf16* Bl = Bh + (WK + KX - 1) * WROW;
+  for (long long ch = ch_begin; ch < ch_end; ++ch) {
+    store_chunk();
+    if (ch + 1 < ch_end) load_chunk(ch + 1);
+    __syncthreads();
+    // wave-uniform skips of dead tiles (third c tile of Cin = 264 / 265; Cout = 8 / 5 / 1 heads)
+    if (c_act && o_left > 32)
+      wgrad_mma_v2<4, KX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    else if (c_act && o_left > 16)
+      wgrad_mma_v2<2, KX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    else if (c_act && o_left > 0)
+      wgrad_mma_v2<1, KX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    __syncthreads();
+  }
+
+  // C/D map of 16x16: column = lane & 15 = input channel c, row = 4 * (lane >> 4) + reg = output channel o
+  float* out = slab + (long long)split * Nout * T * Cs;
+#pragma unroll
+  for (int kx = 0; kx < KX; ++kx)
+#pragma unroll
+    for (int to = 0; to < 4; ++to)
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        const int c = c0 + b_col + 16 * tc + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + a_col + 16 * to + 4 * kg + r;
+          if (o < Nout && c < Cs) out[((long long)o * T + ky * KX + kx) * Cs + c] = acc[kx][to][tc][r];
+        }
+      }
+
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(smem_raw);  // [16][128]
+    *reinterpret_cast<float4*>(red + rr * 128 + 4 * q4) = bsum;
+    __syncthreads();
+    if (tid < 128) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < 16; ++g) sum += red[g * 128 + tid];
+      if (o0 + tid < Nout) bias_slab[(long long)split * Nout + o0 + tid] = sum;
+    }
+  }
+}
+
+int g_scan_wgrad_v2 = 1;  // scan_tune "wgrad_v2": 1 = the 16x16x32 weight-gradient kernel, 0 = the 32x32x16 one
+
 // weight-slab reduction (float4 columns, splits summed in order) + bias-slab reduction in the extra last block
 __global__ __launch_bounds__(256) void slab_bias_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n,
                                                                float* __restrict__ dw, const float* __restrict__ bs,
@@ -913,8 +1143,19 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
     done = true;
   }
   float* bias_slab = db ? ws + (int64_t)sp * Cout * 9 * Cs : nullptr;
-  hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<3, 1>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout, Cout_s,
-                     ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+  if (g_scan_wgrad_v2) {
+    static bool done2 = false;
+    if (!done2) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      done2 = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<3, 1>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout, Cout_s,
+                       ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+  } else {
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<3, 1>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout,
+                       Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+  }
   SCAN_LAUNCH_CHECK("conv3x3_wgrad_bf16x3");
   // one launch reduces the weight slabs and (last block) the bias slabs
   const int64_t n = (int64_t)Cout * 9 * Cs;
@@ -959,7 +1200,22 @@ extern "C" int scan_conv1x1_wgrad_bf16x3(const float* x, const scan_pyramid_t* x
     done = true;
   }
   float* bias_slab = db ? ws + (int64_t)sp * Cout * Cs : nullptr;
-  if (stride == 1)
+  if (g_scan_wgrad_v2) {
+    static bool done2 = false;
+    if (!done2) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<1, 1>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<1, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      done2 = true;
+    }
+    if (stride == 1)
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<1, 1>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
+                         Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *xd);
+    else
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<1, 2>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
+                         Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *xd);
+  } else if (stride == 1)
     hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<1, 1>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
                        Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *xd);
   else

@@ -240,11 +240,13 @@ CONV_CASES = [
 
 @pytest.fixture
 def conv_generation(request):
-    """scan_tune("conv_v2"): 1 = the 16x16x32-MFMA forward / dgrad kernel (default), 0 = the 32x32x16 one."""
+    """scan_tune("conv_v2" / "wgrad_v2"): 1 = the 16x16x32-MFMA kernels (default), 0 = the 32x32x16 ones."""
     from scan_amd import _lib
     old = _lib.query("scan_tune", b"conv_v2", int(request.param))
+    oldw = _lib.query("scan_tune", b"wgrad_v2", int(request.param))
     yield request.param
     _lib.query("scan_tune", b"conv_v2", old)
+    _lib.query("scan_tune", b"wgrad_v2", oldw)
 
 
 @pytest.mark.parametrize("mode,conv_generation", [("fp32", 1), ("bf16x3", 1), ("bf16x3", 0)], indirect=["conv_generation"])

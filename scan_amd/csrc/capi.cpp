@@ -21,6 +21,7 @@ extern "C" int scan_abi_version(void) { return 1; }
 extern int g_scan_conv_bn256;
 extern int g_scan_conv_v2;
 extern int g_scan_wgrad_v2;
+extern int g_scan_conv_wg1024;
 
 extern "C" int scan_tune(const char* key, int value) {
   if (key == nullptr) return -1;
@@ -28,6 +29,7 @@ extern "C" int scan_tune(const char* key, int value) {
   if (strcmp(key, "conv_bn256") == 0) slot = &g_scan_conv_bn256;
   if (strcmp(key, "conv_v2") == 0) slot = &g_scan_conv_v2;
   if (strcmp(key, "wgrad_v2") == 0) slot = &g_scan_wgrad_v2;
+  if (strcmp(key, "conv_wg1024") == 0) slot = &g_scan_conv_wg1024;
   if (slot == nullptr) return -1;
   const int old = *slot;
   *slot = value;

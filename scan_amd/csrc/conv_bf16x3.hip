@@ -774,7 +774,18 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
   const __bf16* Bh = Al + WK * WROW;
   const __bf16* Bl = Bh + (WK + KX - 1) * WROW;
   for (long long ch = ch_begin; ch < ch_end; ++ch) {
+#ifdef SCAN_EXP_WGRAD_NOSTAGE
+    // TIMING ABLATION ONLY (wrong results): the split + LDS writes happen for the first chunk only; the loads stay
+    if (ch == ch_begin) store_chunk();
+    else {
+#pragma unroll
+      for (int i = 0; i < WNA; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
+#pragma unroll
+      for (int i = 0; i < WNB(KX); ++i) asm volatile("" ::"v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+    }
+#else
     store_chunk();
+#endif
     if (ch + 1 < ch_end) load_chunk(ch + 1);
     __syncthreads();
     // wave-uniform skips: a wave whose 32 c columns lie beyond Cs (third c tile of Cin = 264 / 265) or whose o rows
@@ -1039,7 +1050,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
   }
 }
 
-int g_scan_wgrad_v2 = 1;  // scan_tune "wgrad_v2": 1 = the 16x16x32 weight-gradient kernel, 0 = the 32x32x16 one
+// scan_tune "wgrad_v2": 1 = the 16x16x32 weight-gradient kernel, 0 (default) = the 32x32x16 one.  Same-box A/B of the
+// bench step (profiles/r02_ab_wgrad_v2.txt): 0.418 vs 0.414 ms per launch -- this kernel is bound by its staging phases
+// (fp32 -> bf16 split + LDS writes between two barriers per chunk), not by the matrix pipe, so the shape does not pay.
+int g_scan_wgrad_v2 = 0;
 
 // weight-slab reduction (float4 columns, splits summed in order) + bias-slab reduction in the extra last block
 __global__ __launch_bounds__(256) void slab_bias_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n,

@@ -60,7 +60,7 @@ __device__ __forceinline__ int swz(int idx) { return (idx >> 1) & 2; }
 // KS = 1 also serves the stride-2 1x1 convs through MAP (0: same pyramid; 1: source = 2 * output, forward of a stride-2
 // conv; 2: source = output / 2 on even coordinates, zero elsewhere: its data gradient), like the first kernel.
 template <int BN, int TH, int NT, int KS>
-__global__ __launch_bounds__(NT, 2) void conv_bf16x3_v2_kernel(
+__global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
     const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
     float* __restrict__ dst, int Nout, int Ns, int relu, TileTab2 tt, int n_tiles, scan_pyramid_t sd, int map,
@@ -355,6 +355,7 @@ static void launch_v2(const float* x, const scan_pyramid_t* od, int32_t Cs, cons
 // Instance choice for an output pyramid and channel count: 64 (8x16-pixel tiles, 256 threads), 128 or 256 (16x16-pixel
 // tiles, 512 threads; 256 when the channels fill 256-wide tiles and the launch keeps >= 2 workgroups per CU).
 extern int g_scan_conv_bn256;
+int g_scan_conv_wg1024 = 0;  // scan_tune "conv_wg1024": run the 256-channel instance with 16 waves (32 px x 128 ch each)
 static int v2_instance(const scan_pyramid_t* od, int32_t Nout) {
   if (Nout <= 64) return 64;
   TileTab2 tt;
@@ -373,7 +374,12 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
   const __bf16* l = reinterpret_cast<const __bf16*>(wl);
   switch (v2_instance(d, Nout)) {
     case 64: launch_v2<64, 8, 256, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
-    case 256: launch_v2<256, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+    case 256:
+      if (g_scan_conv_wg1024)
+        launch_v2<256, 16, 1024, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else
+        launch_v2<256, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      break;
     default: launch_v2<128, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
   }
   SCAN_LAUNCH_CHECK("conv3x3_bf16x3_v2");

@@ -99,3 +99,67 @@ class MultiHeadAttention(nn.Module):
         context = torch.bmm(attention, value).view(b, -1, d * h)
         output = self.dropout(self.linear_final(context))
         return self.layer_norm(residual + output), attention
+
+
+# ----------------------------------------------------------------------------- NCHW drop-in modules
+# The reference's modules call torch.nn.Conv2d / nn.GroupNorm / F.conv2d on NCHW tensors (rpn/fcos/fcos.py:25-64,
+# rpn/fcos/condgraph.py:86-106,619-629, discriminator/fcos_head_discriminator_con.py:20-87).  These classes keep those
+# constructor signatures and the NCHW call convention, so such a module file runs on the HIP kernels by swapping the
+# import (INTEGRATION.md).  A torch.channels_last NCHW tensor IS the kernels' pixel-major row matrix, so the adaptor
+# is a view in both directions; any other layout is converted once on entry.
+def _to_rows(x):
+    """[N,C,H,W] -> (rows [N*H*W, Cs], PyramidShape, C): zero-copy for channels_last tensors with C % 4 == 0."""
+    n, c, h, w = x.shape
+    rows = x.permute(0, 2, 3, 1)
+    if c % 4 != 0:
+        rows = torch.nn.functional.pad(rows, (0, ops.pad4(c) - c))
+    rows = rows.contiguous().view(n * h * w, -1)
+    return rows, ops.PyramidShape(n, [(h, w)]), c
+
+
+def _to_nchw(rows, shape, c):
+    h, w = shape.sizes[0]
+    return rows.view(shape.n_images, h, w, rows.shape[1])[..., :c].permute(0, 3, 1, 2)  # channels_last NCHW view
+
+
+class Conv2d(nn.Conv2d):
+    """torch.nn.Conv2d(in_channels, out_channels, kernel_size, stride=1, padding=0, ...) on the MFMA conv kernels:
+    kernel 1 / 3 (5 / 7 through the generic kernel), stride 1 / 2, padding = kernel // 2, dilation 1, groups 1 -- the
+    convolutions the SCAN modules build.  Input and output are NCHW (channels_last memory format)."""
+
+    def forward(self, x):
+        k, s = self.kernel_size[0], self.stride[0]
+        if (self.kernel_size[0] != self.kernel_size[1] or self.stride[0] != self.stride[1] or self.groups != 1
+                or tuple(self.dilation) != (1, 1) or tuple(self.padding) != (k // 2, k // 2) or s not in (1, 2)
+                or self.padding_mode != "zeros"):
+            raise RuntimeError("scan_amd.layers.Conv2d: only square kernels, stride 1 / 2, padding = k // 2, "
+                               "dilation 1, groups 1 are built (what the SCAN modules use)")
+        rows, shape, _ = _to_rows(x)
+        w = self.weight
+        if not w.permute(0, 2, 3, 1).is_contiguous():  # kernels read [Cout][k*k][Cin]
+            w = w.contiguous(memory_format=torch.channels_last)
+        y = ops.conv2d(rows, w, self.bias, shape, k, s)
+        return _to_nchw(y, shape.conv_out(k, s), self.out_channels)
+
+
+class GroupNorm(nn.GroupNorm):
+    """torch.nn.GroupNorm(32, 256) (+ the ReLU that follows it in every SCAN tower when relu=True) on NCHW tensors."""
+
+    def __init__(self, num_groups, num_channels, eps=1e-5, affine=True, relu=False):
+        super().__init__(num_groups, num_channels, eps, affine)
+        self.fuse_relu = relu
+
+    def forward(self, x):
+        rows, shape, c = _to_rows(x)
+        y = ops.groupnorm_relu(rows, self.weight, self.bias, shape, relu=self.fuse_relu, eps=self.eps)
+        return _to_nchw(y, shape, c)
+
+
+def dynamic_conv_softmax(features, kernel_par):
+    """GRAPHModule.dynamic_conv + softmax(dim=1) (reference condgraph.py:619-629, 344-346): features [N,256,H,W],
+    kernel_par [K,256] -> (act-map logits [N,K,H,W], act maps [N,K,H,W])."""
+    rows, shape, _ = _to_rows(features)
+    logits, probs = ops.dynconv_softmax(rows, kernel_par)
+    h, w = shape.sizes[0]
+    back = lambda t: t.view(shape.n_images, h, w, t.shape[1]).permute(0, 3, 1, 2)
+    return back(logits), back(probs)

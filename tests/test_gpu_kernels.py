@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+from torch import nn
 
 pytestmark = pytest.mark.gpu
 
@@ -690,3 +691,40 @@ def test_groupnorm_sums_from_conv_epilogue(device, sizes):
         outs.append((y.detach(), r.grad, wv.grad, gv.grad, bt.grad))
     for a, c in zip(*outs):
         assert (a - c).abs().max().item() <= 2e-5 * max(1.0, c.abs().max().item())
+
+
+def test_nchw_drop_in_modules(device):
+    """a tower written like the reference writes it -- nn.Sequential of Conv2d(256, 256, 3, stride=1, padding=1),
+    GroupNorm(32, 256), ReLU (rpn/fcos/fcos.py:25-49) -- on NCHW tensors, with scan_amd.layers classes swapped in for
+    torch.nn's, plus F.conv2d-style dynamic conv + softmax (condgraph.py:619-629): outputs and every gradient against
+    the same module built from torch.nn on the CPU."""
+    from scan_amd import layers as L
+    torch.manual_seed(11)
+
+    def tower(conv, gn):
+        return nn.Sequential(conv(256, 256, kernel_size=3, stride=1, padding=1), gn(32, 256), nn.ReLU(),
+                             conv(256, 8, kernel_size=3, stride=1, padding=1))
+
+    ref = tower(nn.Conv2d, nn.GroupNorm)
+    mine = tower(L.Conv2d, L.GroupNorm).to(device)
+    mine.load_state_dict(ref.state_dict())
+    x = torch.randn(2, 256, 20, 28)
+    xr = x.clone().requires_grad_(True)
+    xm = x.to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    yr, ym = ref(xr), mine(xm)
+    assert ym.shape == yr.shape == (2, 8, 20, 28)
+    np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-4)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    ym.backward(gy.to(device))
+    np.testing.assert_allclose(xm.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=1e-4 * float(xr.grad.abs().max()))
+    for (n, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+        np.testing.assert_allclose(pm.grad.cpu().numpy(), pr.grad.numpy(), rtol=1e-3,
+                                   atol=2e-4 * float(pr.grad.abs().max()), err_msg=n)
+    # semantic-conditioned dynamic conv on NCHW features
+    f = torch.randn(2, 256, 12, 20)
+    kp = torch.randn(9, 256) * 0.1
+    lg, pb = L.dynamic_conv_softmax(f.to(device), kp.to(device))
+    lr = F.conv2d(f, kp.view(9, 256, 1, 1))
+    np.testing.assert_allclose(lg.cpu().numpy(), lr.numpy(), rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(pb.cpu().numpy(), lr.softmax(1).numpy(), rtol=1e-4, atol=1e-5)

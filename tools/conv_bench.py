@@ -54,8 +54,37 @@ def run(shape_def, reps, dev):
     return y, us, flops / us * 1e-6
 
 
+def run_wgrad(shape_def, reps, dev):
+    name, n, sizes, cin, cout = shape_def
+    shape = ops.PyramidShape(n, sizes)
+    cs = ops.pad4(cin)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((shape.rows, cs), device=dev, generator=g)
+    dy = torch.randn((shape.rows, cout), device=dev, generator=g)
+    dw = torch.empty((cout, 9, cs), device=dev)
+    db = torch.empty((cout,), device=dev)
+    ws = torch.empty((_lib.query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),), device=dev)
+    flops = 2.0 * shape.rows * cout * 9 * cin
+
+    def go():
+        _lib.call("scan_conv3x3_wgrad_bf16x3", ops._ptr(x), shape.ref(), cs, ops._ptr(dy), cout, cout, ops._ptr(dw),
+                  ops._ptr(db), 0, ops._ptr(ws), ops._stream())
+
+    go()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        go()
+    e.record()
+    torch.cuda.synchronize()
+    us = s.elapsed_time(e) * 1e3 / reps
+    return dw.clone(), us, flops / us * 1e-6
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--op", choices=("fwd", "wgrad"), default="fwd")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--variants", default="conv_bn256=0,conv_bn256=1")
@@ -70,7 +99,7 @@ def main():
             for key, val in variants:
                 old = _lib.query("scan_tune", key.encode(), int(val))
                 assert old >= 0, key
-                y, us, tf = run(sd, a.reps, dev)
+                y, us, tf = (run if a.op == "fwd" else run_wgrad)(sd, a.reps, dev)
                 _lib.query("scan_tune", key.encode(), old)
                 if ref is None:
                     ref = y

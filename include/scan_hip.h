@@ -47,10 +47,14 @@ int scan_abi_version(void);
  *   "conv_v2"     1 (default): bf16x3 forward / data-gradient convs run on the v_mfma_f32_16x16x32_bf16 kernel;
  *                 0: on the v_mfma_f32_32x32x16_bf16 kernel (same arithmetic, different summation order inside a
  *                 32-channel chunk).
- *   "wgrad_v2"    1 (default) / 0: the same choice for the bf16x3 weight-gradient kernels. */
+ *   "wgrad_v2"    the same choice for the bf16x3 weight-gradient kernels: 1 / 0, or 2 (default) = by shape (the
+ *                 16x16x32 kernel where the input channels fill whole 128-wide tiles).
+ *   "conv_wg1024" 256-channel forward / dgrad instance with 16 waves per workgroup: 1 / 0, or 2 (default) = on
+ *                 multi-level pyramids. */
 int scan_tune(const char* key, int value);
 
-/* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels. */
+/* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels;
+ * 1256 = the 256-channel tile on 16-wave workgroups. */
 int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout);
 
 /* ---- SigmoidFocalLoss  (replaces _C.sigmoid_focalloss_forward / _backward,

@@ -1050,10 +1050,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
   }
 }
 
-// scan_tune "wgrad_v2": 1 = the 16x16x32 weight-gradient kernel, 0 (default) = the 32x32x16 one.  Same-box A/B of the
-// bench step (profiles/r02_ab_wgrad_v2.txt): 0.418 vs 0.414 ms per launch -- this kernel is bound by its staging phases
-// (fp32 -> bf16 split + LDS writes between two barriers per chunk), not by the matrix pipe, so the shape does not pay.
-int g_scan_wgrad_v2 = 0;
+// scan_tune "wgrad_v2": 1 = always the 16x16x32 weight-gradient kernel, 0 = always the 32x32x16 one, 2 (default) = by
+// shape.  Same-process A/B per layer (profiles/r02_wgrad_ab.txt): +3...11 % where the input channels fill whole
+// 128-wide tiles (256 -> 256 towers 758 -> 683 us, conv3_x 1785 -> 1706, conv4_x 1716 -> 1667), -1...3 % on the
+// 264 / 268-channel inputs (dis P3, head_out: a third, almost empty channel tile) -- so those stay on the first kernel.
+int g_scan_wgrad_v2 = 2;
+static inline bool wgrad_use_v2(int Cs) { return g_scan_wgrad_v2 == 1 || (g_scan_wgrad_v2 == 2 && Cs % 128 == 0); }
 
 // weight-slab reduction (float4 columns, splits summed in order) + bias-slab reduction in the extra last block
 __global__ __launch_bounds__(256) void slab_bias_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n,
@@ -1157,7 +1159,7 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
     done = true;
   }
   float* bias_slab = db ? ws + (int64_t)sp * Cout * 9 * Cs : nullptr;
-  if (g_scan_wgrad_v2) {
+  if (wgrad_use_v2(Cs)) {
     static bool done2 = false;
     if (!done2) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1>),
@@ -1214,7 +1216,7 @@ extern "C" int scan_conv1x1_wgrad_bf16x3(const float* x, const scan_pyramid_t* x
     done = true;
   }
   float* bias_slab = db ? ws + (int64_t)sp * Cout * Cs : nullptr;
-  if (g_scan_wgrad_v2) {
+  if (wgrad_use_v2(Cs)) {
     static bool done2 = false;
     if (!done2) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<1, 1>),

@@ -355,7 +355,11 @@ static void launch_v2(const float* x, const scan_pyramid_t* od, int32_t Cs, cons
 // Instance choice for an output pyramid and channel count: 64 (8x16-pixel tiles, 256 threads), 128 or 256 (16x16-pixel
 // tiles, 512 threads; 256 when the channels fill 256-wide tiles and the launch keeps >= 2 workgroups per CU).
 extern int g_scan_conv_bn256;
-int g_scan_conv_wg1024 = 0;  // scan_tune "conv_wg1024": run the 256-channel instance with 16 waves (32 px x 128 ch each)
+// scan_tune "conv_wg1024": the 256-channel instance with 16 waves (32 px x 128 ch each, 128 registers, 4 waves per
+// SIMD) instead of 8 -- 1 = always, 0 = never, 2 (default) = on multi-level pyramids, where it measured +10 % (tower
+// layer over P3..P7, 4 frames: 661 -> 600 us; the small levels' partial tiles leave the 8-wave workgroups short of
+// work to hide latency); single-level layers +-1 %.
+int g_scan_conv_wg1024 = 2;
 static int v2_instance(const scan_pyramid_t* od, int32_t Nout) {
   if (Nout <= 64) return 64;
   TileTab2 tt;
@@ -375,7 +379,7 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
   switch (v2_instance(d, Nout)) {
     case 64: launch_v2<64, 8, 256, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
     case 256:
-      if (g_scan_conv_wg1024)
+      if (g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1))
         launch_v2<256, 16, 1024, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       else
         launch_v2<256, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
@@ -401,4 +405,9 @@ int conv1x1_bf16x3_v2_launch(const float* x, const scan_pyramid_t* xd, int32_t C
 }
 
 // which instance a 3x3 launch on pyramid d with Nout output channels takes (bench.py labels its timings with it)
-extern "C" int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout) { return d ? v2_instance(d, Nout) : -1; }
+// 64 / 128 / 256, or 1256 for the 256-channel tile run by 16-wave (1024-thread) workgroups
+extern "C" int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout) {
+  if (!d) return -1;
+  const int bn = v2_instance(d, Nout);
+  return (bn == 256 && (g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1))) ? 1256 : bn;
+}

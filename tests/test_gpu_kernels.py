@@ -305,6 +305,8 @@ def test_conv_instances_agree_full_size(device):
     from scan_amd import _lib, ops
     shape = ops.PyramidShape(4, [(128, 256)])
     assert _lib.query("scan_conv3x3_bf16x3_instance", shape.ref(), 256) == 256
+    pyr = ops.PyramidShape(4, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)])
+    assert _lib.query("scan_conv3x3_bf16x3_instance", pyr.ref(), 256) == 1256  # 16-wave workgroups on pyramids
     torch.manual_seed(3)
     x = torch.randn(shape.rows, 256, device=device)
     w = (torch.randn(256, 256, 3, 3, device=device) / 48).contiguous(memory_format=torch.channels_last)
@@ -338,6 +340,28 @@ def test_conv_instances_agree_full_size(device):
     for a, c in zip(ref, first):
         assert torch.allclose(a.double(), c.double(), rtol=1e-4, atol=1e-5 * float(c.abs().max())), \
             (a.double() - c.double()).abs().max().item()
+
+
+def test_conv_16_wave_instance_on_pyramid(device):
+    """a tower layer over the five-level pyramid of 4 frames takes the 256-channel tile on 16-wave workgroups; the
+    8-wave workgroups (scan_tune conv_wg1024 = 0) and per-level launches give bit-identical results."""
+    from scan_amd import _lib, ops
+    pyr = ops.PyramidShape(4, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)])
+    torch.manual_seed(5)
+    x = torch.randn(pyr.rows, 256, device=device)
+    w = (torch.randn(256, 256, 3, 3, device=device) / 48).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(256, device=device)
+    with torch.no_grad():
+        y16 = ops.conv2d(x, w, b, pyr, 3, 1, relu=True)
+        old = _lib.query("scan_tune", b"conv_wg1024", 0)
+        try:
+            y8 = ops.conv2d(x, w, b, pyr, 3, 1, relu=True)
+        finally:
+            _lib.query("scan_tune", b"conv_wg1024", old)
+        assert torch.equal(y16, y8)
+        for l in range(pyr.n_levels):
+            yl = ops.conv2d(x[pyr.row_off[l]:pyr.row_off[l + 1]].contiguous(), w, b, pyr.level(l), 3, 1, relu=True)
+            assert torch.equal(yl, y16[pyr.row_off[l]:pyr.row_off[l + 1]]), l
 
 
 def test_conv2d_linearity_full_size(device):

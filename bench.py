@@ -43,14 +43,11 @@ PEAK_BF16X3_TFLOPS = 2500.0 / 3.0
 
 def pmc_traffic(kernel_name):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r01_pmc_traffic.json; FETCH_SIZE doubled per the gfx950 correction).  None if not recorded."""
-    key = {"conv3x3_wgrad_bf16x3_kernel<3,1>": "conv3x3_bf16x3_wgrad",
-           "conv3x3_bf16x3_kernel<128,16,512,3>": "conv3x3_bf16x3_fwd_dgrad_bn128",
-           "conv3x3_bf16x3_kernel<64,8,256,3>": "conv3x3_bf16x3_fwd_bn64", "conv_igemm_kernel<0,4>": "conv_igemm_fwd",
-           "conv_igemm_kernel<1,4>": "conv_igemm_dgrad", "conv_wgrad_kernel": "conv_wgrad_fp32"}.get(kernel_name)
+    (profiles/r02_pmc_traffic.json, written by tools/pmc_summarize.py; FETCH_SIZE doubled per the gfx950 correction),
+    keyed by the kernel symbol.  None if not recorded."""
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            rec = json.load(f).get(key)
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
+            rec = json.load(f).get(kernel_name)
         return rec["hbm_bytes"] if rec else None
     except Exception:
         return None
@@ -68,8 +65,10 @@ def symbol_of(name):
         if bn == 1256:
             bn, nt = 256, 1024
         return "conv_bf16x3_v2_kernel<%d,%d,%d,%d>" % (bn, th, nt, 3 if m.group(1) == "3x3" else 1)
-    return {"conv1x1_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel<1,S>",
-            "conv3x3_bf16x3_wgrad": "conv3x3_wgrad_bf16x3_kernel<3,1>",
+    return {"conv1x1_bf16x3_wgrad_g1": "conv3x3_wgrad_bf16x3_kernel<1,S>",
+            "conv1x1_bf16x3_wgrad_g2": "conv_wgrad_bf16x3_v2_kernel<1,S>",
+            "conv3x3_bf16x3_wgrad_g1": "conv3x3_wgrad_bf16x3_kernel<3,1>",
+            "conv3x3_bf16x3_wgrad_g2": "conv_wgrad_bf16x3_v2_kernel<3,1>",
             "conv_smallcin_bf16x3": "conv_smallcin_kernel",
             "conv_igemm_fwd": "conv_igemm_kernel<0,4>", "conv_igemm_dgrad": "conv_igemm_kernel<1,4>",
             "conv_wgrad": "conv_wgrad_kernel"}.get(name, name)
@@ -307,7 +306,7 @@ def main():
             name, r = dom
             roof = {"bound": "mfma", "kernel": name, "achieved": round(r["tflops"], 2), "peak": round(peak_for(name), 1),
                     "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_for(name), 4), "traffic": pmc_traffic(name),
-                    "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/r01_pmc_traffic.json)",
+                    "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/r02_pmc_traffic.json)",
                     "peak_note": "algorithmic fp32-equivalent FLOPs; bf16x3 kernels spend 3 bf16 MFMAs per product, "
                                  "peak = 2.5 PFLOP/s dense bf16 / 3",
                     "launches": r["launches"], "avg_launch_ms": round(r["avg_ms"], 4),

@@ -56,6 +56,8 @@ int scan_tune(const char* key, int value);
 /* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels;
  * 1256 = the 256-channel tile on 16-wave workgroups. */
 int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout);
+/* Which bf16x3 weight-gradient kernel a launch with input channel stride Cs takes: 2 = 16x16x32 MFMA, 1 = 32x32x16. */
+int scan_conv_wgrad_bf16x3_generation(int32_t Cs);
 
 /* ---- SigmoidFocalLoss  (replaces _C.sigmoid_focalloss_forward / _backward,
  *      csrc/SigmoidFocalLoss.h:10-41, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-187) ----

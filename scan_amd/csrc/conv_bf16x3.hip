@@ -1056,6 +1056,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
 // 264 / 268-channel inputs (dis P3, head_out: a third, almost empty channel tile) -- so those stay on the first kernel.
 int g_scan_wgrad_v2 = 2;
 static inline bool wgrad_use_v2(int Cs) { return g_scan_wgrad_v2 == 1 || (g_scan_wgrad_v2 == 2 && Cs % 128 == 0); }
+// 2 = the 16x16x32 weight-gradient kernel, 1 = the 32x32x16 one, for an input channel stride Cs (bench.py labels)
+extern "C" int scan_conv_wgrad_bf16x3_generation(int32_t Cs) { return wgrad_use_v2(Cs) ? 2 : 1; }
 
 // weight-slab reduction (float4 columns, splits summed in order) + bias-slab reduction in the extra last block
 __global__ __launch_bounds__(256) void slab_bias_reduce_kernel(const float* __restrict__ slab, int splits, int64_t n,

@@ -384,7 +384,12 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
       else
         launch_v2<256, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       break;
-    default: launch_v2<128, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+    default:
+      if (g_scan_conv_wg1024 == 1 || g_scan_conv_wg1024 == 3)
+        launch_v2<128, 16, 1024, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else
+        launch_v2<128, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      break;
   }
   SCAN_LAUNCH_CHECK("conv3x3_bf16x3_v2");
   return 0;

@@ -364,7 +364,8 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[1] and fast and ksize == 3:
             ws = x.new_empty((query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),))
             dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
-            ev = kernel_timer.begin("conv3x3_bf16x3_wgrad", 2.0 * oshape.rows * cout * T * cin)
+            ev = kernel_timer.begin("conv3x3_bf16x3_wgrad_g%d" % query("scan_conv_wgrad_bf16x3_generation", cs)
+                                    if kernel_timer.enabled else "", 2.0 * oshape.rows * cout * T * cin)
             want_db = has_bias and ctx.needs_input_grad[2]
             if want_db:
                 db = ctx.bgrad_buf if direct_b else x.new_empty((cout,))
@@ -380,7 +381,8 @@ class _Conv2d(torch.autograd.Function):
         elif ctx.needs_input_grad[1] and fast:  # 1x1, stride 1 or 2
             ws = x.new_empty((query("scan_conv1x1_wgrad_bf16x3_ws_floats", oshape.ref(), cs, cout),))
             dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
-            ev = kernel_timer.begin("conv1x1_bf16x3_wgrad", 2.0 * oshape.rows * cout * T * cin)
+            ev = kernel_timer.begin("conv1x1_bf16x3_wgrad_g%d" % query("scan_conv_wgrad_bf16x3_generation", cs)
+                                    if kernel_timer.enabled else "", 2.0 * oshape.rows * cout * T * cin)
             want_db = has_bias and ctx.needs_input_grad[2]
             if want_db:
                 db = ctx.bgrad_buf if direct_b else x.new_empty((cout,))

@@ -14,23 +14,33 @@ import gzip
 import json
 import sys
 
-GROUPS = [  # (substring of the kernel name, group key)
+GROUPS = [  # (substring of the kernel name, group key); conv keys = the symbols bench.py's roofline names
+    ("conv_bf16x3_v2_kernelILi256ELi16ELi1024ELi3", "conv_bf16x3_v2_kernel<256,16,1024,3>"),
+    ("conv_bf16x3_v2_kernelILi256ELi16ELi512ELi3", "conv_bf16x3_v2_kernel<256,16,512,3>"),
+    ("conv_bf16x3_v2_kernelILi128ELi16ELi512ELi3", "conv_bf16x3_v2_kernel<128,16,512,3>"),
+    ("conv_bf16x3_v2_kernelILi64ELi8ELi256ELi3", "conv_bf16x3_v2_kernel<64,8,256,3>"),
+    ("conv_bf16x3_v2_kernelILi128ELi16ELi512ELi1", "conv_bf16x3_v2_kernel<128,16,512,1>"),
+    ("conv_bf16x3_v2_kernelILi64ELi8ELi256ELi1", "conv_bf16x3_v2_kernel<64,8,256,1>"),
     ("conv3x3_bf16x3_kernelILi128ELi16ELi512ELi3", "conv3x3_bf16x3_fwd_dgrad_bn128"),
     ("conv3x3_bf16x3_kernelILi64ELi8ELi256ELi3", "conv3x3_bf16x3_fwd_bn64"),
     ("conv3x3_bf16x3_kernelILi128ELi16ELi512ELi1", "conv1x1_bf16x3_fwd_dgrad_bn128"),
     ("conv3x3_bf16x3_kernelILi64ELi8ELi256ELi1", "conv1x1_bf16x3_fwd_dgrad_bn64"),
-    ("conv3x3_wgrad_bf16x3_kernelILi3", "conv3x3_bf16x3_wgrad"), ("conv3x3_wgrad_bf16x3_kernel<3", "conv3x3_bf16x3_wgrad"),
-    ("conv3x3_wgrad_bf16x3_kernelILi1", "conv1x1_bf16x3_wgrad"), ("conv3x3_wgrad_bf16x3_kernel<1", "conv1x1_bf16x3_wgrad"),
-    ("conv_smallcin_kernel", "conv_smallcin_bf16x3"), ("dbscan_neighbors_kernel", "dbscan_neighbors"),
+    ("conv_wgrad_bf16x3_v2_kernelILi3", "conv_wgrad_bf16x3_v2_kernel<3,1>"), ("conv_wgrad_bf16x3_v2_kernel<3", "conv_wgrad_bf16x3_v2_kernel<3,1>"),
+    ("conv_wgrad_bf16x3_v2_kernelILi1", "conv_wgrad_bf16x3_v2_kernel<1,S>"), ("conv_wgrad_bf16x3_v2_kernel<1", "conv_wgrad_bf16x3_v2_kernel<1,S>"),
+    ("conv3x3_wgrad_bf16x3_kernelILi3", "conv3x3_wgrad_bf16x3_kernel<3,1>"), ("conv3x3_wgrad_bf16x3_kernel<3", "conv3x3_wgrad_bf16x3_kernel<3,1>"),
+    ("conv3x3_wgrad_bf16x3_kernelILi1", "conv3x3_wgrad_bf16x3_kernel<1,S>"), ("conv3x3_wgrad_bf16x3_kernel<1", "conv3x3_wgrad_bf16x3_kernel<1,S>"),
+    ("conv_smallcin_kernel", "conv_smallcin_kernel"), ("dbscan_neighbors_kernel", "dbscan_neighbors"),
     ("slab_bias_reduce_kernel", "slab_bias_reduce"),
-    ("conv_igemm_kernel<0", "conv_igemm_fwd"), ("conv_igemm_kernel<1", "conv_igemm_dgrad"),
-    ("conv_wgrad_kernel", "conv_wgrad_fp32"),
+    ("conv_igemm_kernel<0", "conv_igemm_kernel<0,4>"), ("conv_igemm_kernel<1", "conv_igemm_kernel<1,4>"),
+    ("conv_wgrad_kernel", "conv_wgrad_kernel"),
     ("gn_stats_kernel", "gn_stats"), ("gn_apply_kernel", "gn_apply"), ("gn_bwd_reduce_kernel", "gn_bwd_reduce"),
     ("gn_bwd_apply_kernel", "gn_bwd_apply"), ("relu_bwd_kernel", "relu_bwd"),
     ("maxpool2_fwd_kernel", "maxpool2_fwd"), ("maxpool2_bwd_kernel", "maxpool2_bwd"),
     ("dynconv_fwd_kernel", "dynconv_fwd"), ("dynconv_bwd_kernel", "dynconv_bwd"),
-    ("sigmoid_focal_fwd", "sigmoid_focal_fwd"), ("sfl_fwd", "softmax_focal_fwd"), ("sfl_bwd", "softmax_focal_bwd"),
-    ("cka_fwd_kernel", "cka_bce_fwd"), ("cka_bwd_kernel", "cka_bce_bwd"), ("scale_kernel", "grl_scale"),
+    ("focal_fwd_kernel", "sigmoid_focal_fwd"), ("focal_bwd_kernel", "sigmoid_focal_bwd"),
+    ("sfl_kernelILb0", "softmax_focal_fwd"), ("sfl_kernel<false", "softmax_focal_fwd"),
+    ("sfl_kernelILb1", "softmax_focal_bwd"), ("sfl_kernel<true", "softmax_focal_bwd"),
+    ("cka_fwd", "cka_bce_fwd"), ("cka_bwd_kernel", "cka_bce_bwd"), ("scale_kernel", "grl_scale"),
     ("sgd_kernel", "sgd_momentum"), ("weight_split_kernel", "weight_split"),
 ]
 

@@ -62,8 +62,8 @@ def symbol_of(name):
     if m:
         bn = int(m.group(3))
         th, nt = (8, 256) if bn == 64 else (16, 512)
-        if bn == 1256:
-            bn, nt = 256, 1024
+        if bn > 1000:
+            bn, nt = bn - 1000, 1024
         return "conv_bf16x3_v2_kernel<%d,%d,%d,%d>" % (bn, th, nt, 3 if m.group(1) == "3x3" else 1)
     return {"conv1x1_bf16x3_wgrad_g1": "conv3x3_wgrad_bf16x3_kernel<1,S>",
             "conv1x1_bf16x3_wgrad_g2": "conv_wgrad_bf16x3_v2_kernel<1,S>",

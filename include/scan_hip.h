@@ -49,12 +49,14 @@ int scan_abi_version(void);
  *                 32-channel chunk).
  *   "wgrad_v2"    the same choice for the bf16x3 weight-gradient kernels: 1 / 0, or 2 (default) = by shape (the
  *                 16x16x32 kernel where the input channels fill whole 128-wide tiles).
- *   "conv_wg1024" 256-channel forward / dgrad instance with 16 waves per workgroup: 1 / 0, or 2 (default) = on
- *                 multi-level pyramids. */
+ *   "conv_wg1024" 1 (default): the 128- / 256-channel forward / dgrad instances run 16 waves per workgroup; 0: 8 waves;
+ *                 2: 16 waves only for the 256-channel tile on multi-level pyramids.  Same results bit for bit.
+ *   "conv_tpb3"   bit 0 / bit 1: the 128- / 64-channel instance stages three taps per barrier (default 0; same
+ *                 results bit for bit). */
 int scan_tune(const char* key, int value);
 
 /* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels;
- * 1256 = the 256-channel tile on 16-wave workgroups. */
+ * 1128 / 1256 = the 128- / 256-channel tile on 16-wave workgroups. */
 int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout);
 /* Which bf16x3 weight-gradient kernel a launch with input channel stride Cs takes: 2 = 16x16x32 MFMA, 1 = 32x32x16. */
 int scan_conv_wgrad_bf16x3_generation(int32_t Cs);

@@ -59,7 +59,9 @@ __device__ __forceinline__ int swz(int idx) { return (idx >> 1) & 2; }
 // BN: output channels per workgroup; TH: tile rows (tile = TH x 16 pixels); NT: threads; KS: 3 or 1.
 // KS = 1 also serves the stride-2 1x1 convs through MAP (0: same pyramid; 1: source = 2 * output, forward of a stride-2
 // conv; 2: source = output / 2 on even coordinates, zero elsewhere: its data gradient), like the first kernel.
-template <int BN, int TH, int NT, int KS>
+// TPB: taps staged per barrier (1, or 3 = one ky row of the 3x3: the weight tiles of three taps share one barrier
+// interval, 4 barriers per 32-channel chunk instead of 10 -- fits for BN <= 128: 2 x 3 x 16 KB + the 41 KB patch)
+template <int BN, int TH, int NT, int KS, int TPB = 1>
 __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
     const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
@@ -76,12 +78,14 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
   constexpr int TN = BN / (16 * WN_WAVES);      // 16-channel tiles per wave (4, or 8 for BN = 256)
   constexpr int ASLOTS = (NPATCH * 8 + NT - 1) / NT;  // float4 of the halo patch per thread per chunk
   constexpr int BSEG = BN * 4 * 2 / NT;               // 16-byte weight segments per thread per (chunk, tap)
+  constexpr int NGRP = NTAPS / TPB;                   // barrier intervals per chunk
   static_assert(TM * WM_WAVES == TH && (TM % 2) == 0, "tile rows must split evenly (and pair up for the fused pool)");
+  static_assert(NTAPS % TPB == 0, "taps per barrier must divide the tap count");
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __bf16* Ah = reinterpret_cast<__bf16*>(smem_raw);  // [NPATCH][32]
   __bf16* Al = Ah + NPATCH * 32;                     // [NPATCH][32]
-  __bf16* Bs = Al + NPATCH * 32;                     // [2 buf][2 plane][BN][32]
+  __bf16* Bs = Al + NPATCH * 32;                     // [2 buf][TPB taps][2 plane][BN][32]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int bid = xcd_remap_v2(blockIdx.x, gridDim.x);
@@ -146,28 +150,35 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
     }
   };
   // ---- weight tile staging: BN rows x 4 segments x 2 planes per (chunk, tap), double-buffered in LDS
-  uint4 rb[BSEG];
-  auto load_b = [&](int cc, int tap) {
+  uint4 rb[TPB][BSEG];
+  auto load_b = [&](int cc, int grp) {
 #pragma unroll
-    for (int i = 0; i < BSEG; ++i) {
-      const int slot = tid + NT * i;
-      const int plane = slot / (BN * 4);
-      const int rem = slot - plane * BN * 4;
-      const int row = rem >> 2, seg = rem & 3;
-      const int o = n0 + row, c = cc * V2_CK + 8 * seg;
-      const __bf16* base = plane ? wl : wh;
-      rb[i] = (o < Nout && c < Csw) ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * NTAPS + tap) * Csw + c)
-                                    : make_uint4(0u, 0u, 0u, 0u);
+    for (int tt = 0; tt < TPB; ++tt) {
+      const int tap = grp * TPB + tt;
+#pragma unroll
+      for (int i = 0; i < BSEG; ++i) {
+        const int slot = tid + NT * i;
+        const int plane = slot / (BN * 4);
+        const int rem = slot - plane * BN * 4;
+        const int row = rem >> 2, seg = rem & 3;
+        const int o = n0 + row, c = cc * V2_CK + 8 * seg;
+        const __bf16* base = plane ? wl : wh;
+        rb[tt][i] = (o < Nout && c < Csw) ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * NTAPS + tap) * Csw + c)
+                                          : make_uint4(0u, 0u, 0u, 0u);
+      }
     }
   };
   auto store_b = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < BSEG; ++i) {
-      const int slot = tid + NT * i;
-      const int plane = slot / (BN * 4);
-      const int rem = slot - plane * BN * 4;
-      const int row = rem >> 2, seg = rem & 3;
-      *reinterpret_cast<uint4*>(Bs + ((buf * 2 + plane) * BN + row) * 32 + ((seg ^ swz(row)) << 3)) = rb[i];
+    for (int tt = 0; tt < TPB; ++tt) {
+#pragma unroll
+      for (int i = 0; i < BSEG; ++i) {
+        const int slot = tid + NT * i;
+        const int plane = slot / (BN * 4);
+        const int rem = slot - plane * BN * 4;
+        const int row = rem >> 2, seg = rem & 3;
+        *reinterpret_cast<uint4*>(Bs + (((buf * TPB + tt) * 2 + plane) * BN + row) * 32 + ((seg ^ swz(row)) << 3)) = rb[tt][i];
+      }
     }
   };
 
@@ -190,38 +201,42 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
     store_a();
     if (cc + 1 < nchunks) load_a(cc + 1);
 #pragma unroll 1
-    for (int tap = 0; tap < NTAPS; ++tap) {
-      const int buf = (cc * NTAPS + tap) & 1;
+    for (int grp = 0; grp < NGRP; ++grp) {
+      const int buf = (cc * NGRP + grp) & 1;
       store_b(buf);
-      if (tap < NTAPS - 1)
-        load_b(cc, tap + 1);
+      if (grp < NGRP - 1)
+        load_b(cc, grp + 1);
       else if (cc + 1 < nchunks)
         load_b(cc + 1, 0);
       __syncthreads();
-      const int ky = tap / KS, kx = tap - KS * ky;
-      const int pxs = lr + kx;  // patch column of this lane's pixel
-      const int p_off = ((wm * TM + ky) * PWK + pxs) * 32 + ((kg ^ swz(pxs)) << 3);
-      const __bf16* bh = Bs + (buf * 2 + 0) * BN * 32 + w_off;
-      const __bf16* bl = Bs + (buf * 2 + 1) * BN * 32 + w_off;
-      bf16x8 ph[TM], pl[TM];
 #pragma unroll
-      for (int tm = 0; tm < TM; ++tm) {
-        ph[tm] = *reinterpret_cast<const bf16x8*>(Ah + p_off + tm * PWK * 32);
-        pl[tm] = *reinterpret_cast<const bf16x8*>(Al + p_off + tm * PWK * 32);
-      }
+      for (int tt = 0; tt < TPB; ++tt) {
+        const int tap = grp * TPB + tt;
+        const int ky = tap / KS, kx = tap - KS * ky;
+        const int pxs = lr + kx;  // patch column of this lane's pixel
+        const int p_off = ((wm * TM + ky) * PWK + pxs) * 32 + ((kg ^ swz(pxs)) << 3);
+        const __bf16* bh = Bs + ((buf * TPB + tt) * 2 + 0) * BN * 32 + w_off;
+        const __bf16* bl = Bs + ((buf * TPB + tt) * 2 + 1) * BN * 32 + w_off;
+        bf16x8 ph[TM], pl[TM];
 #pragma unroll
-      for (int tn = 0; tn < TN; ++tn) {
-        const bf16x8 whv = *reinterpret_cast<const bf16x8*>(bh + tn * 16 * 32);
-        const bf16x8 wlv = *reinterpret_cast<const bf16x8*>(bl + tn * 16 * 32);
+        for (int tm = 0; tm < TM; ++tm) {
+          ph[tm] = *reinterpret_cast<const bf16x8*>(Ah + p_off + tm * PWK * 32);
+          pl[tm] = *reinterpret_cast<const bf16x8*>(Al + p_off + tm * PWK * 32);
+        }
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, pl[tm], acc[tm][tn], 0, 0, 0);
+        for (int tn = 0; tn < TN; ++tn) {
+          const bf16x8 whv = *reinterpret_cast<const bf16x8*>(bh + tn * 16 * 32);
+          const bf16x8 wlv = *reinterpret_cast<const bf16x8*>(bl + tn * 16 * 32);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlv, ph[tm], acc[tm][tn], 0, 0, 0);
+          for (int tm = 0; tm < TM; ++tm)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, pl[tm], acc[tm][tn], 0, 0, 0);
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm)
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, ph[tm], acc[tm][tn], 0, 0, 0);
+          for (int tm = 0; tm < TM; ++tm)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlv, ph[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, ph[tm], acc[tm][tn], 0, 0, 0);
+        }
       }
     }
   }
@@ -332,7 +347,7 @@ static void make_tiles_v2(const scan_pyramid_t* d, TileTab2* tt, int TH) {
   }
 }
 
-template <int BN, int TH, int NT, int KS>
+template <int BN, int TH, int NT, int KS, int TPB = 1>
 static void launch_v2(const float* x, const scan_pyramid_t* od, int32_t Cs, const __bf16* h, const __bf16* l, int32_t Csw,
                       const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns, int32_t relu,
                       hipStream_t st, double* gn_ws, const scan_pyramid_t* sd, int map) {
@@ -341,25 +356,31 @@ static void launch_v2(const float* x, const scan_pyramid_t* od, int32_t Cs, cons
   make_tiles_v2(od, &tt, TH);
   const int tiles = tt.tile_off[od->n_levels];
   const int n_tiles = (Nout + BN - 1) / BN;
-  const size_t sh = (size_t)(2 * (TH + 2 * HALO) * (V2_TW + 2 * HALO) * 32 + 4 * BN * 32) * sizeof(__bf16);
+  const size_t sh = (size_t)(2 * (TH + 2 * HALO) * (V2_TW + 2 * HALO) * 32 + 4 * TPB * BN * 32) * sizeof(__bf16);
   static bool done = false;
   if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_v2_kernel<BN, TH, NT, KS>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     done = true;
   }
-  hipLaunchKernelGGL((conv_bf16x3_v2_kernel<BN, TH, NT, KS>), dim3(tiles * n_tiles), dim3(NT), sh, st, x, *od, Cs, h, l,
-                     Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *sd, map, gn_ws);
+  hipLaunchKernelGGL((conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB>), dim3(tiles * n_tiles), dim3(NT), sh, st, x, *od, Cs, h,
+                     l, Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *sd, map, gn_ws);
 }
 
 // Instance choice for an output pyramid and channel count: 64 (8x16-pixel tiles, 256 threads), 128 or 256 (16x16-pixel
 // tiles, 512 threads; 256 when the channels fill 256-wide tiles and the launch keeps >= 2 workgroups per CU).
 extern int g_scan_conv_bn256;
-// scan_tune "conv_wg1024": the 256-channel instance with 16 waves (32 px x 128 ch each, 128 registers, 4 waves per
-// SIMD) instead of 8 -- 1 = always, 0 = never, 2 (default) = on multi-level pyramids, where it measured +10 % (tower
-// layer over P3..P7, 4 frames: 661 -> 600 us; the small levels' partial tiles leave the 8-wave workgroups short of
-// work to hide latency); single-level layers +-1 %.
-int g_scan_conv_wg1024 = 2;
+// scan_tune "conv_wg1024": 1 (default) = the 128- and 256-channel 3x3 instances run with 16 waves per workgroup (each
+// wave 32 px x 64 / 128 ch, <= 128 registers, four waves per SIMD) instead of 8 (64 px per wave, two per SIMD); 0 = 8
+// waves; 2 = 16 waves only for the 256-channel tile on multi-level pyramids.  Same-process A/B per layer
+// (profiles/r02_conv_instances.txt): tower layer over P3..P7 603 -> 554 us (+8 %: the small levels' partial tiles
+// leave 8-wave workgroups short of work to hide latency), single-level layers +1...3 %, none slower.
+int g_scan_conv_wg1024 = 1;
+// scan_tune "conv_tpb3": stage the three taps of a ky row per barrier (4 barriers per 32-channel chunk instead of 10)
+// -- bit 0: the 128-channel 3x3 instance, bit 1: the 64-channel one (196 instead of 140 registers: two instead of
+// three workgroups per CU).  Default 0: measured +-1 % on every layer (profiles/r02_conv_instances.txt) -- the barrier
+// count is not what bounds these kernels (as MI355X_MICROARCH.md "Barrier count is not the lever" predicts).
+int g_scan_conv_tpb3 = 0;
 static int v2_instance(const scan_pyramid_t* od, int32_t Nout) {
   if (Nout <= 64) return 64;
   TileTab2 tt;
@@ -377,7 +398,12 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
   const __bf16* h = reinterpret_cast<const __bf16*>(wh);
   const __bf16* l = reinterpret_cast<const __bf16*>(wl);
   switch (v2_instance(d, Nout)) {
-    case 64: launch_v2<64, 8, 256, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+    case 64:
+      if (g_scan_conv_tpb3 & 2)
+        launch_v2<64, 8, 256, 3, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else
+        launch_v2<64, 8, 256, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      break;
     case 256:
       if (g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1))
         launch_v2<256, 16, 1024, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
@@ -385,8 +411,12 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
         launch_v2<256, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       break;
     default:
-      if (g_scan_conv_wg1024 == 1 || g_scan_conv_wg1024 == 3)
+      if (g_scan_conv_wg1024 == 1 && (g_scan_conv_tpb3 & 1))
+        launch_v2<128, 16, 1024, 3, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else if (g_scan_conv_wg1024 == 1)
         launch_v2<128, 16, 1024, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else if (g_scan_conv_tpb3 & 1)
+        launch_v2<128, 16, 512, 3, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       else
         launch_v2<128, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       break;
@@ -410,9 +440,11 @@ int conv1x1_bf16x3_v2_launch(const float* x, const scan_pyramid_t* xd, int32_t C
 }
 
 // which instance a 3x3 launch on pyramid d with Nout output channels takes (bench.py labels its timings with it)
-// 64 / 128 / 256, or 1256 for the 256-channel tile run by 16-wave (1024-thread) workgroups
+// 64 / 128 / 256, or 1128 / 1256 for the 128- / 256-channel tile run by 16-wave (1024-thread) workgroups
 extern "C" int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout) {
   if (!d) return -1;
   const int bn = v2_instance(d, Nout);
-  return (bn == 256 && (g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1))) ? 1256 : bn;
+  if (bn == 256 && (g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1))) return 1256;
+  if (bn == 128 && g_scan_conv_wg1024 == 1) return 1128;
+  return bn;
 }

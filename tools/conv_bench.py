@@ -90,27 +90,30 @@ def main():
     ap.add_argument("--variants", default="conv_bn256=0,conv_bn256=1")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
-    variants = [v.split("=") for v in a.variants.split(",")]
+    variants = [(v, "") for v in a.variants.split(",")]  # each variant: "key=value" or "key=value+key=value"
     for sd in SHAPES:
         ref = None
         line = "%-44s" % sd[0]
         best = {}
         for rnd in range(a.rounds):  # A B A B ...: clock / cache state drifts show up as round-to-round spread
             for key, val in variants:
-                old = _lib.query("scan_tune", key.encode(), int(val))
-                assert old >= 0, key
+                olds = []
+                for kv in key.split("+"):
+                    k, v = kv.split("=")
+                    olds.append((k, _lib.query("scan_tune", k.encode(), int(v))))
+                    assert olds[-1][1] >= 0, k
                 y, us, tf = (run if a.op == "fwd" else run_wgrad)(sd, a.reps, dev)
-                _lib.query("scan_tune", key.encode(), old)
+                for k, o in olds:
+                    _lib.query("scan_tune", k.encode(), o)
                 if ref is None:
                     ref = y
                 b = best.setdefault((key, val), [])
                 b.append(us)
                 if rnd == 0 and not torch.equal(ref, y):  # different kernels agree to rounding, not bit for bit
-                    line += " [%s=%s differs: max %.2e of %.2e]" % (key, val, (ref - y).abs().max().item(),
-                                                                     ref.abs().max().item())
+                    line += " [%s differs: max %.2e of %.2e]" % (key, (ref - y).abs().max().item(), ref.abs().max().item())
         flops = 2.0 * ops.PyramidShape(sd[1], sd[2]).rows * sd[4] * 9 * sd[3]
         for (key, val), us in best.items():
-            line += "  %s=%s: %s us -> %6.1f TF" % (key, val, "/".join("%.0f" % u for u in us), flops / min(us) * 1e-6)
+            line += "  %s: %s us -> %6.1f TF" % (key, "/".join("%.0f" % u for u in us), flops / min(us) * 1e-6)
         print(line, flush=True)
 
 

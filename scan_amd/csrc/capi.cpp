@@ -23,6 +23,7 @@ extern int g_scan_conv_v2;
 extern int g_scan_wgrad_v2;
 extern int g_scan_conv_wg1024;
 extern int g_scan_conv_tpb3;
+extern int g_scan_wgrad_wg1024;
 
 extern "C" int scan_tune(const char* key, int value) {
   if (key == nullptr) return -1;
@@ -32,6 +33,7 @@ extern "C" int scan_tune(const char* key, int value) {
   if (strcmp(key, "wgrad_v2") == 0) slot = &g_scan_wgrad_v2;
   if (strcmp(key, "conv_wg1024") == 0) slot = &g_scan_conv_wg1024;
   if (strcmp(key, "conv_tpb3") == 0) slot = &g_scan_conv_tpb3;
+  if (strcmp(key, "wgrad_wg1024") == 0) slot = &g_scan_wgrad_wg1024;
   if (slot == nullptr) return -1;
   const int old = *slot;
   *slot = value;

@@ -848,9 +848,10 @@ __device__ __forceinline__ bf16x8 tr_read8_v2(const __bf16* p0, const __bf16* p1
 }
 
 // TO: live 16-row o tiles of this wave (4, 2 or 1)
-template <int TO, int KX>
+template <int TO, int KX, int TOMAX>
 __device__ __forceinline__ void wgrad_mma_v2(const __bf16* Ah, const __bf16* Al, const __bf16* Bh, const __bf16* Bl,
-                                             int row_lane, int col4, int a_col, int b_col, f32x4v (&acc)[KX][4][2]) {
+                                             int row_lane, int col4, int a_col, int b_col,
+                                             f32x4v (&acc)[KX][TOMAX][2]) {
 #pragma unroll
   for (int s = 0; s < WK / 32; ++s) {
     // dY rows of this lane: r0 = 32 s + 8 kg + q and r0 + 4 (bit 3 of both = kg & 1: one swizzle per lane)
@@ -883,12 +884,19 @@ __device__ __forceinline__ void wgrad_mma_v2(const __bf16* Ah, const __bf16* Al,
   }
 }
 
-template <int KX, int S>
-__global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
+// NT = 512: 8 waves = 2 (o) x 4 (c), each 64 o x 32 c; NT = 1024: 16 waves = 4 x 4, each 32 o x 32 c (48 accumulator
+// registers, <= 128 registers per lane: four waves per SIMD to hide the staging phases and the transposed-read latency)
+template <int KX, int S, int NT>
+__global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v2_kernel(
     const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
     float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
     int chunks_per_split, int splits, scan_pyramid_t xd) {
   constexpr int HALO = KX / 2, T = KX * KX;
+  constexpr int RG = NT / 32;                         // pixel-row groups of the staging roles (16 or 32)
+  constexpr int NA = WK / RG;                         // dY float4 per thread per chunk
+  constexpr int NB = (WK + KX - 1 + RG - 1) / RG;     // X float4 per thread per chunk
+  constexpr int WO = NT / 256;                        // waves along o (2 or 4)
+  constexpr int TOMAX = 128 / (16 * WO);              // 16-row o tiles per wave (4 or 2)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
 
@@ -910,7 +918,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
   const bool do_bias = (bias_slab != nullptr) && ky == HALO && c_tile == 0;
 
   const int q4 = tid & 31, rr = tid >> 5;
-  float4 ra[WNA], rb[WNB(KX)];
+  float4 ra[NA], rb[NB];
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_chunk = [&](long long ch) {
     int lvl = 0;
@@ -926,8 +934,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
     const long long rowbase = d.row_off[lvl] + row * W;
     const int o = o0 + 4 * q4, c = c0 + 4 * q4;
 #pragma unroll
-    for (int i = 0; i < WNA; ++i) {
-      const int k = rr + 16 * i;
+    for (int i = 0; i < NA; ++i) {
+      const int k = rr + RG * i;
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (x0 + k < W) {
         const long long m = rowbase + x0 + k;
@@ -947,8 +955,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
     const long long xrow = (KX == 1) ? xd.row_off[lvl] + ((row / H) * xd.h[lvl] + (long long)S * y) * Wx
                                      : rowbase + (long long)(ky - 1) * W;
 #pragma unroll
-    for (int i = 0; i < WNB(KX); ++i) {
-      const int j = rr + 16 * i;
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
       const int xx = x0 - HALO + j;
       rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j < WK + KX - 1 && yok && xx >= 0 && xx < W)
@@ -962,8 +970,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
     __bf16* Bl = Bh + (WK + KX - 1) * WROW;
     bf16x4 hi, lo;
 #pragma unroll
-    for (int i = 0; i < WNA; ++i) {
-      const int off = wsw(rr + 16 * i, 4 * q4);
+    for (int i = 0; i < NA; ++i) {
+      const int off = wsw(rr + RG * i, 4 * q4);
       split4(ra[i], hi, lo);
       *reinterpret_cast<bf16x4*>(Ah + off) = hi;
       *reinterpret_cast<bf16x4*>(Al + off) = lo;
@@ -975,8 +983,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
       }
     }
 #pragma unroll
-    for (int i = 0; i < WNB(KX); ++i) {
-      const int j = rr + 16 * i;
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
       if (j < WK + KX - 1) {
         const int off = wsw(j, 4 * q4);
         split4(rb[i], hi, lo);
@@ -986,19 +994,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
     }
   };
 
-  // 8 waves: 2 (o) x 4 (c); each wave 64 o x 32 c = 4 x 2 MFMA tiles of 16 x 16, for each of the KX taps
-  const int wm = wid & 1, wn = wid >> 1;
+  // waves: WO (o) x 4 (c); each wave (128 / WO) o x 32 c = TOMAX x 2 MFMA tiles of 16 x 16, for each of the KX taps
+  const int wm = wid % WO, wn = wid / WO;
   const int lr = lane & 15, kg = lane >> 4;
   const int row_lane = 8 * kg + (lr >> 2), col4 = 4 * (lane & 3);
-  const int a_col = wm * 64, b_col = wn * 32;
+  const int a_col = wm * (16 * TOMAX), b_col = wn * 32;
   const bool c_act = c0 + b_col < Cs;
   const int o_left = Nout - (o0 + a_col);  // live o rows of this wave
 
-  f32x4v acc[KX][4][2];
+  f32x4v acc[KX][TOMAX][2];
 #pragma unroll
   for (int a = 0; a < KX; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b)
+    for (int b = 0; b < TOMAX; ++b)
 #pragma unroll
       for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
@@ -1012,12 +1020,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
     if (ch + 1 < ch_end) load_chunk(ch + 1);
     __syncthreads();
     // wave-uniform skips of dead tiles (third c tile of Cin = 264 / 265; Cout = 8 / 5 / 1 heads)
-    if (c_act && o_left > 32)
-      wgrad_mma_v2<4, KX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    if (TOMAX == 4 && c_act && o_left > 32)
+      wgrad_mma_v2<TOMAX, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
     else if (c_act && o_left > 16)
-      wgrad_mma_v2<2, KX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+      wgrad_mma_v2<2, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
     else if (c_act && o_left > 0)
-      wgrad_mma_v2<1, KX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+      wgrad_mma_v2<1, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
     __syncthreads();
   }
 
@@ -1026,7 +1034,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
 #pragma unroll
   for (int kx = 0; kx < KX; ++kx)
 #pragma unroll
-    for (int to = 0; to < 4; ++to)
+    for (int to = 0; to < TOMAX; ++to)
 #pragma unroll
       for (int tc = 0; tc < 2; ++tc) {
         const int c = c0 + b_col + 16 * tc + lr;
@@ -1038,13 +1046,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
       }
 
   if (do_bias) {
-    float* red = reinterpret_cast<float*>(smem_raw);  // [16][128]
+    float* red = reinterpret_cast<float*>(smem_raw);  // [RG][128]
     *reinterpret_cast<float4*>(red + rr * 128 + 4 * q4) = bsum;
     __syncthreads();
     if (tid < 128) {
       float sum = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) sum += red[g * 128 + tid];
+      for (int g = 0; g < RG; ++g) sum += red[g * 128 + tid];
       if (o0 + tid < Nout) bias_slab[(long long)split * Nout + o0 + tid] = sum;
     }
   }
@@ -1055,6 +1063,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_bf16x3_v2_kernel(
 // 128-wide tiles (256 -> 256 towers 758 -> 683 us, conv3_x 1785 -> 1706, conv4_x 1716 -> 1667), -1...3 % on the
 // 264 / 268-channel inputs (dis P3, head_out: a third, almost empty channel tile) -- so those stay on the first kernel.
 int g_scan_wgrad_v2 = 2;
+// scan_tune "wgrad_wg1024": the 16x16x32 weight-gradient kernel with 16 waves per workgroup (1) or 8 (0)
+int g_scan_wgrad_wg1024 = 0;
 static inline bool wgrad_use_v2(int Cs) { return g_scan_wgrad_v2 == 1 || (g_scan_wgrad_v2 == 2 && Cs % 128 == 0); }
 // 2 = the 16x16x32 weight-gradient kernel, 1 = the 32x32x16 one, for an input channel stride Cs (bench.py labels)
 extern "C" int scan_conv_wgrad_bf16x3_generation(int32_t Cs) { return wgrad_use_v2(Cs) ? 2 : 1; }
@@ -1164,12 +1174,18 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
   if (wgrad_use_v2(Cs)) {
     static bool done2 = false;
     if (!done2) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1>),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1, 512>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1, 1024>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
       done2 = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<3, 1>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout, Cout_s,
-                       ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+    if (g_scan_wgrad_wg1024)
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<3, 1, 1024>), dim3(nt * sp), dim3(1024), sh, st, x, *d, Cs, dy, Cout,
+                         Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+    else
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<3, 1, 512>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout,
+                         Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
   } else {
     hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<3, 1>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout,
                        Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
@@ -1221,17 +1237,17 @@ extern "C" int scan_conv1x1_wgrad_bf16x3(const float* x, const scan_pyramid_t* x
   if (wgrad_use_v2(Cs)) {
     static bool done2 = false;
     if (!done2) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<1, 1>),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<1, 1, 512>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<1, 2>),
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<1, 2, 512>),
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
       done2 = true;
     }
     if (stride == 1)
-      hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<1, 1>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<1, 1, 512>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
                          Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *xd);
     else
-      hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<1, 2>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<1, 2, 512>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
                          Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *xd);
   } else if (stride == 1)
     hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<1, 1>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,

@@ -1063,7 +1063,9 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v2_k
 // 128-wide tiles (256 -> 256 towers 758 -> 683 us, conv3_x 1785 -> 1706, conv4_x 1716 -> 1667), -1...3 % on the
 // 264 / 268-channel inputs (dis P3, head_out: a third, almost empty channel tile) -- so those stay on the first kernel.
 int g_scan_wgrad_v2 = 2;
-// scan_tune "wgrad_wg1024": the 16x16x32 weight-gradient kernel with 16 waves per workgroup (1) or 8 (0)
+// scan_tune "wgrad_wg1024": the 16x16x32 weight-gradient kernel with 16 waves per workgroup (1) instead of 8 (0,
+// default).  Measured 33 % SLOWER on every layer (profiles/r02_wgrad_ab.txt: conv3_x 1784 -> 2654 us): at 128 registers
+// the transposed-read addresses spill inside the MFMA loop and each wave re-reads twice the LDS bytes per MFMA.
 int g_scan_wgrad_wg1024 = 0;
 static inline bool wgrad_use_v2(int Cs) { return g_scan_wgrad_v2 == 1 || (g_scan_wgrad_v2 == 2 && Cs % 128 == 0); }
 // 2 = the 16x16x32 weight-gradient kernel, 1 = the 32x32x16 one, for an input channel stride Cs (bench.py labels)

@@ -24,6 +24,7 @@ extern int g_scan_wgrad_v2;
 extern int g_scan_conv_wg1024;
 extern int g_scan_conv_tpb3;
 extern int g_scan_wgrad_wg1024;
+extern int g_scan_wgrad_v3;
 
 extern "C" int scan_tune(const char* key, int value) {
   if (key == nullptr) return -1;
@@ -34,6 +35,7 @@ extern "C" int scan_tune(const char* key, int value) {
   if (strcmp(key, "conv_wg1024") == 0) slot = &g_scan_conv_wg1024;
   if (strcmp(key, "conv_tpb3") == 0) slot = &g_scan_conv_tpb3;
   if (strcmp(key, "wgrad_wg1024") == 0) slot = &g_scan_wgrad_wg1024;
+  if (strcmp(key, "wgrad_v3") == 0) slot = &g_scan_wgrad_v3;
   if (slot == nullptr) return -1;
   const int old = *slot;
   *slot = value;

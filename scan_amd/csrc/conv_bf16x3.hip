@@ -7,16 +7,21 @@
 // reference is 2e-6 relative.  bf16 MFMA runs 16x the fp32-MFMA rate on CDNA4, so three
 // passes are ~5x faster than v_mfma_f32_32x32x2_f32.
 //
-// Structure (per 256-thread workgroup, 2 workgroups per CU):
-//   output tile   8 x 16 pixels (one image, one pyramid level) x BN = 128 output channels
-//   K loop        input channels in chunks of 32; per chunk the (8+2) x (16+2) x 32 input HALO patch is
-//                 read from HBM/L2 ONCE as fp32, split to bf16 hi/lo while being written to LDS, and then
-//                 reused by all 9 taps (the taps are pure LDS address offsets)
-//   weights       pre-split once per step into bf16 hi/lo [O][9][Csw] (scan_weight_split), staged per
-//                 (chunk, tap) through a double-buffered LDS tile
-//   waves         2 x 2, each 64 pixels x 64 channels = 2 x 2 MFMA tiles of 32x32
-// LDS rows are 80 B (64 B of data + 16 B pad) so the 16-byte fragment reads of consecutive pixels /
-// channels fall on distinct bank groups.
+// This file holds the FIRST generation of the forward / data-gradient kernel (v_mfma_f32_32x32x16_bf16; since round 2
+// the launches go to conv_bf16x3_v2.hip unless scan_tune("conv_v2", 0) -- it stays as the A/B reference and as the
+// arithmetic the second kernel is tested against), the weight split, and the weight-gradient kernels.
+//
+// Structure of the first-generation forward kernel (per 512-thread workgroup, one workgroup per CU: 95 KB of LDS):
+//   output tile   16 x 16 pixels (one image, one pyramid level) x BN = 128 or 256 output channels
+//                 (8 x 16 pixels x 64 channels with 256 threads for Cout <= 64)
+//   K loop        input channels in chunks of 32; per chunk the 18 x 18 x 32 input HALO patch is read from HBM/L2 ONCE
+//                 as fp32, split to bf16 hi/lo while being written to LDS, and then reused by all 9 taps (the taps are
+//                 pure LDS address offsets)
+//   weights       pre-split once per step into bf16 hi/lo [O][9][Csw] (scan_weight_split), staged per (chunk, tap)
+//                 through a double-buffered LDS tile
+//   waves         4 x 2, each 64 pixels x 64 (BN = 256: 128) channels = 2 x 2 (2 x 4) MFMA tiles of 32x32
+// LDS pixel rows are 80 B (64 B of data + 16 B pad) and patch rows 1536 B so the 16-byte fragment reads of consecutive
+// pixels / channels fall on distinct bank groups.
 //
 // dgrad reuses the same kernel: dX = conv3x3(dY, W') with W'[c][t][o] = W[o][8-t][c]
 // (scan_weight_split mode 1 writes the flipped + transposed copy).
@@ -81,7 +86,7 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4& hi, bf16x4& lo) {
 // a stride-2 conv, source pyramid sd is the finer one), 2 source = output / 2 where both coordinates are even, zero
 // elsewhere (its data gradient: sd is the coarser dY pyramid).
 template <int BN, int TH, int NT, int KS = 3>
-__global__ __launch_bounds__(NT, 2) void conv3x3_bf16x3_kernel(
+__global__ __launch_bounds__(NT, NT == 512 ? 2 : 3) void conv3x3_bf16x3_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
     const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
     float* __restrict__ dst, int Nout, int Ns, int relu, TileTab tt, int n_tiles, scan_pyramid_t sd, int map,
@@ -1058,6 +1063,253 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v2_k
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Third generation of the weight-gradient kernel: the 16x16x32 kernel above with the staging phase taken off the
+// critical path.  The stage image drops its row padding (256-byte rows, 16-byte chunk ch of row r stored at
+// ch ^ (((r & 3) << 2) | ((r >> 2) & 3)): conflict-free for the transposed reads of two lane groups 8 rows apart and for
+// the 8-byte staging writes), which shrinks a stage from 83 KB to 66.5 KB -- TWO stages fit.  Each iteration computes on
+// stage i & 1 while the next chunk is split and written into the other stage; ONE barrier per chunk instead of two.
+// The two waves of a SIMD (w and w + 4) run the two halves in opposite order -- waves 0..3 stage first and then issue
+// their MFMAs, waves 4..7 issue their MFMAs first -- so the matrix pipe of a SIMD is fed by one partner while the other
+// converts (MI355X_MICROARCH.md: "two waves that run the same program with one barrier per block: try a stagger").
+// ------------------------------------------------------------------------------------------------
+#define W3ROW 128  // bf16 elements per LDS row: no padding
+#define W3STAGE(KX) ((2 * WK + 2 * (WK + (KX) - 1)) * W3ROW)  // bf16 elements per stage
+__device__ __forceinline__ int wsw3(int row, int col) {
+  const int f = ((row & 3) << 2) | ((row >> 2) & 3);
+  return row * W3ROW + ((((col >> 3) ^ f) << 3) | (col & 7));
+}
+
+// TO: live 16-row o tiles of this wave (4, 2 or 1)
+template <int TO, int KX, int TOMAX>
+__device__ __forceinline__ void wgrad_mma_v3(const __bf16* Ah, const __bf16* Al, const __bf16* Bh, const __bf16* Bl,
+                                             int row_lane, int col4, int a_col, int b_col,
+                                             f32x4v (&acc)[KX][TOMAX][2]) {
+#pragma unroll
+  for (int s = 0; s < WK / 32; ++s) {
+    // dY rows of this lane: r0 = 32 s + 8 kg + q and r0 + 4 (bit 3 of both = kg & 1: one swizzle per lane)
+    const int ra0 = 32 * s + row_lane, ra1 = ra0 + 4;
+    bf16x8 ah[TO], al[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+      const int c = a_col + 16 * t + col4;
+      const int o0 = wsw3(ra0, c), o1 = wsw3(ra1, c);
+      ah[t] = tr_read8_v2(Ah + o0, Ah + o1);
+      al[t] = tr_read8_v2(Al + o0, Al + o1);
+    }
+#pragma unroll
+    for (int kx = 0; kx < KX; ++kx) {
+      const int rb0 = ra0 + kx, rb1 = ra1 + kx;  // X row j <-> pixel x0 - HALO + j: tap kx is a row shift
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        const int c = b_col + 16 * tc + col4;
+        const int o0 = wsw3(rb0, c), o1 = wsw3(rb1, c);
+        const bf16x8 bh = tr_read8_v2(Bh + o0, Bh + o1);
+        const bf16x8 bl = tr_read8_v2(Bl + o0, Bl + o1);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[to], bh, acc[kx][to][tc], 0, 0, 0);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[to], bl, acc[kx][to][tc], 0, 0, 0);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[to], bh, acc[kx][to][tc], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// NT = 512: 8 waves = 2 (o) x 4 (c), each 64 o x 32 c; NT = 1024: 16 waves = 4 x 4, each 32 o x 32 c (48 accumulator
+// registers, <= 128 registers per lane: four waves per SIMD to hide the staging phases and the transposed-read latency)
+template <int KX, int S, int NT>
+__global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v3_kernel(
+    const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
+    float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
+    int chunks_per_split, int splits, scan_pyramid_t xd) {
+  constexpr int HALO = KX / 2, T = KX * KX;
+  constexpr int RG = NT / 32;                         // pixel-row groups of the staging roles (16 or 32)
+  constexpr int NA = WK / RG;                         // dY float4 per thread per chunk
+  constexpr int NB = (WK + KX - 1 + RG - 1) / RG;     // X float4 per thread per chunk
+  constexpr int WO = NT / 256;                        // waves along o (2 or 4)
+  constexpr int TOMAX = 128 / (16 * WO);              // 16-row o tiles per wave (4 or 2)
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  const int qq = L >> 3;
+  int tile = qq % n_tiles;
+  const int split = (qq / n_tiles) * 8 + xcd;
+  const int c_tile = tile % c_tiles;
+  tile /= c_tiles;
+  const int ky = tile % KX;
+  const int o_tile = tile / KX;
+  const int o0 = o_tile * 128, c0 = c_tile * 128;
+  const long long total_chunks = ct.chunk_off[d.n_levels];
+  const long long ch_begin = (long long)split * chunks_per_split;
+  long long ch_end = ch_begin + chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  const bool do_bias = (bias_slab != nullptr) && ky == HALO && c_tile == 0;
+
+  const int q4 = tid & 31, rr = tid >> 5;
+  float4 ra[NA], rb[NB];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto load_chunk = [&](long long ch) {
+    int lvl = 0;
+#pragma unroll
+    for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+      if (i < d.n_levels && ch >= ct.chunk_off[i]) lvl = i;
+    const int H = d.h[lvl], W = d.w[lvl];
+    const long long r = ch - ct.chunk_off[lvl];
+    const int seg = (int)(r % ct.segs[lvl]);
+    const long long row = r / ct.segs[lvl];  // n * H + y
+    const int y = (int)(row % H);
+    const int x0 = seg * WK;
+    const long long rowbase = d.row_off[lvl] + row * W;
+    const int o = o0 + 4 * q4, c = c0 + 4 * q4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int k = rr + RG * i;
+      ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (x0 + k < W) {
+        const long long m = rowbase + x0 + k;
+        if ((Ns & 3) == 0 && o + 3 < Ns) {
+          ra[i] = *reinterpret_cast<const float4*>(dy + m * Ns + o);
+        } else {
+          float t[4] = {0.f, 0.f, 0.f, 0.f};
+          for (int e = 0; e < 4; ++e)
+            if (o + e < Ns) t[e] = dy[m * Ns + o + e];
+          ra[i] = make_float4(t[0], t[1], t[2], t[3]);
+        }
+      }
+    }
+    const int yy = y + ky - HALO;
+    const bool yok = yy >= 0 && yy < H && c < Cs;
+    const int Wx = (KX == 1) ? xd.w[lvl] : W;
+    const long long xrow = (KX == 1) ? xd.row_off[lvl] + ((row / H) * xd.h[lvl] + (long long)S * y) * Wx
+                                     : rowbase + (long long)(ky - 1) * W;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
+      const int xx = x0 - HALO + j;
+      rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j < WK + KX - 1 && yok && xx >= 0 && xx < W)
+        rb[i] = *reinterpret_cast<const float4*>(x + (xrow + (long long)S * xx) * Cs + c);
+    }
+  };
+  auto store_chunk = [&](int stage) {
+    __bf16* Ah = sm + stage * W3STAGE(KX);
+    __bf16* Al = Ah + WK * W3ROW;
+    __bf16* Bh = Al + WK * W3ROW;
+    __bf16* Bl = Bh + (WK + KX - 1) * W3ROW;
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int off = wsw3(rr + RG * i, 4 * q4);
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(Ah + off) = hi;
+      *reinterpret_cast<bf16x4*>(Al + off) = lo;
+      if (do_bias) {
+        bsum.x += ra[i].x;
+        bsum.y += ra[i].y;
+        bsum.z += ra[i].z;
+        bsum.w += ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
+      if (j < WK + KX - 1) {
+        const int off = wsw3(j, 4 * q4);
+        split4(rb[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(Bh + off) = hi;
+        *reinterpret_cast<bf16x4*>(Bl + off) = lo;
+      }
+    }
+  };
+
+  // waves: WO (o) x 4 (c); each wave (128 / WO) o x 32 c = TOMAX x 2 MFMA tiles of 16 x 16, for each of the KX taps
+  const int wm = wid % WO, wn = wid / WO;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int row_lane = 8 * kg + (lr >> 2), col4 = 4 * (lane & 3);
+  const int a_col = wm * (16 * TOMAX), b_col = wn * 32;
+  const bool c_act = c0 + b_col < Cs;
+  const int o_left = Nout - (o0 + a_col);  // live o rows of this wave
+
+  f32x4v acc[KX][TOMAX][2];
+#pragma unroll
+  for (int a = 0; a < KX; ++a)
+#pragma unroll
+    for (int b = 0; b < TOMAX; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  auto mma = [&](int stage) {
+    const __bf16* Ah = sm + stage * W3STAGE(KX);
+    const __bf16* Al = Ah + WK * W3ROW;
+    const __bf16* Bh = Al + WK * W3ROW;
+    const __bf16* Bl = Bh + (WK + KX - 1) * W3ROW;
+    // wave-uniform skips of dead tiles (third c tile of Cin = 264 / 265; Cout = 8 / 5 / 1 heads)
+    if (TOMAX == 4 && c_act && o_left > 32)
+      wgrad_mma_v3<TOMAX, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    else if (c_act && o_left > 16)
+      wgrad_mma_v3<2, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    else if (c_act && o_left > 0)
+      wgrad_mma_v3<1, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+  };
+  auto stage_next = [&](long long ch, int stage) {  // convert chunk ch + 1 (in registers) into `stage`, fetch chunk ch + 2
+    if (ch + 1 < ch_end) {
+      store_chunk(stage);
+      if (ch + 2 < ch_end) load_chunk(ch + 2);
+    }
+  };
+  const bool late = wid >= 4;  // the SIMD partner of wave w is wave w + 4
+  if (ch_begin < ch_end) {
+    load_chunk(ch_begin);
+    store_chunk(0);
+    if (ch_begin + 1 < ch_end) load_chunk(ch_begin + 1);
+  }
+  __syncthreads();
+  for (long long ch = ch_begin; ch < ch_end; ++ch) {
+    const int cur = (int)(ch - ch_begin) & 1;
+    if (!late) {
+      stage_next(ch, cur ^ 1);
+      mma(cur);
+    } else {
+      mma(cur);
+      stage_next(ch, cur ^ 1);
+    }
+    __syncthreads();  // stage cur is free for chunk ch + 2, stage cur ^ 1 is complete
+  }
+
+  // C/D map of 16x16: column = lane & 15 = input channel c, row = 4 * (lane >> 4) + reg = output channel o
+  float* out = slab + (long long)split * Nout * T * Cs;
+#pragma unroll
+  for (int kx = 0; kx < KX; ++kx)
+#pragma unroll
+    for (int to = 0; to < TOMAX; ++to)
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        const int c = c0 + b_col + 16 * tc + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + a_col + 16 * to + 4 * kg + r;
+          if (o < Nout && c < Cs) out[((long long)o * T + ky * KX + kx) * Cs + c] = acc[kx][to][tc][r];
+        }
+      }
+
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(smem_raw);  // [RG][128]
+    *reinterpret_cast<float4*>(red + rr * 128 + 4 * q4) = bsum;
+    __syncthreads();
+    if (tid < 128) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) sum += red[g * 128 + tid];
+      if (o0 + tid < Nout) bias_slab[(long long)split * Nout + o0 + tid] = sum;
+    }
+  }
+}
+
 // scan_tune "wgrad_v2": 1 = always the 16x16x32 weight-gradient kernel, 0 = always the 32x32x16 one, 2 (default) = by
 // shape.  Same-process A/B per layer (profiles/r02_wgrad_ab.txt): +3...11 % where the input channels fill whole
 // 128-wide tiles (256 -> 256 towers 758 -> 683 us, conv3_x 1785 -> 1706, conv4_x 1716 -> 1667), -1...3 % on the
@@ -1067,6 +1319,8 @@ int g_scan_wgrad_v2 = 2;
 // default).  Measured 33 % SLOWER on every layer (profiles/r02_wgrad_ab.txt: conv3_x 1784 -> 2654 us): at 128 registers
 // the transposed-read addresses spill inside the MFMA loop and each wave re-reads twice the LDS bytes per MFMA.
 int g_scan_wgrad_wg1024 = 0;
+// scan_tune "wgrad_v3": 1 = the double-buffered, staggered 16x16x32 weight-gradient kernel for the 3x3 convs
+int g_scan_wgrad_v3 = 0;
 static inline bool wgrad_use_v2(int Cs) { return g_scan_wgrad_v2 == 1 || (g_scan_wgrad_v2 == 2 && Cs % 128 == 0); }
 // 2 = the 16x16x32 weight-gradient kernel, 1 = the 32x32x16 one, for an input channel stride Cs (bench.py labels)
 extern "C" int scan_conv_wgrad_bf16x3_generation(int32_t Cs) { return wgrad_use_v2(Cs) ? 2 : 1; }
@@ -1173,7 +1427,17 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
     done = true;
   }
   float* bias_slab = db ? ws + (int64_t)sp * Cout * 9 * Cs : nullptr;
-  if (wgrad_use_v2(Cs)) {
+  if (g_scan_wgrad_v3 == 1 || (g_scan_wgrad_v3 == 2 && Cs % 128 == 0)) {
+    const size_t sh3 = (size_t)2 * W3STAGE(3) * sizeof(__bf16);
+    static bool done3 = false;
+    if (!done3) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v3_kernel<3, 1, 512>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh3);
+      done3 = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_bf16x3_v3_kernel<3, 1, 512>), dim3(nt * sp), dim3(512), sh3, st, x, *d, Cs, dy, Cout,
+                       Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+  } else if (wgrad_use_v2(Cs)) {
     static bool done2 = false;
     if (!done2) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1, 512>),

@@ -49,6 +49,9 @@ int scan_abi_version(void);
  *                 32-channel chunk).
  *   "wgrad_v2"    the same choice for the bf16x3 weight-gradient kernels: 1 / 0, or 2 (default) = by shape (the
  *                 16x16x32 kernel where the input channels fill whole 128-wide tiles).
+ *   "wgrad_v3"    1: the double-buffered, staggered 16x16x32 weight-gradient kernel (default 0: measured slower).
+ *   "wgrad_wg1024" 2 (default): 16-wave workgroups for the weight-gradient launches that stay on the 32x32x16 kernel;
+ *                 1: for the 16x16x32 kernel (measured slower); 0: 8 waves.
  *   "conv_wg1024" 1 (default): the 128- / 256-channel forward / dgrad instances run 16 waves per workgroup; 0: 8 waves;
  *                 2: 16 waves only for the 256-channel tile on multi-level pyramids.  Same results bit for bit.
  *   "conv_tpb3"   bit 0 / bit 1: the 128- / 64-channel instance stages three taps per barrier (default 0; same

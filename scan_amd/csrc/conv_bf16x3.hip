@@ -617,9 +617,9 @@ __device__ __forceinline__ bf16x8 tr_read8(const __bf16* p0) {
 
 // MFMA work of one staged chunk for one wave: TMN = number of live 32-row o tiles (2, or 1 when the second lies
 // beyond Nout)
-template <int TMN, int KX>
+template <int TMN, int KX, int TMAX = 2>
 __device__ __forceinline__ void wgrad_mma(const __bf16* Ah, const __bf16* Al, const __bf16* Bh, const __bf16* Bl,
-                                          int tr_off, int a_col, int b_col, f32x16 (&acc)[KX][2]) {
+                                          int tr_off, int a_col, int b_col, f32x16 (&acc)[KX][TMAX]) {
 #pragma unroll
   for (int s = 0; s < WK / 16; ++s) {
     bf16x8 ah[TMN], al[TMN];
@@ -647,12 +647,19 @@ __device__ __forceinline__ void wgrad_mma(const __bf16* Ah, const __bf16* Al, co
 // KX = 3: the 3x3 / stride-1 conv (three kx taps of one ky per workgroup).  KX = 1: 1x1 convs (one tap, no halo), whose
 // X operand may be gathered with stride S from the finer pyramid xd (ResNet's stride-2 1x1 convs); d is always the
 // pyramid of dY, over which the K chunks run.
-template <int KX, int S>
-__global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
+// NT = 512: 8 waves = 2 (o) x 4 (c), each 64 o x 32 c; NT = 1024: 16 waves = 4 x 4, each 32 o x 32 c (48 accumulator
+// registers per lane, four waves per SIMD)
+template <int KX, int S, int NT = 512>
+__global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv3x3_wgrad_bf16x3_kernel(
     const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
     float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
     int chunks_per_split, int splits, scan_pyramid_t xd) {
   constexpr int HALO = KX / 2, T = KX * KX;
+  constexpr int RG = NT / 32;                       // pixel-row groups of the staging roles
+  constexpr int NA = WK / RG;                       // dY float4 per thread per chunk
+  constexpr int NB = (WK + KX - 1 + RG - 1) / RG;   // X float4 per thread per chunk
+  constexpr int WO = NT / 256;                      // waves along o
+  constexpr int TMAX = 128 / (32 * WO);             // 32-row o tiles per wave (2 or 1)
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
 
@@ -674,9 +681,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
   if (ch_end > total_chunks) ch_end = total_chunks;
   const bool do_bias = (bias_slab != nullptr) && ky == HALO && c_tile == 0;
 
-  // staging roles: float4 column q4, pixel rows rr + 16 i
+  // staging roles: float4 column q4, pixel rows rr + RG i
   const int q4 = tid & 31, rr = tid >> 5;
-  float4 ra[WNA], rb[WNB(KX)];
+  float4 ra[NA], rb[NB];
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_chunk = [&](long long ch) {
     int lvl = 0;
@@ -692,8 +699,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     const long long rowbase = d.row_off[lvl] + row * W;
     const int o = o0 + 4 * q4, c = c0 + 4 * q4;
 #pragma unroll
-    for (int i = 0; i < WNA; ++i) {
-      const int k = rr + 16 * i;
+    for (int i = 0; i < NA; ++i) {
+      const int k = rr + RG * i;
       ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (x0 + k < W) {
         const long long m = rowbase + x0 + k;
@@ -714,8 +721,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     const long long xrow = (KX == 1) ? xd.row_off[lvl] + ((row / H) * xd.h[lvl] + (long long)S * y) * Wx
                                      : rowbase + (long long)(ky - 1) * W;
 #pragma unroll
-    for (int i = 0; i < WNB(KX); ++i) {
-      const int j = rr + 16 * i;
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
       const int xx = x0 - HALO + j;
       rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (j < WK + KX - 1 && yok && xx >= 0 && xx < W)
@@ -729,8 +736,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     __bf16* Bl = Bh + (WK + KX - 1) * WROW;
     bf16x4 hi, lo;
 #pragma unroll
-    for (int i = 0; i < WNA; ++i) {
-      const int off = (rr + 16 * i) * WROW + 4 * q4;
+    for (int i = 0; i < NA; ++i) {
+      const int off = (rr + RG * i) * WROW + 4 * q4;
       split4(ra[i], hi, lo);
       *reinterpret_cast<bf16x4*>(Ah + off) = hi;
       *reinterpret_cast<bf16x4*>(Al + off) = lo;
@@ -742,8 +749,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
       }
     }
 #pragma unroll
-    for (int i = 0; i < WNB(KX); ++i) {
-      const int j = rr + 16 * i;
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
       if (j < WK + KX - 1) {
         const int off = j * WROW + 4 * q4;
         split4(rb[i], hi, lo);
@@ -755,19 +762,19 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
 
   // 8 waves: 2 (o) x 4 (c); each wave 64 o x 32 c = 2 x 1 MFMA tiles, for each of the 3 kx taps.  Waves that share
   // a c column group sit on different SIMDs (wid % 4), so a tile with one live column group keeps two SIMDs busy
-  const int wm = wid & 1, wn = wid >> 1;
+  const int wm = wid % WO, wn = wid / WO;
   const int lr = lane & 31, lh = lane >> 5;
   // transposed-read lane address: pixel row 8h + (l&15)>>2, channel column 16*((l>>4)&1) + 4*(l&3)
   const int tr_off = (8 * lh + ((lane & 15) >> 2)) * WROW + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
-  const int a_col = wm * 64, b_col = wn * 32;
+  const int a_col = wm * (32 * TMAX), b_col = wn * 32;
   const bool c_act = c0 + b_col < Cs;
   const bool o_act0 = o0 + a_col < Nout, o_act1 = o0 + a_col + 32 < Nout;
 
-  f32x16 acc[KX][2];
+  f32x16 acc[KX][TMAX];
 #pragma unroll
   for (int a = 0; a < KX; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < TMAX; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
@@ -784,9 +791,9 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     if (ch == ch_begin) store_chunk();
     else {
 #pragma unroll
-      for (int i = 0; i < WNA; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
+      for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
 #pragma unroll
-      for (int i = 0; i < WNB(KX); ++i) asm volatile("" ::"v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+      for (int i = 0; i < NB; ++i) asm volatile("" ::"v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
     }
 #else
     store_chunk();
@@ -795,10 +802,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
     __syncthreads();
     // wave-uniform skips: a wave whose 32 c columns lie beyond Cs (third c tile of Cin = 264 / 265) or whose o rows
     // lie beyond Nout (Cout = 8 / 5 / 1 heads) has nothing to contribute; it still stages and synchronises
-    if (c_act && o_act1)
-      wgrad_mma<2, KX>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
+    if (TMAX == 2 && c_act && o_act1)
+      wgrad_mma<TMAX, KX, TMAX>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
     else if (c_act && o_act0)
-      wgrad_mma<1, KX>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
+      wgrad_mma<1, KX, TMAX>(Ah, Al, Bh, Bl, tr_off, a_col, b_col, acc);
     __syncthreads();  // every wave is done with this chunk's LDS image
   }
 
@@ -807,7 +814,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
 #pragma unroll
   for (int kx = 0; kx < KX; ++kx)
 #pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
+    for (int tm = 0; tm < TMAX; ++tm)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int o = o0 + a_col + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -815,13 +822,13 @@ __global__ __launch_bounds__(512, 2) void conv3x3_wgrad_bf16x3_kernel(
       }
 
   if (do_bias) {  // column sums of this split's dY rows: reduce the 16 pixel-row groups through LDS
-    float* red = reinterpret_cast<float*>(smem_raw);  // [16][128]
+    float* red = reinterpret_cast<float*>(smem_raw);  // [RG][128]
     *reinterpret_cast<float4*>(red + rr * 128 + 4 * q4) = bsum;
     __syncthreads();
     if (tid < 128) {
       float sum = 0.f;
 #pragma unroll
-      for (int g = 0; g < 16; ++g) sum += red[g * 128 + tid];
+      for (int g = 0; g < RG; ++g) sum += red[g * 128 + tid];
       if (o0 + tid < Nout) bias_slab[(long long)split * Nout + o0 + tid] = sum;
     }
   }
@@ -1315,10 +1322,12 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v3_k
 // 128-wide tiles (256 -> 256 towers 758 -> 683 us, conv3_x 1785 -> 1706, conv4_x 1716 -> 1667), -1...3 % on the
 // 264 / 268-channel inputs (dis P3, head_out: a third, almost empty channel tile) -- so those stay on the first kernel.
 int g_scan_wgrad_v2 = 2;
-// scan_tune "wgrad_wg1024": the 16x16x32 weight-gradient kernel with 16 waves per workgroup (1) instead of 8 (0,
-// default).  Measured 33 % SLOWER on every layer (profiles/r02_wgrad_ab.txt: conv3_x 1784 -> 2654 us): at 128 registers
-// the transposed-read addresses spill inside the MFMA loop and each wave re-reads twice the LDS bytes per MFMA.
-int g_scan_wgrad_wg1024 = 0;
+// scan_tune "wgrad_wg1024": 16 waves per workgroup instead of 8 -- 2 (default) = for the launches that stay on the
+// 32x32x16 kernel (input channels not a multiple of 128: dis P3 264 -> 1024 2503 -> 2420 us, head_out 268 -> 256
+// 912 -> 864; the padded image needs no per-read address arithmetic, 128 registers, no spills); 1 = for the 16x16x32
+// kernel, measured 33 % SLOWER on every layer (conv3_x 1784 -> 2654 us: at 128 registers its swizzled transposed-read
+// addresses spill inside the MFMA loop); 0 = 8 waves everywhere.  profiles/r02_wgrad_ab.txt.
+int g_scan_wgrad_wg1024 = 2;
 // scan_tune "wgrad_v3": 1 = the double-buffered, staggered 16x16x32 weight-gradient kernel for the 3x3 convs
 int g_scan_wgrad_v3 = 0;
 static inline bool wgrad_use_v2(int Cs) { return g_scan_wgrad_v2 == 1 || (g_scan_wgrad_v2 == 2 && Cs % 128 == 0); }
@@ -1446,12 +1455,21 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
       done2 = true;
     }
-    if (g_scan_wgrad_wg1024)
+    if (g_scan_wgrad_wg1024 == 1)
       hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<3, 1, 1024>), dim3(nt * sp), dim3(1024), sh, st, x, *d, Cs, dy, Cout,
                          Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
     else
       hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<3, 1, 512>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout,
                          Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+  } else if (g_scan_wgrad_wg1024 == 2) {
+    static bool done4 = false;
+    if (!done4) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_bf16x3_kernel<3, 1, 1024>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      done4 = true;
+    }
+    hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<3, 1, 1024>), dim3(nt * sp), dim3(1024), sh, st, x, *d, Cs, dy, Cout,
+                       Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
   } else {
     hipLaunchKernelGGL((conv3x3_wgrad_bf16x3_kernel<3, 1>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout,
                        Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);

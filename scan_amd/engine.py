@@ -24,6 +24,12 @@ from .modeling import fcos as fcos_mod
 from .modeling.fcos import build_fcos
 from .modeling.resnet import build_resnet_fpn_backbone
 
+# Parameters used on the side HIP streams (P4..P7 discriminators, FCOS head) get their torch-tier gradients from
+# AccumulateGrad nodes that run on those streams; Trainer._join_streams orders them before anything consumes the
+# gradient buffers, so autograd's "stream does not match" advice does not apply here.
+if hasattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch"):
+    torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+
 LEVELS = ("P3", "P4", "P5", "P6", "P7")
 DIS_ORDER = ("P7", "P6", "P5", "P4", "P3")  # order the reference builds / iterates them
 

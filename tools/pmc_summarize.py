@@ -17,6 +17,7 @@ import sys
 GROUPS = [  # (substring of the kernel name, group key); conv keys = the symbols bench.py's roofline names
     ("conv_bf16x3_v2_kernelILi256ELi16ELi1024ELi3", "conv_bf16x3_v2_kernel<256,16,1024,3>"),
     ("conv_bf16x3_v2_kernelILi256ELi16ELi512ELi3", "conv_bf16x3_v2_kernel<256,16,512,3>"),
+    ("conv_bf16x3_v2_kernelILi128ELi16ELi1024ELi3", "conv_bf16x3_v2_kernel<128,16,1024,3>"),
     ("conv_bf16x3_v2_kernelILi128ELi16ELi512ELi3", "conv_bf16x3_v2_kernel<128,16,512,3>"),
     ("conv_bf16x3_v2_kernelILi64ELi8ELi256ELi3", "conv_bf16x3_v2_kernel<64,8,256,3>"),
     ("conv_bf16x3_v2_kernelILi128ELi16ELi512ELi1", "conv_bf16x3_v2_kernel<128,16,512,1>"),

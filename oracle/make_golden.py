@@ -574,6 +574,125 @@ def gen_pipeline():
     print("pipeline.npz written, %d bytes" % os.path.getsize(os.path.join(GOLD, "pipeline.npz")))
 
 
+VOC_XML = """<annotation><filename>{name}</filename><size><width>{w}</width><height>{h}</height><depth>3</depth></size>
+{objs}</annotation>"""
+VOC_OBJ = ("<object><name>{name}</name><difficult>{diff}</difficult><bndbox><xmin>{x1}</xmin><ymin>{y1}</ymin>"
+           "<xmax>{x2}</xmax><ymax>{y2}</ymax></bndbox></object>")
+
+
+def _voc_cases():
+    """(id, (w, h), [(name, difficult, x1, y1, x2, y2)]): 1-based boxes incl. ones that touch / cross the frame, a
+    degenerate one (empty after clipping), a difficult one, a non-car and mixed-case names.  (An image without any car makes the reference raise --
+    BoxList rejects the 1-D empty tensor, sim10k.py:63 -- so none is in the fixture.)"""
+    return [
+        ("000001", (48, 32), [("car", 0, 1, 1, 48, 32), ("Car ", 0, 10, 5, 30, 20), ("person", 0, 3, 3, 20, 20),
+                              ("car", 1, 5, 6, 25, 26)]),
+        ("000002", (40, 24), [("car", 0, 35, 10, 60, 30), ("car", 0, 7, 7, 7, 20), ("car", 0, 41, 2, 45, 9),
+                              ("CAR", 0, 2, 3, 4, 5)]),
+        ("000003", (33, 31), [("truck", 0, 2, 2, 9, 9), ("car", 0, 4, 4, 33, 31)]),
+    ]
+
+
+def gen_datasets():
+    """Datasets either side of the path, from the reference's own classes on a synthetic tree:
+    Sim10kDataset / KittiDataset (data/datasets/sim10k.py, kitti.py: importable, stdlib + PIL only), the BoxList
+    operations COCODataset.__getitem__ applies to json boxes (coco.py:69-86: xywh -> xyxy, clip_to_image) and
+    prepare_for_coco_detection (evaluation/coco/coco_eval.py:69-98).  COCODataset itself subclasses torchvision's
+    CocoDetection over pycocotools (both absent): its json handling is pinned through these pieces only."""
+    import importlib.util
+    import io
+    import tempfile
+    rh.setup()
+    from PIL import Image
+    from fcos_core.structures.bounding_box import BoxList
+    out, meta = {}, {"voc": []}
+
+    def load(path, name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(rh.REF, "fcos_core", *path))
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+
+    sim, kit = load(("data", "datasets", "sim10k.py"), "ref_sim10k"), load(("data", "datasets", "kitti.py"), "ref_kitti")
+    for cls_name, mod, ext, use_difficult in (("Sim10kDataset", sim, "jpg", False), ("Sim10kDataset", sim, "jpg", True),
+                                              ("KittiDataset", kit, "png", False)):
+        with tempfile.TemporaryDirectory() as root:
+            for d in ("Annotations", "JPEGImages", os.path.join("ImageSets", "Main")):
+                os.makedirs(os.path.join(root, d))
+            files = {}
+            for k, (iid, (w, h), objs) in enumerate(_voc_cases()):
+                xml = VOC_XML.format(name=iid, w=w, h=h, objs="".join(
+                    VOC_OBJ.format(name=n, diff=df, x1=a, y1=b, x2=c, y2=d) for n, df, a, b, c, d in objs))
+                open(os.path.join(root, "Annotations", iid + ".xml"), "w").write(xml)
+                buf = io.BytesIO()
+                Image.fromarray(synth.synth_u8_image(h, w, 4242 + k)).save(buf, format="JPEG" if ext == "jpg" else "PNG")
+                open(os.path.join(root, "JPEGImages", iid + "." + ext), "wb").write(buf.getvalue())
+                files[iid] = {"xml": xml, "image_hex": buf.getvalue().hex()}
+            open(os.path.join(root, "ImageSets", "Main", "train.txt"), "w").write(
+                "".join(iid + "\n" for iid, _, _ in _voc_cases()))
+            ds = getattr(mod, cls_name)(root, "train", use_difficult=use_difficult, transforms=None)
+            tag = "%s_d%d" % (cls_name, int(use_difficult))
+            items = []
+            for i in range(len(ds)):
+                img, tgt, idx = ds[i]
+                out["%s_img_%d" % (tag, i)] = np.asarray(img).copy()
+                out["%s_boxes_%d" % (tag, i)] = tgt.bbox.numpy().reshape(-1, 4)
+                out["%s_labels_%d" % (tag, i)] = tgt.get_field("labels").numpy().astype(np.int64).reshape(-1)
+                items.append({"size": list(tgt.size), "info": ds.get_img_info(i)})
+            meta["voc"].append({"cls": cls_name, "ext": ext, "use_difficult": use_difficult, "tag": tag, "files": files,
+                                "ids": [iid for iid, _, _ in _voc_cases()], "items": items})
+            print("datasets", tag, [out["%s_boxes_%d" % (tag, i)].shape[0] for i in range(len(ds))])
+
+    # COCO json boxes -> target boxes (coco.py:69-86)
+    g = torch.Generator().manual_seed(99)
+    W, H = 96, 64
+    xywh = torch.cat([torch.rand(40, 2, generator=g) * torch.tensor([W * 1.1, H * 1.1]) - 4,
+                      torch.rand(40, 2, generator=g) * 50 - 2], 1)
+    xywh[:6, 2:] = torch.tensor([[0.0, 5.0], [1.0, 1.0], [5.0, 0.5], [2.0, 2.0], [1.5, 30.0], [300.0, 300.0]])
+    xywh = torch.cat([xywh, torch.tensor([[3.0, 4.0, 20.0, 10.0], [0.0, 0.0, 96.0, 64.0], [95.0, 63.0, 5.0, 5.0]])])
+    labels = torch.arange(len(xywh)) % 8 + 1
+    t = BoxList(xywh.clone(), (W, H), mode="xywh").convert("xyxy")
+    t.add_field("labels", labels)
+    out["coco_xywh"] = xywh.numpy()
+    out["coco_size"] = np.asarray([W, H], np.int64)
+    out["coco_xyxy"] = t.bbox.numpy().copy()
+    t = t.clip_to_image(remove_empty=True)
+    out["coco_clipped"] = t.bbox.numpy()
+    out["coco_clipped_labels"] = t.get_field("labels").numpy().astype(np.int64)
+
+    # prepare_for_coco_detection (coco_eval.py:69-98)
+    ce = load(("data", "datasets", "evaluation", "coco", "coco_eval.py"), "ref_coco_eval")
+
+    class FakeDataset:
+        id_to_img_map = {0: 11, 1: 5, 2: 42, 3: 7}
+        contiguous_category_id_to_json_id = {i + 1: v for i, v in enumerate([24, 25, 26, 27, 28, 31, 32, 33])}
+        infos = [{"width": 2048, "height": 1024}, {"width": 1914, "height": 1052}, {"width": 640, "height": 480},
+                 {"width": 500, "height": 333}]
+
+        def get_img_info(self, i):
+            return self.infos[i]
+
+    preds, pin = [], []
+    for i, (w, h, n) in enumerate([(1600, 800, 7), (1333, 733, 5), (800, 600, 0), (901, 600, 4)]):
+        b = torch.rand(n, 4, generator=g) * torch.tensor([w * 0.6, h * 0.6, w * 0.4, h * 0.4])
+        b[:, 2:] += b[:, :2]
+        bl = BoxList(b, (w, h), mode="xyxy")
+        bl.add_field("scores", torch.rand(n, generator=g))
+        bl.add_field("labels", torch.randint(1, 9, (n,), generator=g))
+        preds.append(bl)
+        pin.append({"boxes": b.tolist(), "scores": bl.get_field("scores").tolist(),
+                    "labels": bl.get_field("labels").tolist(), "size": [w, h]})
+    res = ce.prepare_for_coco_detection(preds, FakeDataset())
+    meta["prepare"] = {"predictions": pin, "infos": FakeDataset.infos,
+                       "id_to_img_map": {str(k): v for k, v in FakeDataset.id_to_img_map.items()},
+                       "cat_map": {str(k): v for k, v in FakeDataset.contiguous_category_id_to_json_id.items()},
+                       "results": res}
+    np.savez_compressed(os.path.join(GOLD, "datasets.npz"), **out)
+    json.dump(meta, open(os.path.join(GOLD, "datasets.json"), "w"))
+    print("datasets.npz / datasets.json written: %d + %d bytes, %d coco results" % (
+        os.path.getsize(os.path.join(GOLD, "datasets.npz")), os.path.getsize(os.path.join(GOLD, "datasets.json")), len(res)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -622,6 +741,8 @@ def main():
         gen_step(a.check, H=512, W=1024, N=1, name="step_mid_512x1024")
     if "pipeline" in todo:
         gen_pipeline()
+    if "datasets" in todo:
+        gen_datasets()
     if "cfg" in todo:
         gen_cfg()
     if "ckpt" in todo:

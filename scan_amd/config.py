@@ -64,7 +64,7 @@ DEFAULTS = {
     "TEST": {"MODE": "common", "DETECTIONS_PER_IMG": 100, "IMS_PER_BATCH": 4},  # defaults.py:576-578, 691
     "SOLVER": {  # defaults.py:513-565, 655-682
         "MAX_ITER": 40000, "MOMENTUM": 0.9, "WEIGHT_DECAY": 0.0005, "WEIGHT_DECAY_BIAS": 0, "IMS_PER_BATCH": 16,
-        "CHECKPOINT_PERIOD": 2500, "INITIAL_AP50": 10, "VAL_ITER": 250,
+        "CHECKPOINT_PERIOD": 2500, "INITIAL_AP50": 10, "VAL_ITER": 250, "VAL_TYPE": "AP50", "ADAPT_VAL_ON": True,
         "BACKBONE": dict(_SOLVER_GROUP), "FCOS": dict(_SOLVER_GROUP), "DIS": dict(_SOLVER_GROUP),
         "MIDDLE_HEAD": dict(_SOLVER_GROUP),
     },
@@ -243,5 +243,6 @@ def settings(cfg):
         grl_weight={l: float(A["GRL_WEIGHT_%s" % l]) for l in LEVELS},
         size_divisibility=int(cfg.DATALOADER.SIZE_DIVISIBILITY), ims_per_batch=int(cfg.SOLVER.IMS_PER_BATCH),
         initial_ap50=float(cfg.SOLVER.INITIAL_AP50), max_iter=int(cfg.SOLVER.MAX_ITER),
+        val_iter=int(cfg.SOLVER.VAL_ITER), val_type=str(cfg.SOLVER.VAL_TYPE), adapt_val_on=bool(cfg.SOLVER.ADAPT_VAL_ON),
         solver={k: solver_group(cfg, k) for k in ("backbone", "fcos", "middle_head", "dis")},
     )

@@ -589,3 +589,35 @@ def inference_distributed(model, batches):
     if merged is None:
         return None
     return [merged[i] for i in sorted(merged)]
+
+
+@torch.no_grad()
+def validation(model, dataset, batch_size=4, size_divisible=32, output_folder=None):
+    """The in-loop validation of the DA trainer (reference engine/trainer.py:100-122 validataion() ->
+    engine/inference.py:62-120 inference() -> do_coco_validation): every rank runs the detector over its share of
+    ``dataset`` (items r, r + world, ... as DistributedSampler(shuffle=False) deals them, samplers/distributed.py:
+    43-56), detections are taken back to each frame's original size (BoxList.resize, coco_eval.py:78-82), gathered
+    on rank 0 and scored.  Returns (COCOResults, coco result dicts) on rank 0, None elsewhere; the models are left in
+    eval mode (the trainer switches them back, trainer.py:484-485)."""
+    from . import coco_eval, comm, data, datasets
+    collate = data.BatchCollator(size_divisible)
+    rank, world = comm.get_rank(), comm.get_world_size()
+    mine = list(range(rank, len(dataset), world))
+    dev = next(next(iter(model.values())).parameters()).device
+    results, ids = [], []
+    for k in range(0, len(mine), batch_size):
+        il, _, idxs = collate([dataset[i] for i in mine[k:k + batch_size]])
+        for (boxes, scores, labels), (h, w), idx in zip(inference(model, il), il.image_sizes, idxs):
+            info = dataset.get_img_info(idx)
+            boxes = datasets.resize_detections(boxes, (w, h), (info["width"], info["height"]))
+            results.append((boxes, scores, labels))
+            ids.append(int(idx))
+    merged = comm.gather_detections(results, ids, device=dev)
+    if merged is None:
+        return None
+    predictions = []
+    for i in range(len(dataset)):
+        info = dataset.get_img_info(i)
+        b, s, l = merged[i]
+        predictions.append((b, s, l, (info["width"], info["height"])))
+    return coco_eval.do_coco_validation(dataset, predictions, output_folder)

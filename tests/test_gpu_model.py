@@ -557,3 +557,65 @@ def test_checkpoint_resume_continues_training(device, tmp_path):
         assert torch.allclose(a, c, rtol=1e-4, atol=5e-6), (k, (a - c).abs().max().item())
         assert torch.allclose(tr_a.groups[k].flat_m, tr_c.groups[k].flat_m, rtol=1e-3, atol=1e-5), k
     assert torch.allclose(model_a["middle_head"].prototype, model_c["middle_head"].prototype, rtol=1e-4, atol=1e-5)
+
+
+def test_validation_loop_end_to_end(device, tmp_path):
+    """COCO json + image files -> COCODataset -> test transforms -> BatchCollator -> detector -> detections back in
+    the original frames -> COCO results -> AP -> the forward_target gate (reference trainer.py:100-122,465-479).  The
+    ground truth is made of the model's own detections on two of the three frames, so the expected AP is known."""
+    from PIL import Image
+    from scan_amd import coco_eval, config, data, datasets, engine, synth
+    cfg = config.load("c2f", ["INPUT.MIN_SIZE_TEST", 128, "INPUT.MAX_SIZE_TEST", 256])
+    st = config.settings(cfg)
+    K = st["num_classes"]
+    sizes = [(100, 200), (128, 256), (96, 144)]  # h, w: resized to 128x256, 128x256, 128x192
+    os.makedirs(tmp_path / "img")
+    images = []
+    for i, (h, w) in enumerate(sizes):
+        Image.fromarray(synth.synth_u8_image(h, w, 600 + i)).save(tmp_path / "img" / ("f%d.png" % i))
+        images.append({"id": 10 + 7 * i, "width": w, "height": h, "file_name": "f%d.png" % i})
+    cats = [{"id": c, "name": str(c)} for c in (24, 25, 26, 27, 28, 31, 32, 33)]
+    model = engine.build_model(device=device, settings=dict(st, test_mode="precision"))
+    engine.load_state_dicts(model, synth.shifted_state_dicts(K))
+    empty = datasets.CocoIndex({"images": images, "annotations": [], "categories": cats})
+    ds = datasets.COCODataset(empty, str(tmp_path / "img"), False, transforms=data.build_transforms(cfg, is_train=False),
+                              device=device)
+    results, raw = engine.validation(model, ds, batch_size=2, size_divisible=st["size_divisibility"])
+    dets = raw["bbox"]
+    assert len(dets) > 0 and results.results["bbox"]["AP50"] == -1  # no ground truth at all: undefined, not zero
+    by_img = {}
+    for d in dets:
+        by_img.setdefault(d["image_id"], []).append(d)
+        info = [im for im in images if im["id"] == d["image_id"]][0]
+        x, y, w, h = d["bbox"]
+        assert d["category_id"] in (24, 25, 26, 27, 28, 31, 32, 33) and 0.0 < d["score"] <= 1.0
+        assert -1.0 <= x and -1.0 <= y and x + w <= info["width"] + 1.0 and y + h <= info["height"] + 1.0 and w > 0 and h > 0
+    assert set(by_img) <= {10, 17, 24} and len(by_img) >= 2
+    # the detector run by hand on frame 1 (already 128x256: resize and the way back are identities)
+    il, _, _ = data.BatchCollator(32)([ds[1]])
+    boxes, scores, labels = engine.inference(model, il)[0]
+    mine = sorted(by_img[17], key=lambda d: -d["score"])
+    assert len(mine) == len(boxes)
+    order = torch.argsort(scores, descending=True)
+    got = torch.tensor([d["bbox"] for d in mine])
+    want = datasets.xyxy_to_xywh(boxes[order].cpu())
+    assert torch.allclose(got, want, atol=1e-4)
+    # ground truth := the detections of the first two frames -> those two are perfect, the third frame's are all false
+    anns = [{"id": k + 1, "image_id": d["image_id"], "category_id": d["category_id"], "bbox": d["bbox"],
+             "area": d["bbox"][2] * d["bbox"][3], "iscrowd": 0} for k, d in enumerate(dets) if d["image_id"] in (10, 17)]
+    gt = datasets.CocoIndex({"images": images, "annotations": anns, "categories": cats})
+    ds2 = datasets.COCODataset(gt, str(tmp_path / "img"), True, transforms=data.build_transforms(cfg, is_train=False),
+                               device=device)
+    assert len(ds2) == 2  # the frame without annotations is dropped, as the reference's training sets are
+    ds3 = datasets.COCODataset(gt, str(tmp_path / "img"), False, transforms=data.build_transforms(cfg, is_train=False),
+                               device=device)
+    results3, raw3 = engine.validation(model, ds3, batch_size=2, size_divisible=st["size_divisibility"])
+    assert [(d["image_id"], d["category_id"]) for d in raw3["bbox"]] == [(d["image_id"], d["category_id"]) for d in dets]
+    r = results3.results["bbox"]
+    assert 0.0 < r["AP50"] <= 1.0 and r["AP"] <= r["AP50"]
+    perfect = coco_eval.evaluate_predictions_on_coco(gt, [d for d in dets if d["image_id"] in (10, 17)],
+                                                     str(tmp_path / "p.json")).stats
+    assert perfect[1] == pytest.approx(1.0)
+    gate = coco_eval.TargetGate(st["initial_ap50"], st["val_type"], st["val_iter"], st["adapt_val_on"])
+    gate.update(results3)
+    assert gate.forward_target == (r["AP50"] * 100 > st["initial_ap50"])

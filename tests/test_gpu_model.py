@@ -612,7 +612,7 @@ def test_validation_loop_end_to_end(device, tmp_path):
     results3, raw3 = engine.validation(model, ds3, batch_size=2, size_divisible=st["size_divisibility"])
     assert [(d["image_id"], d["category_id"]) for d in raw3["bbox"]] == [(d["image_id"], d["category_id"]) for d in dets]
     r = results3.results["bbox"]
-    assert 0.0 < r["AP50"] <= 1.0 and r["AP"] <= r["AP50"]
+    assert 0.0 < r["AP50"] < 1.0 and r["AP"] <= r["AP50"] + 1e-9  # exact boxes: AP = AP50; frame 3 adds false positives
     perfect = coco_eval.evaluate_predictions_on_coco(gt, [d for d in dets if d["image_id"] in (10, 17)],
                                                      str(tmp_path / "p.json")).stats
     assert perfect[1] == pytest.approx(1.0)

@@ -621,3 +621,56 @@ def validation(model, dataset, batch_size=4, size_divisible=32, output_folder=No
         b, s, l = merged[i]
         predictions.append((b, s, l, (info["width"], info["height"])))
     return coco_eval.do_coco_validation(dataset, predictions, output_folder)
+
+
+def do_train(trainer, loader_source, loader_target, max_iter, val_dataset=None, gate=None, save_dir=None,
+             checkpoint_period=0, val_batch_size=4, size_divisible=32, log=None):
+    """The DA training loop around Trainer.step (reference engine/trainer.py:124-500, the with_DA branch): source and
+    target batches in lock step (:269-271), ``forward_target`` from the validation gate (:350), every sub-model stepped
+    once per iteration (inside Trainer.step), the loss scalars reduced to rank 0 for the meters (:76-98), validation
+    every VAL_ITER iterations with a checkpoint on a new best (:465-479) -- or a checkpoint every
+    ``checkpoint_period`` iterations when validation is off (:486-488) -- and ``model_final`` at the end (:489-490).
+
+    loader_*: iterables of (ImageList, targets, ids) as data.BatchCollator returns them.  gate: coco_eval.TargetGate.
+    Returns the list of per-iteration reduced loss dicts (python floats; rank 0 only, empty elsewhere)."""
+    from . import comm
+    history = []
+    start = trainer.iteration
+    for it, ((il_s, tg_s, _), (il_t, _, _)) in enumerate(zip(loader_source, loader_target), start + 1):
+        if it > max_iter:
+            break
+        forward_target = gate.forward_target if gate is not None else False
+        dev = il_s.tensors.device if il_s.tensors is not None else il_s.rows.device
+        tg_s = [(b.to(dev), l.to(dev)) for b, l in tg_s]
+        losses = trainer.step(il_s, tg_s, il_t, forward_target=forward_target)
+        reduced = comm.reduce_loss_dict(losses)
+        if comm.is_main_process():
+            names = sorted(reduced)  # one device->host copy for all the scalars
+            vals = torch.stack([reduced[k].detach().float().reshape(()) for k in names]).tolist()
+            rec = dict(zip(names, vals))
+            rec["iteration"], rec["forward_target"] = it, forward_target
+            history.append(rec)
+            if log is not None:
+                log(rec)
+        if gate is not None and val_dataset is not None and gate.due(it):
+            out = validation(trainer.model, val_dataset, batch_size=val_batch_size, size_divisible=size_divisible)
+            best = False
+            if out is not None:
+                best = gate.update(out[0])
+            if comm.get_world_size() > 1:  # every rank must take the same branch next iteration
+                flag = torch.tensor([gate.ap50_emp, float(best)], dtype=torch.float64, device=dev)
+                dist.broadcast(flag, 0)
+                gate.ap50_emp, best = float(flag[0]), bool(flag[1] > 0)
+                gate.best = max(gate.best, gate.ap50_emp) if best else gate.best
+            if best and save_dir is not None and comm.is_main_process():
+                trainer.save_checkpoint(save_dir, "model_{}_{:07d}".format(gate.best, it))
+            for m in trainer.model.values():
+                m.train()
+        elif gate is None and checkpoint_period and it % checkpoint_period == 0 and save_dir is not None \
+                and comm.is_main_process():
+            trainer.save_checkpoint(save_dir, "model_{:07d}".format(it))
+        if it == max_iter:
+            if save_dir is not None and comm.is_main_process():
+                trainer.save_checkpoint(save_dir, "model_final")
+            break
+    return history

@@ -619,3 +619,52 @@ def test_validation_loop_end_to_end(device, tmp_path):
     gate = coco_eval.TargetGate(st["initial_ap50"], st["val_type"], st["val_iter"], st["adapt_val_on"])
     gate.update(results3)
     assert gate.forward_target == (r["AP50"] * 100 > st["initial_ap50"])
+
+
+def test_do_train_loop_validates_gates_and_checkpoints(device, tmp_path):
+    """engine.do_train (reference trainer.py:124-500, DA branch): lock-step loaders, validation every VAL_ITER
+    iterations, forward_target switched on by the gate for the iterations AFTER a validation that clears the bar, a
+    checkpoint at each new best and model_final at the end."""
+    from PIL import Image
+    from scan_amd import coco_eval, config, data, datasets, engine, synth
+    cfg = config.load("c2f", ["INPUT.MIN_SIZE_TEST", 128, "INPUT.MAX_SIZE_TEST", 256, "SOLVER.VAL_ITER", 2,
+                              "SOLVER.INITIAL_AP50", 30])
+    st = config.settings(cfg)
+    K = st["num_classes"]
+    os.makedirs(tmp_path / "img")
+    images = []
+    for i in range(2):
+        Image.fromarray(synth.synth_u8_image(128, 256, 900 + i)).save(tmp_path / "img" / ("v%d.png" % i))
+        images.append({"id": i + 1, "width": 256, "height": 128, "file_name": "v%d.png" % i})
+    cats = [{"id": c, "name": str(c)} for c in range(1, K)]
+    model = engine.build_model(device=device, settings=dict(st, test_mode="precision"), attn_dropout=0.0)
+    engine.load_state_dicts(model, synth.shifted_state_dicts(K))
+    tf = data.build_transforms(cfg, is_train=False)
+    blank = datasets.COCODataset(datasets.CocoIndex({"images": images, "annotations": [], "categories": cats}),
+                                 str(tmp_path / "img"), False, transforms=tf, device=device)
+    _, raw = engine.validation(model, blank, batch_size=2)
+    # validation truth := what the initial model detects, so the first validation scores high unless training moved it
+    anns = [{"id": k + 1, "image_id": d["image_id"], "category_id": d["category_id"], "bbox": d["bbox"],
+             "area": d["bbox"][2] * d["bbox"][3], "iscrowd": 0} for k, d in enumerate(raw["bbox"])]
+    val = datasets.COCODataset(datasets.CocoIndex({"images": images, "annotations": anns, "categories": cats}),
+                               str(tmp_path / "img"), False, transforms=tf, device=device)
+
+    def loader(seed, with_targets):
+        for k in range(100):
+            il = engine.to_image_list(synth.synth_images(2, 128, 256, seed + k).to(device))
+            yield il, (synth.synth_targets(2, 128, 256, K - 1, 6, seed + 50 + k) if with_targets else None), (0, 1)
+
+    trainer = engine.Trainer(model, settings=st, base_lr=1e-5)
+    gate = coco_eval.TargetGate(st["initial_ap50"], st["val_type"], st["val_iter"], st["adapt_val_on"])
+    seen = []
+    hist = engine.do_train(trainer, loader(1, True), loader(7, False), max_iter=5, val_dataset=val, gate=gate,
+                           save_dir=str(tmp_path / "ck"), val_batch_size=2, log=seen.append)
+    assert [h["iteration"] for h in hist] == [1, 2, 3, 4, 5] and seen == hist and trainer.iteration == 5
+    # validation ran after iterations 2 and 4; with lr 1e-5 the detections barely move: AP50 far above the bar of 30
+    assert gate.ap50_emp > 30 and gate.best == pytest.approx(max(gate.best, gate.ap50_emp))
+    assert [h["forward_target"] for h in hist] == [False, False, True, True, True]
+    assert "consistency_loss_gt" in hist[2] or "node_loss_gt" in hist[2] or len(hist[2]) >= len(hist[0])
+    files = sorted(os.listdir(tmp_path / "ck"))
+    assert "model_final.pth" in files and any(f.startswith("model_") and f.endswith("0000002.pth") for f in files)
+    assert all(np.isfinite(v) for h in hist for k, v in h.items() if k not in ("iteration", "forward_target"))
+    assert all(m.training for m in model.values())

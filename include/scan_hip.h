@@ -239,6 +239,11 @@ int scan_groupnorm_stats(const float* x, const scan_pyramid_t* d, int32_t C, int
                          float* ws, void* stream);
 int scan_groupnorm_relu_forward(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G, const float* stats,
                                 const float* gamma, const float* beta, int32_t relu, float* y, void* stream);
+/* scan_groupnorm_stats_from_sums + scan_groupnorm_relu_forward as ONE launch (sums: fp64 [n_levels*N*G][2] accumulated
+ * by scan_conv3x3_gn_bf16x3; stats [n_levels*N*G][2] is written for scan_groupnorm_relu_backward). */
+int scan_groupnorm_relu_forward_from_sums(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
+                                          const float* sums, float eps, const float* gamma, const float* beta,
+                                          int32_t relu, float* y, float* stats, void* stream);
 int64_t scan_groupnorm_ws_floats(const scan_pyramid_t* d, int32_t C, int32_t G);
 /* dx, dgamma[C] (+)=, dbeta[C] (+)=; beta [C] is the forward's shift: the ReLU mask is recomputed from x with the
  * forward's exact operation order instead of reading y back (may be NULL when relu == 0);
@@ -283,6 +288,57 @@ int scan_dbscan_finish(int64_t n, void* ws, uint8_t* in_cluster0, void* stream);
  * g' = g + wd*p ; buf = momentum*buf + g' ; p -= lr*buf   (first_step != 0: buf = g') */
 int scan_sgd_momentum(float* p, const float* g, float* buf, int64_t n, float lr, float wd, float momentum,
                       int32_t first_step, void* stream);
+
+/* The same update over up to SCAN_SGD_MAX_SEGMENTS (p, g, buf) ranges in ONE launch: the weights and the biases of the
+ * eight sub-models each have their own lr / weight decay (solver/build.py:20-28: one param group per parameter, biases
+ * with BIAS_LR_FACTOR and WEIGHT_DECAY_BIAS), which torch.optim.SGD walks one parameter at a time.  segs is HOST memory
+ * (copied into the kernel arguments); element arithmetic identical to scan_sgd_momentum. */
+#define SCAN_SGD_MAX_SEGMENTS 32
+typedef struct {
+  float* p;
+  const float* g;
+  float* buf;
+  int64_t n;
+  float lr;
+  float wd;
+  int32_t first_step;
+  int32_t reserved;
+} scan_sgd_segment_t;
+int scan_sgd_momentum_multi(const scan_sgd_segment_t* segs, int32_t n_segs, float momentum, void* stream);
+
+/* ---- bf16 hi / lo planes of many conv weights in one launch (same element mapping as scan_weight_split) ----
+ * jobs: DEVICE array of n_jobs records of SCAN_SPLIT_JOB_WORDS int64: {w, wh, wl (device addresses), O, T, Cs, mode,
+ * rows (= mode ? Cs : O), Csw, first_block}; first_block = running sum of scan_weight_split_job_blocks() over the jobs
+ * before it, total_blocks the sum over all.  No reference counterpart (the reference convolves in fp32 through
+ * cuDNN); it exists because a DA iteration re-splits ~120 weights after every optimizer step. */
+#define SCAN_SPLIT_JOB_WORDS 10
+int64_t scan_weight_split_job_blocks(int32_t O, int32_t T, int32_t Cs, int32_t mode, int32_t Csw);
+int scan_weight_split_batched(const int64_t* jobs, int32_t n_jobs, int64_t total_blocks, void* stream);
+
+/* ---- CKA discriminator class branches as two stacked convolutions ----
+ * replaces the per-class loop of FCOSDiscriminator_con.forward (modeling/discriminator/
+ * fcos_head_discriminator_con.py:104-121: for each foreground class c, classifier_cls_c = conv3x3(C+1 -> H) -> ReLU ->
+ * conv3x3(H -> 1) on cat(x, act[:, c+1])).  branches[c] holds the four parameter tensors of class c (HOST array of
+ * device pointers): w0 [H][C+1][3][3], b0 [H], w2 [1][H][3][3], b2 [1]; element (o, ci, k = 3*ky + kx) of w0 lives at
+ * o*s1o + ci*s1c + k*s1k, element (h, k) of w2 at h*s2c + k*s2k (so NCHW- and channels-last-stored parameters both
+ * work).  stack writes
+ *   w1 [Cf*H][9][Cs1]: row c*H+o = w0_c[o] on columns 0..C-1, w0_c[o][C] on column C+c, zero elsewhere
+ *   b1 [Cf*H], w2 [Cf][9][Cs2]: row c = w2_c on columns c*H..c*H+H-1, zero elsewhere; b2 [Cf]
+ * in the [O][T][Cs] layout the convolution entry points take.  unstack is its adjoint: the gradient of w1 / b1 / w2 /
+ * b2 (any of them NULL = absent) scattered into grads[c] (same strides), added to what is there when accumulate != 0. */
+#define SCAN_CKA_MAX_CLASSES 16
+typedef struct {
+  const float* w0;
+  const float* b0;
+  const float* w2;
+  const float* b2;
+} scan_cka_branch_t;
+int scan_cka_stack_weights(const scan_cka_branch_t* branches, int32_t Cf, int32_t C, int32_t H, int64_t s1o, int64_t s1c,
+                           int64_t s1k, int64_t s2c, int64_t s2k, int32_t Cs1, int32_t Cs2, float* w1, float* b1,
+                           float* w2, float* b2, void* stream);
+int scan_cka_unstack_grads(const scan_cka_branch_t* grads, int32_t Cf, int32_t C, int32_t H, int64_t s1o, int64_t s1c,
+                           int64_t s1k, int64_t s2c, int64_t s2k, int32_t Cs1, int32_t Cs2, const float* dw1,
+                           const float* db1, const float* dw2, const float* db2, int32_t accumulate, void* stream);
 
 /* ---- input pipeline: the step in front of the path ----
  * scan_resize_bilinear_u8 replaces torchvision F.resize on a PIL image = PIL Image.resize(size, BILINEAR), as

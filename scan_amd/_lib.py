@@ -27,6 +27,22 @@ class PyramidDesc(ctypes.Structure):
 
 _PD = ctypes.POINTER(PyramidDesc)
 
+
+class SgdSegment(ctypes.Structure):
+    """scan_sgd_segment_t"""
+    _fields_ = [("p", c_vp), ("g", c_vp), ("buf", c_vp), ("n", c_i64), ("lr", c_f32), ("wd", c_f32),
+                ("first_step", c_i32), ("reserved", c_i32)]
+
+
+class CkaBranch(ctypes.Structure):
+    """scan_cka_branch_t"""
+    _fields_ = [("w0", c_vp), ("b0", c_vp), ("w2", c_vp), ("b2", c_vp)]
+
+
+SGD_MAX_SEGMENTS = 32
+CKA_MAX_CLASSES = 16
+SPLIT_JOB_WORDS = 10
+
 # name -> (restype, argtypes); every symbol include/scan_hip.h declares
 SIGNATURES = {
     "scan_last_error": (ctypes.c_char_p, []),
@@ -66,6 +82,7 @@ SIGNATURES = {
     "scan_relu_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "scan_groupnorm_stats": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_f32, c_vp, c_vp, c_vp]),
     "scan_groupnorm_relu_forward": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "scan_groupnorm_relu_forward_from_sums": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "scan_groupnorm_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
     "scan_groupnorm_relu_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "scan_maxpool2x2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -85,6 +102,13 @@ SIGNATURES = {
     "scan_dbscan_bfs_step": (ctypes.c_int, [c_i64, c_vp, c_i32, c_vp, c_vp]),
     "scan_dbscan_finish": (ctypes.c_int, [c_i64, c_vp, c_vp, c_vp]),
     "scan_sgd_momentum": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_i32, c_vp]),
+    "scan_sgd_momentum_multi": (ctypes.c_int, [ctypes.POINTER(SgdSegment), c_i32, c_f32, c_vp]),
+    "scan_weight_split_job_blocks": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "scan_weight_split_batched": (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp]),
+    "scan_cka_stack_weights": (ctypes.c_int, [ctypes.POINTER(CkaBranch), c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64,
+                                              c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "scan_cka_unstack_grads": (ctypes.c_int, [ctypes.POINTER(CkaBranch), c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64,
+                                              c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "scan_resize_bilinear_u8": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                                c_i32, c_vp]),
     "scan_normalize_image_u8": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_f32),

@@ -22,6 +22,7 @@ struct GnBlock {
   int rows;      // rows in this block
   int il;        // image-level index
   int hw;
+  bool first;    // first row chunk of its (level, image)
 };
 __device__ __forceinline__ GnBlock gn_block(const scan_pyramid_t& d, const GnTab& t) {
   GnBlock b;
@@ -32,6 +33,7 @@ __device__ __forceinline__ GnBlock gn_block(const scan_pyramid_t& d, const GnTab
   const int r = blockIdx.x - t.blk_off[lvl];
   const int n = r / t.per_img[lvl], chunk = r - n * t.per_img[lvl];
   b.il = lvl * d.n_images + n;
+  b.first = chunk == 0;
   b.hw = d.h[lvl] * d.w[lvl];
   const int64_t start = (int64_t)chunk * GN_RPB;
   b.rows = (int)((b.hw - start) < GN_RPB ? (b.hw - start) : GN_RPB);
@@ -104,15 +106,35 @@ __device__ __forceinline__ float4 gn_affine4(const float4 v, float mean, float r
   return o;
 }
 
+// sums != nullptr: (mean, rstd) are derived here from the fp64 (sum, sum of squares) a conv epilogue accumulated -- the
+// arithmetic of gn_stats_final_kernel, so the launch of its own goes away -- and the first block of every (level, image)
+// writes them to stats_out for the backward pass.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, scan_pyramid_t d, GnTab tab, int G,
                                                        const float* __restrict__ stats,
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int relu,
-                                                       float* __restrict__ y) {
+                                                       float* __restrict__ y, const double* __restrict__ sums,
+                                                       float eps, float* __restrict__ stats_out) {
   const GnBlock b = gn_block(d, tab);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 1;
-  const float mean = stats[((int64_t)b.il * G + g) * 2], rstd = stats[((int64_t)b.il * G + g) * 2 + 1];
+  float mean, rstd;
+  if (sums != nullptr) {
+    const int64_t i = (int64_t)b.il * G + g;
+    const double cnt = (double)b.hw * (GN_C / G);
+    const double m = sums[2 * i] / cnt;
+    double var = sums[2 * i + 1] / cnt - m * m;
+    if (var < 0) var = 0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (b.first && wid == 0 && (lane & 1) == 0) {
+      stats_out[2 * i] = mean;
+      stats_out[2 * i + 1] = rstd;
+    }
+  } else {
+    mean = stats[((int64_t)b.il * G + g) * 2];
+    rstd = stats[((int64_t)b.il * G + g) * 2 + 1];
+  }
   const float4 ga = *reinterpret_cast<const float4*>(gamma + 4 * lane);
   const float4 be = *reinterpret_cast<const float4*>(beta + 4 * lane);
   const int64_t base = b.row0 * GN_C + 4 * lane;
@@ -217,7 +239,23 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ dy, scan_pyramid_t d, GnTab tab,
                                                            int G, const float* __restrict__ stats,
                                                            const float* __restrict__ gamma, int relu,
-                                                           const double* __restrict__ ws_g, float* __restrict__ dx) {
+                                                           const double* __restrict__ ws_g, float* __restrict__ dx,
+                                                           const double* __restrict__ ws_c, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta, int accumulate) {
+  if (blockIdx.x == 0) {
+    // the channel sums are final (the reduce kernel ran before this launch): fold the GN_REP replicas into dgamma /
+    // dbeta here instead of in a one-block launch of its own (256 threads == 256 channels)
+    const int c = threadIdx.x;
+    double sa = 0.0, sb = 0.0;
+#pragma unroll
+    for (int r = 0; r < GN_REP; ++r) {
+      sa += ws_c[(int64_t)r * 2 * GN_C + 2 * c];
+      sb += ws_c[(int64_t)r * 2 * GN_C + 2 * c + 1];
+    }
+    const float a = (float)sa, bb = (float)sb;
+    dgamma[c] = accumulate ? dgamma[c] + a : a;
+    dbeta[c] = accumulate ? dbeta[c] + bb : bb;
+  }
   const GnBlock b = gn_block(d, tab);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 1;
@@ -251,20 +289,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       }
     }
   }
-}
-
-__global__ void gn_bwd_param_final_kernel(const double* __restrict__ ws_c, float* __restrict__ dgamma,
-                                          float* __restrict__ dbeta, int accumulate) {
-  const int c = threadIdx.x;
-  double sa = 0.0, sb = 0.0;
-#pragma unroll
-  for (int r = 0; r < GN_REP; ++r) {
-    sa += ws_c[(int64_t)r * 2 * GN_C + 2 * c];
-    sb += ws_c[(int64_t)r * 2 * GN_C + 2 * c + 1];
-  }
-  const float a = (float)sa, b = (float)sb;
-  dgamma[c] = accumulate ? dgamma[c] + a : a;
-  dbeta[c] = accumulate ? dbeta[c] + b : b;
 }
 
 static int gn_check(const scan_pyramid_t* d, int C, int G, const char* who) {
@@ -329,8 +353,25 @@ extern "C" int scan_groupnorm_relu_forward(const float* x, const scan_pyramid_t*
   SCAN_CHECK_ARG(x && stats && gamma && beta && y, "groupnorm_relu_forward: null pointer");
   GnTab tab;
   const int nblk = gn_tab(d, &tab);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), x, *d, tab, G, stats, gamma, beta, relu, y);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), x, *d, tab, G, stats, gamma, beta, relu, y,
+                     (const double*)nullptr, 0.f, (float*)nullptr);
   SCAN_LAUNCH_CHECK("gn_apply");
+  return 0;
+}
+
+// scan_groupnorm_stats_from_sums + scan_groupnorm_relu_forward in one launch: sums = fp64 [n_levels*N*G][2] from
+// scan_conv3x3_gn_bf16x3's epilogue; stats [n_levels*N*G][2] is written for the backward pass.
+extern "C" int scan_groupnorm_relu_forward_from_sums(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
+                                                     const float* sums, float eps, const float* gamma,
+                                                     const float* beta, int32_t relu, float* y, float* stats,
+                                                     void* stream) {
+  if (gn_check(d, C, G, "groupnorm_relu_forward_from_sums")) return -1;
+  SCAN_CHECK_ARG(x && sums && stats && gamma && beta && y, "groupnorm_relu_forward_from_sums: null pointer");
+  GnTab tab;
+  const int nblk = gn_tab(d, &tab);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), x, *d, tab, G, (const float*)nullptr,
+                     gamma, beta, relu, y, reinterpret_cast<const double*>(sums), eps, stats);
+  SCAN_LAUNCH_CHECK("gn_apply_from_sums");
   return 0;
 }
 
@@ -353,9 +394,8 @@ extern "C" int scan_groupnorm_relu_backward(const float* x, const float* beta, c
   const int nblk = gn_tab(d, &tab);
   hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, x, beta, dy, *d, tab, G, stats, gamma, relu, ws_g, ws_c);
   SCAN_LAUNCH_CHECK("gn_bwd_reduce");
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, x, beta, dy, *d, tab, G, stats, gamma, relu, ws_g, dx);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, x, beta, dy, *d, tab, G, stats, gamma, relu, ws_g, dx,
+                     ws_c, dgamma, dbeta, accumulate);
   SCAN_LAUNCH_CHECK("gn_bwd_apply");
-  hipLaunchKernelGGL(gn_bwd_param_final_kernel, dim3(1), dim3(GN_C), 0, st, ws_c, dgamma, dbeta, accumulate);
-  SCAN_LAUNCH_CHECK("gn_bwd_param_final");
   return 0;
 }

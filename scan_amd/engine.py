@@ -223,6 +223,13 @@ class FlatGroup:
                 by_name[name].copy_(st["momentum_buffer"].to(self.flat_m.device))
         self.first = len(sd["state"]) == 0
 
+    def segments(self, lr_factor=1.0):
+        """(p, g, buf, lr, wd, first_step) of the weight range and of the bias range, for ops.sgd_momentum_multi_"""
+        lr = self.lr * lr_factor
+        return [(self.flat_p[:self.n_w], self.flat_g[:self.n_w], self.flat_m[:self.n_w], lr, self.wd, self.first),
+                (self.flat_p[self.n_w:], self.flat_g[self.n_w:], self.flat_m[self.n_w:], lr * self.bias_lr_factor,
+                 self.wd_bias, self.first)]
+
     def step(self, lr_factor=1.0):
         lr = self.lr * lr_factor
         ops.sgd_momentum_(self.flat_p[:self.n_w], self.flat_g[:self.n_w], self.flat_m[:self.n_w], lr, self.wd,
@@ -295,6 +302,7 @@ class Trainer:
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
         self.comm_stream = torch.cuda.Stream() if self.distributed else None
         self._pending = []
+        self._split_plan = ops.SplitPlan()  # the conv weights re-split at the start of every iteration, in one launch
         # The five CKA discriminators are independent; P4..P7 have 16 K ... 256 pixel rows, far too few tiles to
         # fill 256 CUs, so they run on side HIP streams next to P3 (autograd replays each backward on the stream
         # of its forward, so the backward overlaps the same way).
@@ -359,8 +367,17 @@ class Trainer:
 
     def _optimizer_step(self):
         """optimizer.step() + scheduler.step() of every sub-model (reference engine/trainer.py:418-424)."""
-        for k, g in self.groups.items():
-            g.step(warmup_factor(self.iteration, **self.sched[k]))
+        moms = {g.momentum for g in self.groups.values()}
+        if len(moms) == 1:
+            # every (weights | biases) range of every sub-model in ONE launch, each with its own lr / weight decay
+            segs = []
+            for k, g in self.groups.items():
+                segs.extend(g.segments(warmup_factor(self.iteration, **self.sched[k])))
+                g.first = False
+            ops.sgd_momentum_multi_(segs, moms.pop())
+        else:
+            for k, g in self.groups.items():
+                g.step(warmup_factor(self.iteration, **self.sched[k]))
         self.iteration += 1
         # parameters changed in place (same data_ptr): the cached bf16 hi/lo weight planes are stale from here on,
         # whoever runs next -- the next step, an in-loop validation or inference()
@@ -421,7 +438,7 @@ class Trainer:
         loss (label 0) on the two halves of a level.  The reference's three backward calls (trainer.py:299,343,377)
         accumulate into the same .grad, so ONE backward of the summed losses leaves identical gradients."""
         model, lam = self.model, self.con_dis_lambda
-        ops.begin_weight_epoch()
+        ops.begin_weight_epoch(self._split_plan)
         fcos_mod.reset_target_plan()
         for m in model.values():
             m.train()
@@ -506,7 +523,7 @@ class Trainer:
             if _padded_shape(il_s) == _padded_shape(il_t):
                 return self.step_paired(il_s, targets_s, il_t, forward_target)
         model, lam = self.model, self.con_dis_lambda
-        ops.begin_weight_epoch()  # parameters change once per iteration: reuse their bf16 planes within it
+        ops.begin_weight_epoch(self._split_plan)  # parameters change once per iteration: reuse their bf16 planes within it
         fcos_mod.reset_target_plan()
         for m in model.values():
             m.train()

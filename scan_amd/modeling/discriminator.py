@@ -40,7 +40,9 @@ class FCOSDiscriminator_con(nn.Module):
                 nn.init.constant_(m.bias, 0)
         self.grad_reverse = GradientReversal(grad_reverse_lambda)
 
-    def _stacked_weights(self):
+    def _stacked_weights_torch(self):
+        """the stacked weights spelled out in torch ops (what ops.cka_stacked_weights computes in one launch); kept as
+        the readable definition and for the test that compares the two"""
         Cf, C = self.num_classes, self.in_channels
         blocks = [getattr(self, "classifier_cls_%d" % c) for c in range(Cf)]
         w0 = torch.stack([b[0].weight for b in blocks], 0)  # [Cf,128,C+1,3,3]
@@ -60,11 +62,12 @@ class FCOSDiscriminator_con(nn.Module):
         feature = self.grad_reverse(feature)
         act_maps = self.grad_reverse(act_maps)
         x = run_tower(self.dis_tower, feature, shape, self.num_convs)
-        w1, b1, w2, b2 = self._stacked_weights()
         xcat = torch.cat([x, act_maps[:, 1:]], 1)  # [M, 256 + Cf]; 264 is a multiple of 4
         pad = ops.pad4(xcat.shape[1]) - xcat.shape[1]
         if pad:
             xcat = torch.nn.functional.pad(xcat, (0, pad))
+        blocks = [getattr(self, "classifier_cls_%d" % c) for c in range(Cf)]
+        w1, b1, w2, b2 = ops.cka_stacked_weights([(b[0], b[2]) for b in blocks], self.in_channels, 128, xcat.shape[1])
         h = ops.conv2d(xcat, w1, b1, shape, 3, 1, relu="deferred")  # its only consumer masks dx by (h > 0)
         return ops.conv2d(h, w2, b2, shape, 3, 1, mask_dx=True)[:, :Cf], act_maps
 

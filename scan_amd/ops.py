@@ -10,6 +10,7 @@ level-major / image / y / x order, Cs = channel stride, a multiple of 4) plus a
 ``PyramidShape`` describing how rows split into levels (see include/scan_hip.h).
 """
 import ctypes
+import weakref
 
 import torch
 
@@ -173,23 +174,75 @@ def _round8(c):
 SPLIT_EPOCH = None
 _split_cache = {}
 _epoch_counter = [0]
+_active_plan = None
 
 
-def begin_weight_epoch():
+class SplitPlan:
+    """The conv weights one owner (an engine.Trainer) needs as bf16 planes in every iteration.  The first iteration
+    splits them one launch per weight as they are met and records (parameter, geometry, plane buffers) here; every later
+    begin_weight_epoch(plan) re-splits ALL of them with ONE launch (scan_weight_split_batched) into the same buffers
+    -- ~120 launches of 3-8 us on the critical path become one.  A job holds only a weak reference to its parameter:
+    it is dropped when the parameter dies, and a weight that stops matching (another model at the same address) misses
+    on the shape test in _conv3x3_bf16x3 and replaces its job."""
+
+    def __init__(self):
+        self.jobs = {}     # (data_ptr, mode, csw) -> (weakref to the parameter, O, T, cs_w, mode, rows, csw, wh, wl)
+        self.table = None  # device int64 [n_jobs, SPLIT_JOB_WORDS]
+        self.order = []
+        self.blocks = 0
+        self.dirty = True
+
+    def add(self, key, param, O, T, cs_w, mode, rows, csw, wh, wl):
+        self.jobs[key] = (weakref.ref(param), O, T, cs_w, mode, rows, csw, wh, wl)
+        self.dirty = True
+
+    def run(self):
+        dead = [k for k, j in self.jobs.items() if j[0]() is None or j[0]().data_ptr() != k[0]]
+        for k in dead:
+            del self.jobs[k]
+        if dead:
+            self.dirty = True
+        if not self.jobs:
+            return
+        if self.dirty:
+            rows, off = [], 0
+            self.order = list(self.jobs.keys())
+            for k in self.order:
+                _, O, T, cs_w, mode, r, csw, wh, wl = self.jobs[k]
+                rows.append([k[0], wh.data_ptr(), wl.data_ptr(), O, T, cs_w, mode, r, csw, off])
+                off += query("scan_weight_split_job_blocks", O, T, cs_w, mode, csw)
+            dev = self.jobs[self.order[0]][7].device
+            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self.blocks = off
+            self.dirty = False
+        call("scan_weight_split_batched", _ptr(self.table), len(self.order), self.blocks, _stream())
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        for k in self.order:
+            j = self.jobs[k]
+            _split_cache[k] = (SPLIT_EPOCH, j[7], j[8], ev)
+
+
+def begin_weight_epoch(plan=None):
     """Start of a span in which parameters do not change (one training iteration): the bf16 planes split inside it are
-    reused by every launch that reads the same weight (forward, data gradient, source / target passes)."""
-    global SPLIT_EPOCH
+    reused by every launch that reads the same weight (forward, data gradient, source / target passes).  With a
+    SplitPlan the planes it knows are produced right here, in one launch."""
+    global SPLIT_EPOCH, _active_plan
     _epoch_counter[0] += 1
     SPLIT_EPOCH = _epoch_counter[0]
     _split_cache.clear()
+    _active_plan = plan
+    if plan is not None:
+        plan.run()
 
 
 def invalidate_weight_planes():
     """Parameters are about to change or have changed in place (optimizer step, state_dict / checkpoint load): drop
     every cached plane and stop caching until the next begin_weight_epoch().  In-place updates keep data_ptr, so a
     stale entry would otherwise be served to e.g. inference() after training."""
-    global SPLIT_EPOCH
+    global SPLIT_EPOCH, _active_plan
     SPLIT_EPOCH = None
+    _active_plan = None
     _split_cache.clear()
 
 
@@ -198,7 +251,7 @@ _gn_sums = {}
 
 
 def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None,
-                    mask=None, dst_shape=None, cmap=0, pool=False, gn_sums=False):
+                    mask=None, dst_shape=None, cmap=0, pool=False, gn_sums=False, param=None):
     """wp: packed fp32 weights [O][T][Cs_w], T = 9 (3x3 / stride 1) or 1 (1x1; dst_shape = output pyramid, cmap =
     scan_conv1x1_bf16x3's map).  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
     st = _stream()
@@ -211,7 +264,7 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
     if cache_key is not None and SPLIT_EPOCH is not None:
         key = (cache_key, mode, csw)
         hit = _split_cache.get(key)
-        if hit is not None and hit[0] != SPLIT_EPOCH:
+        if hit is not None and (hit[0] != SPLIT_EPOCH or tuple(hit[1].shape) != (rows, T, csw)):
             hit = None
     if hit is not None:
         wh, wl = hit[1], hit[2]
@@ -225,6 +278,8 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
             _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
+            if _active_plan is not None and param is not None and wp.data_ptr() == cache_key == param.data_ptr():
+                _active_plan.add((cache_key, mode, csw), param, O, T, cs_w, mode, rows, csw, wh, wl)
     y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
     if kernel_timer.enabled:  # label the record with the template instance the launch takes (64 / 128 / 256 channels)
         inst = query("scan_conv3x3_bf16x3_instance", (dst_shape or shape).ref(), nout) if T == 9 else (128 if nout > 64 else 64)
@@ -304,11 +359,11 @@ class _Conv2d(torch.autograd.Function):
                     raise RuntimeError("conv2d(pool=True) needs a 3x3 conv on a single-level pyramid")
                 (h, w_) = shape.sizes[0]
                 y = _conv3x3_bf16x3(x, shape, wp, cout, shape.n_images * (h // 2) * (w_ // 2), cs, 0, bias, relu, cout_s,
-                                    "conv3x3_bf16x3_fwd", flops, cache_key=ckey, pool=True)
+                                    "conv3x3_bf16x3_fwd", flops, cache_key=ckey, pool=True, param=weight)
             else:
                 y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s,
                                     "conv3x3_bf16x3_fwd" if ksize == 3 else "conv1x1_bf16x3_fwd", flops,
-                                    cache_key=ckey, dst_shape=oshape, cmap=stride - 1,
+                                    cache_key=ckey, dst_shape=oshape, cmap=stride - 1, param=weight,
                                     gn_sums=gn_sums and ksize == 3 and cout == 256 and cout_s == 256 and not relu)
         else:
             y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
@@ -348,7 +403,7 @@ class _Conv2d(torch.autograd.Function):
             dx = _conv3x3_bf16x3(dy, oshape, pack_weight(weight, cs), cout, x.shape[0], cout_s, 1, None, False, cs,
                                  "conv3x3_bf16x3_dgrad" if ksize == 3 else "conv1x1_bf16x3_dgrad",
                                  2.0 * oshape.rows * cout * T * cin, cache_key=ctx.ckey, mask=mask, dst_shape=shape,
-                                 cmap=0 if stride == 1 else 2)
+                                 cmap=0 if stride == 1 else 2, param=weight)
         elif ctx.needs_input_grad[0]:
             wp = pack_weight(weight, cs)
             wt = x.new_empty((cs, T, cout_s))
@@ -567,17 +622,19 @@ class _GroupNormReLU(torch.autograd.Function):
         _chk(x, gamma, beta)
         C = x.shape[1]
         st = _stream()
-        nws = query("scan_groupnorm_ws_floats", shape.ref(), C, 32)
-        ws = torch.empty((nws // 2 + 1,), dtype=torch.float64, device=x.device)
         stats = x.new_empty((shape.n_levels * shape.n_images * 32 * 2,))
         sums = _gn_sums.pop(x.data_ptr(), None)
-        if sums is not None:  # accumulated by the epilogue of the conv that produced x
-            call("scan_groupnorm_stats_from_sums", _ptr(sums), shape.ref(), C, 32, eps, _ptr(stats), st)
-        else:
-            call("scan_groupnorm_stats", _ptr(x), shape.ref(), C, 32, eps, _ptr(stats), _ptr(ws), st)
         y = torch.empty_like(x)
-        call("scan_groupnorm_relu_forward", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta), int(relu),
-             _ptr(y), st)
+        if sums is not None:  # accumulated by the epilogue of the conv that produced x: one launch normalises and
+            # leaves (mean, rstd) behind for the backward
+            call("scan_groupnorm_relu_forward_from_sums", _ptr(x), shape.ref(), C, 32, _ptr(sums), eps, _ptr(gamma),
+                 _ptr(beta), int(relu), _ptr(y), _ptr(stats), st)
+        else:
+            nws = query("scan_groupnorm_ws_floats", shape.ref(), C, 32)
+            ws = torch.empty((nws // 2 + 1,), dtype=torch.float64, device=x.device)
+            call("scan_groupnorm_stats", _ptr(x), shape.ref(), C, 32, eps, _ptr(stats), _ptr(ws), st)
+            call("scan_groupnorm_relu_forward", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta),
+                 int(relu), _ptr(y), st)
         ctx.save_for_backward(x, beta, gamma, stats)  # the backward recomputes the ReLU mask from x: y is not kept
         ctx.cfg = (shape, relu)
         ctx.gbuf = ctx.bbuf = None
@@ -901,7 +958,90 @@ def dbscan_in_cluster0(pts, eps, min_samples=5):
     return out.bool()
 
 
+# ----------------------------------------------------------------------------- CKA discriminator class branches
+class _CkaStackedWeights(torch.autograd.Function):
+    """The Cf per-class classifier branches (conv3x3 C+1 -> H, conv3x3 H -> 1; reference
+    discriminator/fcos_head_discriminator_con.py:44-62) as the weights of two stacked convolutions -- one launch
+    forward (scan_cka_stack_weights), one launch backward (scan_cka_unstack_grads, straight into the parameters' flat
+    gradient buffers when they have them) instead of the ~40 stack / slice / mul / cat kernels and their autograd
+    mirror images per discriminator."""
+
+    @staticmethod
+    def forward(ctx, C, H, cs1, *params):
+        cf = len(params) // 4
+        w0s, b0s, w2s, b2s = params[0::4], params[1::4], params[2::4], params[3::4]
+        _chk(*params)
+        w0, w2 = w0s[0], w2s[0]
+        assert tuple(w0.shape) == (H, C + 1, 3, 3) and tuple(w2.shape) == (1, H, 3, 3), (w0.shape, w2.shape)
+        for a, b in zip(w0s, w2s):
+            if a.stride() != w0.stride() or b.stride() != w2.stride() or a.shape != w0.shape or b.shape != w2.shape:
+                raise RuntimeError("cka_stacked_weights: the class branches must share one memory layout")
+        if w0.stride(2) != 3 * w0.stride(3) or w2.stride(2) != 3 * w2.stride(3):
+            raise RuntimeError("cka_stacked_weights: the 3x3 taps of a weight must be evenly strided")
+        strides = (w0.stride(0), w0.stride(1), w0.stride(3), w2.stride(1), w2.stride(3))
+        cs2 = cf * H
+        dev = w0.device
+        w1 = torch.empty((cf * H, 9, cs1), device=dev)
+        b1 = torch.empty((cf * H,), device=dev)
+        w2o = torch.empty((cf, 9, cs2), device=dev)
+        b2 = torch.empty((cf,), device=dev)
+        arr = (_lib.CkaBranch * cf)()
+        for a, p0, q0, p2, q2 in zip(arr, w0s, b0s, w2s, b2s):
+            a.w0, a.b0, a.w2, a.b2 = p0.data_ptr(), q0.data_ptr(), p2.data_ptr(), q2.data_ptr()
+        call("scan_cka_stack_weights", arr, cf, C, H, *strides, cs1, cs2, _ptr(w1), _ptr(b1), _ptr(w2o), _ptr(b2),
+             _stream())
+        ctx.cfg = (cf, C, H, cs1, cs2, strides)
+        ctx.params = params  # parameters (leaf tensors), needed for their .grad buffers; not graph intermediates
+        # logical conv weights [O, Cin, 3, 3] stored channels-last: conv2d reads them in place
+        return (w1.view(cf * H, 3, 3, cs1).permute(0, 3, 1, 2), b1, w2o.view(cf, 3, 3, cs2).permute(0, 3, 1, 2), b2)
+
+    @staticmethod
+    def backward(ctx, dw1, db1, dw2, db2):
+        cf, C, H, cs1, cs2, strides = ctx.cfg
+        params = ctx.params
+
+        def ohwi(g):
+            return None if g is None else g.permute(0, 2, 3, 1).contiguous()
+
+        dw1, dw2 = ohwi(dw1), ohwi(dw2)
+        db1 = None if db1 is None else db1.contiguous()
+        db2 = None if db2 is None else db2.contiguous()
+        direct = all(getattr(p, "_scan_flat", False) and p.grad is not None and p.grad.stride() == p.stride()
+                     for p in params)
+        tgt = [p.grad for p in params] if direct else [torch.zeros_like(p) for p in params]
+        arr = (_lib.CkaBranch * cf)()
+        for c, a in enumerate(arr):
+            a.w0, a.b0, a.w2, a.b2 = (t.data_ptr() for t in tgt[4 * c:4 * c + 4])
+        call("scan_cka_unstack_grads", arr, cf, C, H, *strides, cs1, cs2, _ptr(dw1), _ptr(db1), _ptr(dw2), _ptr(db2),
+             1, _stream())
+        return (None, None, None) + (tuple(None for _ in params) if direct else tuple(tgt))
+
+
+def cka_stacked_weights(branches, C, H, cs1):
+    """branches: the Cf (conv0, conv2) module pairs.  Returns (w1 [Cf*H, cs1, 3, 3], b1, w2 [Cf, Cf*H, 3, 3], b2) with
+    cs1 = the (padded) channel count of cat(x, act[1:])."""
+    params = []
+    for c0, c2 in branches:
+        params += [c0.weight, c0.bias, c2.weight, c2.bias]
+    return _CkaStackedWeights.apply(int(C), int(H), int(cs1), *params)
+
+
 # ----------------------------------------------------------------------------- optimizer
+def sgd_momentum_multi_(segments, momentum):
+    """segments: list of (p, g, buf, lr, wd, first_step) flat fp32 tensors of equal length -- all updated by ONE launch
+    (scan_sgd_momentum_multi), element arithmetic as sgd_momentum_."""
+    segments = [sg for sg in segments if sg[0].numel() > 0]
+    for k in range(0, len(segments), _lib.SGD_MAX_SEGMENTS):
+        part = segments[k:k + _lib.SGD_MAX_SEGMENTS]
+        arr = (_lib.SgdSegment * len(part))()
+        for a, (p, g, buf, lr, wd, first) in zip(arr, part):
+            _chk(p, g, buf)
+            assert p.numel() == g.numel() == buf.numel()
+            a.p, a.g, a.buf, a.n = p.data_ptr(), g.data_ptr(), buf.data_ptr(), p.numel()
+            a.lr, a.wd, a.first_step, a.reserved = float(lr), float(wd), int(bool(first)), 0
+        call("scan_sgd_momentum_multi", arr, len(part), float(momentum), _stream())
+
+
 def sgd_momentum_(p, g, buf, lr, wd, momentum, first_step):
     _chk(p, g, buf)
     call("scan_sgd_momentum", _ptr(p), _ptr(g), _ptr(buf), p.numel(), float(lr), float(wd), float(momentum),

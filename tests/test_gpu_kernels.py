@@ -766,3 +766,124 @@ def test_nchw_drop_in_modules(device):
     lr = F.conv2d(f, kp.view(9, 256, 1, 1))
     np.testing.assert_allclose(lg.cpu().numpy(), lr.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(pb.cpu().numpy(), lr.softmax(1).numpy(), rtol=1e-4, atol=1e-5)
+
+
+# ----------------------------------------------------------------------------- many-tensor launches (csrc/batched.hip)
+def test_weight_split_batched_equals_single_launches(device):
+    """scan_weight_split_batched over a table of jobs writes bit for bit the planes scan_weight_split writes one
+    weight at a time (both modes, 3x3 and 1x1, channel counts that need row padding)."""
+    from scan_amd import _lib, ops
+    g = torch.Generator().manual_seed(21)
+    jobs, expect, rows, off = [], [], [], 0
+    for (O, T, Cs) in [(256, 9, 256), (128, 9, 64), (8, 9, 256), (256, 1, 512), (1024, 9, 264), (12, 9, 268), (64, 9, 4)]:
+        w = torch.randn(O, T, Cs, generator=g).to(device)
+        for mode in (0, 1):
+            nrows = O if mode == 0 else Cs
+            csw = ops._round8(Cs if mode == 0 else O)
+            wh = torch.zeros((nrows, T, csw), dtype=torch.bfloat16, device=device)
+            wl = torch.zeros_like(wh)
+            eh, el = torch.empty_like(wh), torch.empty_like(wh)
+            _lib.call("scan_weight_split", ops._ptr(w), O, T, Cs, mode, ops._ptr(eh), ops._ptr(el), csw, ops._stream())
+            rows.append([w.data_ptr(), wh.data_ptr(), wl.data_ptr(), O, T, Cs, mode, nrows, csw, off])
+            off += _lib.query("scan_weight_split_job_blocks", O, T, Cs, mode, csw)
+            jobs.append((w, wh, wl))
+            expect.append((eh, el))
+    table = torch.tensor(rows, dtype=torch.int64).to(device)
+    assert table.shape[1] == _lib.SPLIT_JOB_WORDS
+    _lib.call("scan_weight_split_batched", ops._ptr(table), len(rows), off, ops._stream())
+    torch.cuda.synchronize()
+    for (w, wh, wl), (eh, el) in zip(jobs, expect):
+        assert torch.equal(wh.view(torch.int16), eh.view(torch.int16)) and torch.equal(wl.view(torch.int16), el.view(torch.int16))
+    with pytest.raises(RuntimeError):
+        _lib.call("scan_weight_split_batched", ops._ptr(table), 0, off, ops._stream())
+
+
+def test_split_plan_resplits_after_parameter_update(device):
+    """ops.SplitPlan: the second begin_weight_epoch re-splits every recorded weight in one launch, from the CURRENT
+    parameter values, and the conv that follows uses those planes (same output as without a plan)."""
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(22)
+    x, shape = _rows(torch.randn(2, 64, 24, 40, generator=g), device)
+    w = (torch.randn(64, 64, 3, 3, generator=g) / 24).to(device).contiguous(memory_format=torch.channels_last)
+    w.requires_grad_(True)
+    w._scan_flat = True
+    plan = ops.SplitPlan()
+    try:
+        ops.begin_weight_epoch(plan)
+        xr = x.clone().requires_grad_(True)
+        y0 = ops.conv2d(xr, w, None, shape)
+        y0.sum().backward()
+        assert len(plan.jobs) == 2  # forward and data-gradient planes of the one weight
+        with torch.no_grad():
+            w.mul_(-0.5)
+        ops.begin_weight_epoch(plan)
+        assert len(ops._split_cache) == 2  # both planes are ready before any conv ran
+        with torch.no_grad():
+            y1 = ops.conv2d(x, w, None, shape)
+        assert len(plan.jobs) == 2 and not plan.dirty
+    finally:
+        ops.invalidate_weight_planes()
+    with torch.no_grad():
+        y2 = ops.conv2d(x, w, None, shape)  # no plan, no cache
+    assert torch.equal(y1, y2)
+    y0 = y0.detach()
+    assert (y1 + 0.5 * y0).abs().max().item() <= 1e-5 * y0.abs().max().item()
+    del w, xr
+    ops.begin_weight_epoch(plan)  # the parameter died: its jobs are dropped, nothing is launched on freed memory
+    assert not plan.jobs
+    ops.invalidate_weight_planes()
+
+
+def test_sgd_multi_equals_single_launches(device):
+    from scan_amd import ops
+    torch.manual_seed(3)
+    specs = [(100003, 0.01, 5e-4, False), (7, 0.02, 0.0, False), (4096, 0.003, 1e-4, True), (0, 0.1, 0.0, False),
+             (250000, 0.01, 5e-4, True)] * 8  # 40 segments: more than one launch's table
+    segs, refs = [], []
+    for n, lr, wd, first in specs:
+        p, g, m = torch.randn(n, device=device), torch.randn(n, device=device), torch.randn(n, device=device)
+        pr, mr = p.clone(), m.clone()
+        if n:
+            ops.sgd_momentum_(pr, g, mr, lr, wd, 0.9, first)
+        segs.append((p, g, m, lr, wd, first))
+        refs.append((pr, mr))
+    ops.sgd_momentum_multi_(segs, 0.9)
+    for (p, g, m, *_), (pr, mr) in zip(segs, refs):
+        assert torch.equal(p, pr) and torch.equal(m, mr)
+
+
+@pytest.mark.parametrize("cf,channels_last", [(8, True), (8, False), (1, True)])
+def test_cka_stacked_weights_equal_torch_construction(device, cf, channels_last):
+    """ops.cka_stacked_weights (one launch each way) against the stack / slice / eye / cat construction it replaces:
+    same stacked weights, same parameter gradients -- returned to autograd and accumulated into flat buffers."""
+    from scan_amd import ops
+    from scan_amd.modeling.discriminator import FCOSDiscriminator_con
+    torch.manual_seed(31)
+    dis = FCOSDiscriminator_con(num_convs=1, in_channels=256, num_classes=cf + 1).to(device)
+    blocks = [getattr(dis, "classifier_cls_%d" % c) for c in range(cf)]
+    for b in blocks:
+        for m in (b[0], b[2]):
+            nn.init.normal_(m.weight, std=0.1)
+            nn.init.normal_(m.bias, std=0.1)
+            if not channels_last:
+                m.weight.data = m.weight.data.contiguous()
+    cs1 = ops.pad4(256 + cf)
+    w1, b1, w2, b2 = ops.cka_stacked_weights([(b[0], b[2]) for b in blocks], 256, 128, cs1)
+    rw1, rb1, rw2, rb2 = dis._stacked_weights_torch()
+    assert w1.shape == (cf * 128, cs1, 3, 3) and w1.permute(0, 2, 3, 1).is_contiguous()
+    assert torch.equal(w1[:, :256 + cf], rw1) and float(w1[:, 256 + cf:].abs().sum()) == 0
+    assert torch.equal(b1, rb1) and torch.equal(w2, rw2) and torch.equal(b2, rb2)
+    cot = [torch.randn_like(t) for t in (w1, b1, w2, b2)]
+    params = [p for b in blocks for p in (b[0].weight, b[0].bias, b[2].weight, b[2].bias)]
+    ref = torch.autograd.grad([rw1, rb1, rw2, rb2], params, [cot[0][:, :256 + cf], cot[1], cot[2], cot[3]])
+    got = torch.autograd.grad([w1, b1, w2, b2], params, cot)
+    for a, r in zip(got, ref):
+        assert torch.equal(a, r)
+    # parameters living in flat buffers: the backward adds into .grad and hands autograd nothing
+    for p in params:
+        p.grad = torch.ones_like(p)
+        p._scan_flat = True
+    w1, b1, w2, b2 = ops.cka_stacked_weights([(b[0], b[2]) for b in blocks], 256, 128, cs1)
+    torch.autograd.backward([w1, b1, w2, b2], cot)
+    for p, r in zip(params, ref):
+        assert torch.equal(p.grad, 1 + r)

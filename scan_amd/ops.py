@@ -970,7 +970,10 @@ class _CkaStackedWeights(torch.autograd.Function):
     def forward(ctx, C, H, cs1, *params):
         cf = len(params) // 4
         w0s, b0s, w2s, b2s = params[0::4], params[1::4], params[2::4], params[3::4]
-        _chk(*params)
+        for t in params:  # strided (channels-last) weights are fine here: the kernel takes element strides
+            if not t.is_cuda or t.dtype != torch.float32:
+                raise RuntimeError("scan_amd ops run only on fp32 GPU (HIP) tensors -- got %s %s; no CPU fallback"
+                                   % (t.device, t.dtype))
         w0, w2 = w0s[0], w2s[0]
         assert tuple(w0.shape) == (H, C + 1, 3, 3) and tuple(w2.shape) == (1, H, 3, 3), (w0.shape, w2.shape)
         for a, b in zip(w0s, w2s):

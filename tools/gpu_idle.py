@@ -3,7 +3,7 @@
     rocprofv3 --kernel-trace -d out --output-format csv -- python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-pointwise
     python tools/gpu_idle.py out/*/*_kernel_trace.csv
 
-Steps are delimited by the last `sgd_kernel` launch of each iteration.  For every step: wall span, the
+Steps are delimited by the last `sgd_kernel` / `sgd_multi_kernel` launch of each iteration.  For every step: wall span, the
 union of all kernel intervals (busy), idle = span - busy, and the largest gaps with the kernels either side, so a
 gap can be attributed (host synchronisation point, host-bound launch sequence, stream join).
 """
@@ -21,7 +21,7 @@ def main():
         for r in csv.DictReader(f):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    sgd_end = [e for s, e, n in rows if n.startswith("sgd_kernel")]
+    sgd_end = [e for s, e, n in rows if n.startswith("sgd_kernel") or n.startswith("sgd_multi_kernel")]
     # group consecutive sgd launches (one per sub-model) into one boundary per step: a new step starts when the
     # distance to the previous sgd launch exceeds 5 ms
     bounds = []

@@ -368,7 +368,7 @@ class Trainer:
     def _optimizer_step(self):
         """optimizer.step() + scheduler.step() of every sub-model (reference engine/trainer.py:418-424)."""
         moms = {g.momentum for g in self.groups.values()}
-        if len(moms) == 1:
+        if len(moms) == 1 and ops.BATCHED:
             # every (weights | biases) range of every sub-model in ONE launch, each with its own lr / weight decay
             segs = []
             for k, g in self.groups.items():

@@ -67,7 +67,11 @@ class FCOSDiscriminator_con(nn.Module):
         if pad:
             xcat = torch.nn.functional.pad(xcat, (0, pad))
         blocks = [getattr(self, "classifier_cls_%d" % c) for c in range(Cf)]
-        w1, b1, w2, b2 = ops.cka_stacked_weights([(b[0], b[2]) for b in blocks], self.in_channels, 128, xcat.shape[1])
+        if ops.BATCHED:
+            w1, b1, w2, b2 = ops.cka_stacked_weights([(b[0], b[2]) for b in blocks], self.in_channels, 128,
+                                                     xcat.shape[1])
+        else:
+            w1, b1, w2, b2 = self._stacked_weights_torch()
         h = ops.conv2d(xcat, w1, b1, shape, 3, 1, relu="deferred")  # its only consumer masks dx by (h > 0)
         return ops.conv2d(h, w2, b2, shape, 3, 1, mask_dx=True)[:, :Cf], act_maps
 

@@ -10,6 +10,7 @@ level-major / image / y / x order, Cs = channel stride, a multiple of 4) plus a
 ``PyramidShape`` describing how rows split into levels (see include/scan_hip.h).
 """
 import ctypes
+import os
 import weakref
 
 import torch
@@ -171,6 +172,11 @@ def _round8(c):
 
 # bf16 hi/lo planes of the parameters are valid for one optimizer step: engine.Trainer bumps SPLIT_EPOCH at the
 # start of every iteration and the planes of flat-buffer parameters are reused by the source / target passes.
+# SCAN_BATCHED=0 in the environment (or ops.BATCHED = False): the one-launch-per-tensor paths this build replaced --
+# per-weight plane splits, per-group SGD launches, the torch construction of the discriminators' stacked weights, the
+# separate GroupNorm statistics finalisation -- for same-box A/B measurements (profiles/r02_batched_ab.txt).  Same
+# results either way.
+BATCHED = os.environ.get("SCAN_BATCHED", "1") != "0"
 SPLIT_EPOCH = None
 _split_cache = {}
 _epoch_counter = [0]
@@ -231,9 +237,9 @@ def begin_weight_epoch(plan=None):
     _epoch_counter[0] += 1
     SPLIT_EPOCH = _epoch_counter[0]
     _split_cache.clear()
-    _active_plan = plan
-    if plan is not None:
-        plan.run()
+    _active_plan = plan if BATCHED else None
+    if _active_plan is not None:
+        _active_plan.run()
 
 
 def invalidate_weight_planes():
@@ -625,7 +631,11 @@ class _GroupNormReLU(torch.autograd.Function):
         stats = x.new_empty((shape.n_levels * shape.n_images * 32 * 2,))
         sums = _gn_sums.pop(x.data_ptr(), None)
         y = torch.empty_like(x)
-        if sums is not None:  # accumulated by the epilogue of the conv that produced x: one launch normalises and
+        if sums is not None and not BATCHED:
+            call("scan_groupnorm_stats_from_sums", _ptr(sums), shape.ref(), C, 32, eps, _ptr(stats), st)
+            call("scan_groupnorm_relu_forward", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta),
+                 int(relu), _ptr(y), st)
+        elif sums is not None:  # accumulated by the epilogue of the conv that produced x: one launch normalises and
             # leaves (mean, rstd) behind for the backward
             call("scan_groupnorm_relu_forward_from_sums", _ptr(x), shape.ref(), C, 32, _ptr(sums), eps, _ptr(gamma),
                  _ptr(beta), int(relu), _ptr(y), _ptr(stats), st)

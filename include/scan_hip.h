@@ -340,6 +340,23 @@ int scan_cka_unstack_grads(const scan_cka_branch_t* grads, int32_t Cf, int32_t C
                            int64_t s1k, int64_t s2c, int64_t s2k, int32_t Cs1, int32_t Cs2, const float* dw1,
                            const float* db1, const float* dw2, const float* db2, int32_t accumulate, void* stream);
 
+/* ---- the class branches' second convolution: G groups of 128 channels -> one output channel per group ----
+ * replaces `classifier_cls_c[2]` = nn.Conv2d(128, 1, 3, padding=1) applied per foreground class
+ * (fcos_head_discriminator_con.py:44-62,118-119), for all classes at once: x [M][G*128] rows of a pyramid (the ReLU-ed
+ * hidden maps of the G classes side by side), w = the stacked weight [G][9][G*128] of scan_cka_stack_weights (only the
+ * diagonal blocks w[g][t][g*128 + i] are read), y [M][Ns >= G] (columns >= G are written as zero).  Plain fp32 FMA
+ * arithmetic, HBM-bound (one read of x).  ws: scan_gconv3x3_to1_ws_floats floats.
+ *   dgrad: dx[q][c] = sum_t dy[q - off(t)][g(c)] * w[g][t][c], multiplied by (mask[q][c] > 0) when mask != NULL (the
+ *          deferred ReLU of the producer); wgrad: dw[g][t][g*128 + i] (diagonal blocks only; added to dw when
+ *          accumulate != 0), deterministic. */
+int64_t scan_gconv3x3_to1_ws_floats(const scan_pyramid_t* d, int32_t G, int32_t Cg);
+int scan_gconv3x3_to1_forward(const float* x, const scan_pyramid_t* d, int32_t G, int32_t Cg, const float* w,
+                              const float* bias, float* y, int32_t Ns, float* ws, void* stream);
+int scan_gconv3x3_to1_dgrad(const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G, int32_t Cg, const float* w,
+                            const float* mask, float* dx, void* stream);
+int scan_gconv3x3_to1_wgrad(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G, int32_t Cg,
+                            float* dw, int32_t accumulate, float* ws, void* stream);
+
 /* ---- input pipeline: the step in front of the path ----
  * scan_resize_bilinear_u8 replaces torchvision F.resize on a PIL image = PIL Image.resize(size, BILINEAR), as
  * called by Resize.__call__ (reference data/transforms/transforms.py:57-61): Pillow's two-pass fixed-point resampler.

@@ -73,6 +73,10 @@ class FCOSDiscriminator_con(nn.Module):
         else:
             w1, b1, w2, b2 = self._stacked_weights_torch()
         h = ops.conv2d(xcat, w1, b1, shape, 3, 1, relu="deferred")  # its only consumer masks dx by (h > 0)
+        if ops.GROUPED_CLS and Cf in (1, 2, 4, 8):
+            # one output channel per class from that class's 128 hidden channels: an HBM-bound grouped kernel instead of
+            # a dense conv over the block-diagonal weight (64x the useful multiply-adds)
+            return ops.gconv3x3_to1(h, w2, b2, shape, Cf, mask_dx=True)[:, :Cf], act_maps
         return ops.conv2d(h, w2, b2, shape, 3, 1, mask_dx=True)[:, :Cf], act_maps
 
     def _loss(self, logits, act_maps, target):

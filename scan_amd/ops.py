@@ -1039,6 +1039,58 @@ def cka_stacked_weights(branches, C, H, cs1):
     return _CkaStackedWeights.apply(int(C), int(H), int(cs1), *params)
 
 
+class _GroupedConvTo1(torch.autograd.Function):
+    """conv3x3 [M, G*128] -> [M, Ns >= G], one output channel per group of 128 (the class branches' second conv);
+    w = the stacked weight [G, G*128, 3, 3] (channels-last) whose diagonal blocks are the per-class weights.
+    mask_dx: x is a deferred-ReLU output (see _Conv2d)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, shape, G, mask_dx):
+        _chk(x, bias)
+        gc = G * 128
+        assert x.shape == (shape.rows, gc) and tuple(w.shape) == (G, gc, 3, 3) and w.permute(0, 2, 3, 1).is_contiguous()
+        ns = pad4(G)
+        y = x.new_empty((shape.rows, ns))
+        ws = x.new_empty((query("scan_gconv3x3_to1_ws_floats", shape.ref(), G, 128),))
+        call("scan_gconv3x3_to1_forward", _ptr(x), shape.ref(), G, 128, _ptr(w), _ptr(bias), _ptr(y), ns, _ptr(ws),
+             _stream())
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (shape, G, ns, mask_dx, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        shape, G, ns, mask_dx, has_bias = ctx.cfg
+        dy = dy.contiguous()
+        st = _stream()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            call("scan_gconv3x3_to1_dgrad", _ptr(dy), ns, shape.ref(), G, 128, _ptr(w), _ptr(x if mask_dx else None),
+                 _ptr(dx), st)
+        if ctx.needs_input_grad[1]:
+            dwp = x.new_zeros((G, 9, G * 128))  # off-diagonal blocks: exact zeros (they meet a zero in the adjoint)
+            ws = x.new_empty((query("scan_gconv3x3_to1_ws_floats", shape.ref(), G, 128),))
+            call("scan_gconv3x3_to1_wgrad", _ptr(x), _ptr(dy), ns, shape.ref(), G, 128, _ptr(dwp), 0, _ptr(ws), st)
+            dw = dwp.view(G, 3, 3, G * 128).permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            M = dy.shape[0]
+            cws = x.new_empty((query("scan_colsum_ws_floats", M, G),))
+            db = x.new_empty((G,))
+            call("scan_colsum", _ptr(dy), M, G, ns, _ptr(db), 0, _ptr(cws), st)
+        return dx, dw, db, None, None, None
+
+
+# SCAN_GROUPED_CLS=0: the class branches' second conv on the dense MFMA kernel (block-diagonal weight), for A/B
+GROUPED_CLS = os.environ.get("SCAN_GROUPED_CLS", "1") != "0"
+
+
+def gconv3x3_to1(x, w, bias, shape, G, mask_dx=False):
+    """x [M, G*128] -> [M, pad4(G)]: y[:, g] = conv3x3(x[:, g*128:(g+1)*128], w[g, g*128:(g+1)*128]) + bias[g]."""
+    return _GroupedConvTo1.apply(x, w, bias, shape, int(G), bool(mask_dx))
+
+
 # ----------------------------------------------------------------------------- optimizer
 def sgd_momentum_multi_(segments, momentum):
     """segments: list of (p, g, buf, lr, wd, first_step) flat fp32 tensors of equal length -- all updated by ONE launch

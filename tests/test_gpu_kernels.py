@@ -887,3 +887,76 @@ def test_cka_stacked_weights_equal_torch_construction(device, cf, channels_last)
     torch.autograd.backward([w1, b1, w2, b2], cot)
     for p, r in zip(params, ref):
         assert torch.equal(p.grad, 1 + r)
+
+
+@pytest.mark.parametrize("G,sizes", [(8, [(16, 24), (8, 12), (3, 5)]), (8, [(40, 64)]), (1, [(12, 20), (5, 7)]), (2, [(9, 9)])])
+def test_grouped_conv_to_one_channel_per_group(device, G, sizes):
+    """scan_gconv3x3_to1_*: the class branches' second conv (nn.Conv2d(128, 1, 3, padding=1) per class, reference
+    fcos_head_discriminator_con.py:44-62) for all classes at once, against F.conv2d(groups=G) on the CPU -- forward,
+    the ReLU-masked data gradient, the weight gradient (diagonal blocks only) and the bias gradient."""
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(41 + G)
+    N, gc = 2, G * 128
+    xs = [torch.relu(torch.randn(N, gc, h, w, generator=g)) for h, w in sizes]
+    wg = torch.randn(G, 128, 3, 3, generator=g) / 30
+    bg = torch.randn(G, generator=g)
+    # stacked weight: the per-group weights on the diagonal blocks, junk elsewhere (must be ignored)
+    ws = torch.randn(G, gc, 3, 3, generator=g)
+    for c in range(G):
+        ws[c, c * 128:(c + 1) * 128] = wg[c]
+    rows, shape = _pyr(xs, device)
+    rows.requires_grad_(True)
+    wd = ws.to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bd = bg.to(device).requires_grad_(True)
+    y = ops.gconv3x3_to1(rows, wd, bd, shape, G, mask_dx=True)
+    assert y.shape == (shape.rows, ops.pad4(G)) and float(y[:, G:].abs().sum()) == 0
+    gys = [torch.randn(N, G, h, w, generator=g) for h, w in sizes]
+    gy_rows, _ = _pyr([F.pad(t, (0, 0, 0, 0, 0, ops.pad4(G) - G)) for t in gys], device)
+    y.backward(gy_rows)
+    wr, br = wg.clone().requires_grad_(True), bg.clone().requires_grad_(True)
+    dx_ref = []
+    for l, x in enumerate(xs):
+        xr = x.clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, br, padding=1, groups=G)
+        got = ops.rows_to_nchw(y.detach(), shape, l, G).cpu()
+        np.testing.assert_allclose(got.numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-5)
+        yr.backward(gys[l])
+        dx_ref.append(xr.grad * (x > 0))  # the producer's deferred ReLU: the consumer masks its dx
+    for l, r in enumerate(dx_ref):
+        got = ops.rows_to_nchw(rows.grad, shape, l, gc).cpu()
+        np.testing.assert_allclose(got.numpy(), r.numpy(), rtol=1e-4, atol=1e-5)
+    dw = wd.grad.cpu()
+    for c in range(G):
+        np.testing.assert_allclose(dw[c, c * 128:(c + 1) * 128].numpy(), wr.grad[c].numpy(), rtol=2e-4,
+                                   atol=2e-5 * float(wr.grad.abs().max()))
+        off = torch.cat([dw[c, :c * 128], dw[c, (c + 1) * 128:]], 0)
+        assert float(off.abs().sum()) == 0  # exact zeros off the diagonal
+    np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=2e-4, atol=1e-4)
+
+
+def test_discriminator_grouped_branch_equals_dense_branch(device):
+    """FCOSDiscriminator_con with the grouped second conv and the one-launch weight stacking against the dense
+    block-diagonal conv and the torch construction: same loss, same gradients (bf16x3 vs fp32-FMA rounding apart)."""
+    from scan_amd import ops
+    from scan_amd.modeling.discriminator import FCOSDiscriminator_con
+    torch.manual_seed(5)
+    dis = FCOSDiscriminator_con(num_convs=2, in_channels=256, num_classes=9).to(device)
+    for m in dis.modules():
+        if isinstance(m, nn.Conv2d):
+            nn.init.normal_(m.weight, std=0.05)
+    shape = ops.PyramidShape(2, [(24, 40)])
+    feat = torch.randn(shape.rows, 256, device=device)
+    act = torch.softmax(torch.randn(shape.rows, 9, device=device), 1)
+    res = []
+    for flag in (True, False):
+        ops.GROUPED_CLS = ops.BATCHED = flag
+        try:
+            f = feat.clone().requires_grad_(True)
+            dis.zero_grad()
+            ls, lt = dis.forward_pair(f, act, shape, 1)
+            (ls + 2 * lt).backward()
+            res.append([ls.detach(), lt.detach(), f.grad] + [p.grad.clone() for p in dis.parameters()])
+        finally:
+            ops.GROUPED_CLS = ops.BATCHED = True
+    for a, b in zip(*res):
+        assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1e-6), (a.shape, (a - b).abs().max().item())

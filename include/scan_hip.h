@@ -356,6 +356,10 @@ int scan_gconv3x3_to1_dgrad(const float* dy, int32_t Ns, const scan_pyramid_t* d
                             const float* mask, float* dx, void* stream);
 int scan_gconv3x3_to1_wgrad(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G, int32_t Cg,
                             float* dw, int32_t accumulate, float* ws, void* stream);
+/* both gradients from one pass over x (relu_mask != 0: dx *= (x > 0)) */
+int scan_gconv3x3_to1_backward(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G, int32_t Cg,
+                               const float* w, int32_t relu_mask, float* dx, float* dw, int32_t accumulate, float* ws,
+                               void* stream);
 
 /* ---- input pipeline: the step in front of the path ----
  * scan_resize_bilinear_u8 replaces torchvision F.resize on a PIL image = PIL Image.resize(size, BILINEAR), as

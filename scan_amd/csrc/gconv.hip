@@ -21,9 +21,20 @@
 
 #define GC_G 128  // channels per group
 
-__device__ __forceinline__ float half_wave_sum(float v) {  // sum over the 32-lane half of a wave, result in every lane
-#pragma unroll
-  for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+// Sum over each 32-lane half of the wave on the DPP path (no LDS crossbar): quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror leave every lane of a 16-lane row with the row's sum; row_bcast15 then adds row 0 into row 1 and row 2 into
+// row 3.  The total is valid in the lanes with (lane & 16) != 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+  return v + __builtin_bit_cast(float, r);
+}
+__device__ __forceinline__ float half_wave_sum_hi(float v) {
+  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);  // row_mirror
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
   return v;
 }
 
@@ -34,6 +45,8 @@ __device__ __forceinline__ int64_t neighbour_row(const scan_pyramid_t& d, int64_
   return m + (int64_t)oy * d.w[rc.lvl] + ox;
 }
 
+#define GC_UNROLL 2  // pixels in flight per thread
+
 __global__ __launch_bounds__(256) void gconv_taps_kernel(const float* __restrict__ x, int64_t M, int G, int GC,
                                                          const float* __restrict__ w, float* __restrict__ T) {
   const int quads = GC >> 2;                  // channel quads per pixel (32 per group)
@@ -43,16 +56,26 @@ __global__ __launch_bounds__(256) void gconv_taps_kernel(const float* __restrict
   float4 wv[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(w + ((int64_t)g * 9 + t) * GC + 4 * cq);
-  for (int64_t q = (int64_t)blockIdx.x * slots + slot; q < M; q += (int64_t)gridDim.x * slots) {
-    const float4 h = *reinterpret_cast<const float4*>(x + q * GC + 4 * cq);
-    float mine = 0.f;
+  const int64_t stride = (int64_t)gridDim.x * slots;
+  for (int64_t q0 = (int64_t)blockIdx.x * slots + slot; q0 < M; q0 += GC_UNROLL * stride) {
+    float4 h[GC_UNROLL];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      float s = __fmaf_rn(h.x, wv[t].x, __fmaf_rn(h.y, wv[t].y, __fmaf_rn(h.z, wv[t].z, h.w * wv[t].w)));
-      s = half_wave_sum(s);
-      if (l32 == t) mine = s;
+    for (int u = 0; u < GC_UNROLL; ++u) {
+      const int64_t q = q0 + u * stride;
+      h[u] = q < M ? *reinterpret_cast<const float4*>(x + q * GC + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (l32 < 9) T[(q * G + g) * 9 + l32] = mine;
+#pragma unroll
+    for (int u = 0; u < GC_UNROLL; ++u) {
+      const int64_t q = q0 + u * stride;
+      float mine = 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float s = __fmaf_rn(h[u].x, wv[t].x, __fmaf_rn(h[u].y, wv[t].y, __fmaf_rn(h[u].z, wv[t].z, h[u].w * wv[t].w)));
+        s = half_wave_sum_hi(s);
+        if (l32 == 16 + t) mine = s;
+      }
+      if (q < M && l32 >= 16 && l32 < 25) T[(q * G + g) * 9 + (l32 - 16)] = mine;
+    }
   }
 }
 
@@ -77,71 +100,80 @@ __global__ __launch_bounds__(256) void gconv_gather_kernel(const float* __restri
   }
 }
 
-__global__ __launch_bounds__(256) void gconv_dgrad_kernel(const float* __restrict__ dy, int Ns, scan_pyramid_t d, int G,
-                                                          int GC, const float* __restrict__ w,
-                                                          const float* __restrict__ mask, float* __restrict__ dx) {
+// Backward in one pass over x: per input pixel q the nine dy[q - off(t)][g] values serve both the data gradient
+// (dx[q] = mask * sum_t dy_t * w[t]) and the weight gradient (acc[t] += dy_t * x[q]); x is read once.
+// slab[block][t][GC]: the block's partial of dw[g(c)][t][c].
+template <bool DO_DX, bool DO_DW>
+__global__ __launch_bounds__(256) void gconv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int Ns,
+                                                        scan_pyramid_t d, int G, int GC, const float* __restrict__ w,
+                                                        int relu_mask, float* __restrict__ dx, int64_t rows_per_block,
+                                                        float* __restrict__ slab) {
+  __shared__ float red[DO_DW ? 9 * 1024 : 4];
   const int64_t M = d.row_off[d.n_levels];
   const int quads = GC >> 2, slots = 256 / quads;
   const int cq = threadIdx.x % quads, slot = threadIdx.x / quads;
   const int g = cq >> 5;
-  float4 wv[9];
+  float4 wv[9], acc[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(w + ((int64_t)g * 9 + t) * GC + 4 * cq);
-  for (int64_t q = (int64_t)blockIdx.x * slots + slot; q < M; q += (int64_t)gridDim.x * slots) {
-    const RowCoord rc = decode_row(d, q);
-    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = 0; t < 9; ++t) {
+    wv[t] = DO_DX ? *reinterpret_cast<const float4*>(w + ((int64_t)g * 9 + t) * GC + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int64_t qb = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t qe = qb + rows_per_block < M ? qb + rows_per_block : M;
+  const bool need_x = DO_DW || relu_mask;
+  for (int64_t q0 = qb + slot; q0 < qe; q0 += GC_UNROLL * slots) {
+    float4 h[GC_UNROLL];
+    float gy[GC_UNROLL][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      // y[p] took h[p + off(t)] * w[t], so h[q] feeds y[q - off(t)]
-      const int64_t p = neighbour_row(d, q, rc, 1 - t / 3, 1 - t % 3);
-      if (p >= 0) {
-        const float gy = dy[p * Ns + g];
-        o.x = __fmaf_rn(gy, wv[t].x, o.x);
-        o.y = __fmaf_rn(gy, wv[t].y, o.y);
-        o.z = __fmaf_rn(gy, wv[t].z, o.z);
-        o.w = __fmaf_rn(gy, wv[t].w, o.w);
+    for (int u = 0; u < GC_UNROLL; ++u) {
+      const int64_t q = q0 + u * slots;
+      h[u] = (q < qe && need_x) ? *reinterpret_cast<const float4*>(x + q * GC + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (q < qe) {
+        const RowCoord rc = decode_row(d, q);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          // y[p] took x[p + off(t)] * w[t], so x[q] feeds y[q - off(t)]
+          const int64_t p = neighbour_row(d, q, rc, 1 - t / 3, 1 - t % 3);
+          gy[u][t] = p >= 0 ? dy[p * Ns + g] : 0.f;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) gy[u][t] = 0.f;
       }
     }
-    if (mask != nullptr) {
-      const float4 mk = *reinterpret_cast<const float4*>(mask + q * GC + 4 * cq);
-      o.x = mk.x > 0.f ? o.x : 0.f;
-      o.y = mk.y > 0.f ? o.y : 0.f;
-      o.z = mk.z > 0.f ? o.z : 0.f;
-      o.w = mk.w > 0.f ? o.w : 0.f;
-    }
-    *reinterpret_cast<float4*>(dx + q * GC + 4 * cq) = o;
-  }
-}
-
-// slab[block][t][GC]: the block's partial of dw[g(c)][t][c]
-__global__ __launch_bounds__(256) void gconv_wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                          int Ns, scan_pyramid_t d, int G, int GC, int64_t rows_per_block,
-                                                          float* __restrict__ slab) {
-  __shared__ float red[9 * 1024];
-  const int64_t M = d.row_off[d.n_levels];
-  const int quads = GC >> 2, slots = 256 / quads;
-  const int cq = threadIdx.x % quads, slot = threadIdx.x / quads;
-  const int g = cq >> 5;
-  float4 acc[9];
 #pragma unroll
-  for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  const int64_t q0 = (int64_t)blockIdx.x * rows_per_block;
-  const int64_t q1 = q0 + rows_per_block < M ? q0 + rows_per_block : M;
-  for (int64_t q = q0 + slot; q < q1; q += slots) {
-    const RowCoord rc = decode_row(d, q);
-    const float4 h = *reinterpret_cast<const float4*>(x + q * GC + 4 * cq);
+    for (int u = 0; u < GC_UNROLL; ++u) {
+      const int64_t q = q0 + u * slots;
+      if (DO_DW) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const int64_t p = neighbour_row(d, q, rc, 1 - t / 3, 1 - t % 3);
-      if (p >= 0) {
-        const float gy = dy[p * Ns + g];
-        acc[t].x = __fmaf_rn(gy, h.x, acc[t].x);
-        acc[t].y = __fmaf_rn(gy, h.y, acc[t].y);
-        acc[t].z = __fmaf_rn(gy, h.z, acc[t].z);
-        acc[t].w = __fmaf_rn(gy, h.w, acc[t].w);
+        for (int t = 0; t < 9; ++t) {
+          acc[t].x = __fmaf_rn(gy[u][t], h[u].x, acc[t].x);
+          acc[t].y = __fmaf_rn(gy[u][t], h[u].y, acc[t].y);
+          acc[t].z = __fmaf_rn(gy[u][t], h[u].z, acc[t].z);
+          acc[t].w = __fmaf_rn(gy[u][t], h[u].w, acc[t].w);
+        }
+      }
+      if (DO_DX && q < qe) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          o.x = __fmaf_rn(gy[u][t], wv[t].x, o.x);
+          o.y = __fmaf_rn(gy[u][t], wv[t].y, o.y);
+          o.z = __fmaf_rn(gy[u][t], wv[t].z, o.z);
+          o.w = __fmaf_rn(gy[u][t], wv[t].w, o.w);
+        }
+        if (relu_mask) {
+          o.x = h[u].x > 0.f ? o.x : 0.f;
+          o.y = h[u].y > 0.f ? o.y : 0.f;
+          o.z = h[u].z > 0.f ? o.z : 0.f;
+          o.w = h[u].w > 0.f ? o.w : 0.f;
+        }
+        *reinterpret_cast<float4*>(dx + q * GC + 4 * cq) = o;
       }
     }
   }
+  if (!DO_DW) return;
   float* out = slab + (int64_t)blockIdx.x * 9 * GC;
   if (slots == 1) {
 #pragma unroll
@@ -209,35 +241,58 @@ extern "C" int scan_gconv3x3_to1_forward(const float* x, const scan_pyramid_t* d
   return 0;
 }
 
-extern "C" int scan_gconv3x3_to1_dgrad(const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G, int32_t Cg,
-                                       const float* w, const float* mask, float* dx, void* stream) {
-  if (gconv_check(d, G, Cg, "gconv3x3_to1_dgrad")) return -1;
-  SCAN_CHECK_ARG(dy && w && dx && Ns >= G, "gconv3x3_to1_dgrad: bad arguments (Ns=%d)", Ns);
+static int gconv_backward(const float* x, const float* dy, int Ns, const scan_pyramid_t* d, int G, int Cg, const float* w,
+                          int relu_mask, float* dx, float* dw, int accumulate, float* ws, hipStream_t st,
+                          const char* who) {
+  if (gconv_check(d, G, Cg, who)) return -1;
+  SCAN_CHECK_ARG(dy && Ns >= G && (dx || dw), "%s: bad arguments (Ns=%d)", who, Ns);
+  SCAN_CHECK_ARG(!dx || w, "%s: the data gradient needs the weights", who);
+  SCAN_CHECK_ARG(!dw || (x && ws), "%s: the weight gradient needs x and a workspace", who);
+  SCAN_CHECK_ARG(!(dx && relu_mask) || x, "%s: the ReLU mask needs x", who);
   const int64_t M = d->row_off[d->n_levels];
   if (M == 0) return 0;
-  const int GC = G * Cg, slots = 256 / (GC / 4);
-  hipLaunchKernelGGL(gconv_dgrad_kernel, dim3(grid_for((M + slots - 1) / slots, 1)), dim3(256), 0, as_stream(stream), dy,
-                     Ns, *d, G, GC, w, mask, dx);
-  SCAN_LAUNCH_CHECK("gconv_dgrad");
-  return 0;
-}
-
-extern "C" int scan_gconv3x3_to1_wgrad(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G,
-                                       int32_t Cg, float* dw, int32_t accumulate, float* ws, void* stream) {
-  if (gconv_check(d, G, Cg, "gconv3x3_to1_wgrad")) return -1;
-  SCAN_CHECK_ARG(x && dy && dw && ws && Ns >= G, "gconv3x3_to1_wgrad: bad arguments (Ns=%d)", Ns);
-  const int64_t M = d->row_off[d->n_levels];
   const int GC = G * Cg;
-  hipStream_t st = as_stream(stream);
   int blocks = 1024;
   int64_t rpb = (M + blocks - 1) / blocks;
   if (rpb < 16) rpb = 16;  // small levels: fewer, fuller workgroups
   blocks = (int)((M + rpb - 1) / rpb);
-  if (blocks < 1) blocks = 1;
-  hipLaunchKernelGGL(gconv_wgrad_kernel, dim3(blocks), dim3(256), 0, st, x, dy, Ns, *d, G, GC, rpb, ws);
-  SCAN_LAUNCH_CHECK("gconv_wgrad");
-  hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((9 * GC + 255) / 256), dim3(256), 0, st, ws, blocks, G, GC, dw,
-                     accumulate);
-  SCAN_LAUNCH_CHECK("gconv_wgrad_reduce");
+  if (dx && dw)
+    hipLaunchKernelGGL((gconv_bwd_kernel<true, true>), dim3(blocks), dim3(256), 0, st, x, dy, Ns, *d, G, GC, w, relu_mask, dx,
+                       rpb, ws);
+  else if (dx)
+    hipLaunchKernelGGL((gconv_bwd_kernel<true, false>), dim3(blocks), dim3(256), 0, st, x, dy, Ns, *d, G, GC, w, relu_mask, dx,
+                       rpb, ws);
+  else
+    hipLaunchKernelGGL((gconv_bwd_kernel<false, true>), dim3(blocks), dim3(256), 0, st, x, dy, Ns, *d, G, GC, w, 0, dx, rpb,
+                       ws);
+  SCAN_LAUNCH_CHECK(who);
+  if (dw) {
+    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((9 * GC + 255) / 256), dim3(256), 0, st, ws, blocks, G, GC, dw,
+                       accumulate);
+    SCAN_LAUNCH_CHECK("gconv_wgrad_reduce");
+  }
   return 0;
+}
+
+extern "C" int scan_gconv3x3_to1_dgrad(const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G, int32_t Cg,
+                                       const float* w, const float* mask, float* dx, void* stream) {
+  SCAN_CHECK_ARG(dx, "gconv3x3_to1_dgrad: null output");
+  return gconv_backward(mask, dy, Ns, d, G, Cg, w, mask != nullptr, dx, nullptr, 0, nullptr, as_stream(stream),
+                        "gconv3x3_to1_dgrad");
+}
+
+extern "C" int scan_gconv3x3_to1_wgrad(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G,
+                                       int32_t Cg, float* dw, int32_t accumulate, float* ws, void* stream) {
+  SCAN_CHECK_ARG(dw, "gconv3x3_to1_wgrad: null output");
+  return gconv_backward(x, dy, Ns, d, G, Cg, nullptr, 0, nullptr, dw, accumulate, ws, as_stream(stream),
+                        "gconv3x3_to1_wgrad");
+}
+
+// both gradients from ONE pass over x (relu_mask != 0: dx is multiplied by (x > 0), the producer's deferred ReLU)
+extern "C" int scan_gconv3x3_to1_backward(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G,
+                                          int32_t Cg, const float* w, int32_t relu_mask, float* dx, float* dw,
+                                          int32_t accumulate, float* ws, void* stream) {
+  SCAN_CHECK_ARG(x && dx && dw, "gconv3x3_to1_backward: null pointer");
+  return gconv_backward(x, dy, Ns, d, G, Cg, w, relu_mask, dx, dw, accumulate, ws, as_stream(stream),
+                        "gconv3x3_to1_backward");
 }

@@ -1064,16 +1064,21 @@ class _GroupedConvTo1(torch.autograd.Function):
         shape, G, ns, mask_dx, has_bias = ctx.cfg
         dy = dy.contiguous()
         st = _stream()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            dx = torch.empty_like(x)
-            call("scan_gconv3x3_to1_dgrad", _ptr(dy), ns, shape.ref(), G, 128, _ptr(w), _ptr(x if mask_dx else None),
-                 _ptr(dx), st)
+        dx = dw = db = dwp = None
         if ctx.needs_input_grad[1]:
             dwp = x.new_zeros((G, 9, G * 128))  # off-diagonal blocks: exact zeros (they meet a zero in the adjoint)
             ws = x.new_empty((query("scan_gconv3x3_to1_ws_floats", shape.ref(), G, 128),))
-            call("scan_gconv3x3_to1_wgrad", _ptr(x), _ptr(dy), ns, shape.ref(), G, 128, _ptr(dwp), 0, _ptr(ws), st)
             dw = dwp.view(G, 3, 3, G * 128).permute(0, 3, 1, 2)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+        if dx is not None and dwp is not None:  # one pass over x for both
+            call("scan_gconv3x3_to1_backward", _ptr(x), _ptr(dy), ns, shape.ref(), G, 128, _ptr(w), int(mask_dx), _ptr(dx),
+                 _ptr(dwp), 0, _ptr(ws), st)
+        elif dx is not None:
+            call("scan_gconv3x3_to1_dgrad", _ptr(dy), ns, shape.ref(), G, 128, _ptr(w), _ptr(x if mask_dx else None),
+                 _ptr(dx), st)
+        elif dwp is not None:
+            call("scan_gconv3x3_to1_wgrad", _ptr(x), _ptr(dy), ns, shape.ref(), G, 128, _ptr(dwp), 0, _ptr(ws), st)
         if has_bias and ctx.needs_input_grad[2]:
             M = dy.shape[0]
             cws = x.new_empty((query("scan_colsum_ws_floats", M, G),))

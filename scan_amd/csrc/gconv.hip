@@ -200,16 +200,32 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __restrict__ slab, int blocks, int G, int GC,
+// slab [blocks][n] -> partial [parts][n]: part p sums its contiguous run of blocks in order (grid.y = parts)
+__global__ __launch_bounds__(256) void gconv_slab_partial_kernel(const float* __restrict__ slab, int blocks, int n,
+                                                                 int per_part, float* __restrict__ partial) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b0 = blockIdx.y * per_part;
+  const int b1 = b0 + per_part < blocks ? b0 + per_part : blocks;
+  float s = 0.f;
+#pragma unroll 8
+  for (int b = b0; b < b1; ++b) s += slab[(int64_t)b * n + i];
+  partial[(int64_t)blockIdx.y * n + i] = s;
+}
+
+__global__ __launch_bounds__(256) void gconv_wgrad_reduce_kernel(const float* __restrict__ partial, int parts, int G, int GC,
                                                                  float* __restrict__ dw, int accumulate) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // over 9 * GC
   if (i >= 9 * GC) return;
   const int t = i / GC, c = i - t * GC;
   float s = 0.f;
-  for (int b = 0; b < blocks; ++b) s += slab[(int64_t)b * 9 * GC + i];
+  for (int b = 0; b < parts; ++b) s += partial[(int64_t)b * 9 * GC + i];
   float* dst = dw + ((int64_t)(c / GC_G) * 9 + t) * GC + c;
   *dst = accumulate ? *dst + s : s;
 }
+
+#define GC_MAX_BLOCKS 1024
+#define GC_PARTS 32
 
 static int gconv_check(const scan_pyramid_t* d, int G, int Cg, const char* who) {
   SCAN_CHECK_ARG(d && d->n_levels >= 1 && d->n_levels <= SCAN_MAX_LEVELS, "%s: bad pyramid", who);
@@ -222,7 +238,7 @@ extern "C" int64_t scan_gconv3x3_to1_ws_floats(const scan_pyramid_t* d, int32_t 
   if (!d) return -1;
   const int64_t M = d->row_off[d->n_levels];
   const int64_t taps = M * G * 9;                    // forward
-  const int64_t slab = (int64_t)1024 * 9 * G * Cg;   // wgrad partials (at most 1024 workgroups)
+  const int64_t slab = (int64_t)(GC_MAX_BLOCKS + GC_PARTS) * 9 * G * Cg;  // wgrad partials of <= 1024 workgroups + 32 sums
   return taps > slab ? taps : slab;
 }
 
@@ -252,7 +268,7 @@ static int gconv_backward(const float* x, const float* dy, int Ns, const scan_py
   const int64_t M = d->row_off[d->n_levels];
   if (M == 0) return 0;
   const int GC = G * Cg;
-  int blocks = 1024;
+  int blocks = GC_MAX_BLOCKS;
   int64_t rpb = (M + blocks - 1) / blocks;
   if (rpb < 16) rpb = 16;  // small levels: fewer, fuller workgroups
   blocks = (int)((M + rpb - 1) / rpb);
@@ -267,7 +283,13 @@ static int gconv_backward(const float* x, const float* dy, int Ns, const scan_py
                        ws);
   SCAN_LAUNCH_CHECK(who);
   if (dw) {
-    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((9 * GC + 255) / 256), dim3(256), 0, st, ws, blocks, G, GC, dw,
+    // fixed-order two-level sum of the per-workgroup partials: 32 runs of consecutive blocks, then the 32 run sums
+    const int n = 9 * GC, per = (blocks + GC_PARTS - 1) / GC_PARTS, parts = (blocks + per - 1) / per;
+    float* partial = ws + (int64_t)GC_MAX_BLOCKS * n;
+    hipLaunchKernelGGL(gconv_slab_partial_kernel, dim3((n + 255) / 256, parts), dim3(256), 0, st, ws, blocks, n, per,
+                       partial);
+    SCAN_LAUNCH_CHECK("gconv_slab_partial");
+    hipLaunchKernelGGL(gconv_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, partial, parts, G, GC, dw,
                        accumulate);
     SCAN_LAUNCH_CHECK("gconv_wgrad_reduce");
   }

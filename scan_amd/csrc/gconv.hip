@@ -45,7 +45,8 @@ __device__ __forceinline__ int64_t neighbour_row(const scan_pyramid_t& d, int64_
   return m + (int64_t)oy * d.w[rc.lvl] + ox;
 }
 
-#define GC_UNROLL 2  // pixels in flight per thread
+#define GC_UNROLL 2   // pixels in flight per thread, backward (36 + 36 + 26 live registers per lane)
+#define GC_UNROLL_F 4 // forward: 4 KiB per wave in flight
 
 __global__ __launch_bounds__(256) void gconv_taps_kernel(const float* __restrict__ x, int64_t M, int G, int GC,
                                                          const float* __restrict__ w, float* __restrict__ T) {
@@ -57,15 +58,15 @@ __global__ __launch_bounds__(256) void gconv_taps_kernel(const float* __restrict
 #pragma unroll
   for (int t = 0; t < 9; ++t) wv[t] = *reinterpret_cast<const float4*>(w + ((int64_t)g * 9 + t) * GC + 4 * cq);
   const int64_t stride = (int64_t)gridDim.x * slots;
-  for (int64_t q0 = (int64_t)blockIdx.x * slots + slot; q0 < M; q0 += GC_UNROLL * stride) {
-    float4 h[GC_UNROLL];
+  for (int64_t q0 = (int64_t)blockIdx.x * slots + slot; q0 < M; q0 += GC_UNROLL_F * stride) {
+    float4 h[GC_UNROLL_F];
 #pragma unroll
-    for (int u = 0; u < GC_UNROLL; ++u) {
+    for (int u = 0; u < GC_UNROLL_F; ++u) {
       const int64_t q = q0 + u * stride;
       h[u] = q < M ? *reinterpret_cast<const float4*>(x + q * GC + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int u = 0; u < GC_UNROLL; ++u) {
+    for (int u = 0; u < GC_UNROLL_F; ++u) {
       const int64_t q = q0 + u * stride;
       float mine = 0.f;
 #pragma unroll

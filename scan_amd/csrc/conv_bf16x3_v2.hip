@@ -381,6 +381,9 @@ int g_scan_conv_wg1024 = 1;
 // three workgroups per CU).  Default 0: measured +-1 % on every layer (profiles/r02_conv_instances.txt) -- the barrier
 // count is not what bounds these kernels (as MI355X_MICROARCH.md "Barrier count is not the lever" predicts).
 int g_scan_conv_tpb3 = 0;
+// scan_tune "conv_bn64_th16": the <= 64-channel 3x3 instance on 16x16-pixel tiles (4 waves x 64 px x 64 ch: 48 MFMAs per
+// wave and barrier instead of 24) instead of 8x16 -- 1: single-level pyramids with H, W multiples of 16, 0: never.
+int g_scan_conv_bn64_th16 = 0;
 static int v2_instance(const scan_pyramid_t* od, int32_t Nout) {
   if (Nout <= 64) return 64;
   TileTab2 tt;
@@ -399,7 +402,9 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
   const __bf16* l = reinterpret_cast<const __bf16*>(wl);
   switch (v2_instance(d, Nout)) {
     case 64:
-      if (g_scan_conv_tpb3 & 2)
+      if (g_scan_conv_bn64_th16 && d->n_levels == 1 && d->h[0] % 16 == 0 && d->w[0] % 16 == 0)
+        launch_v2<64, 16, 256, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else if (g_scan_conv_tpb3 & 2)
         launch_v2<64, 8, 256, 3, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       else
         launch_v2<64, 8, 256, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);

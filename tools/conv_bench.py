@@ -24,6 +24,8 @@ SHAPES = [
     ("conv4_x 512->512 @128x256, 4 frames", 4, [(128, 256)], 512, 512),
     ("conv5_x 512->512 @64x128, 4 frames", 4, [(64, 128)], 512, 512),
     ("conv2_2 128->128 @512x1024, 4 frames", 4, [(512, 1024)], 128, 128),
+    ("conv1_2 64->64 @1024x2048, 4 frames", 4, [(1024, 2048)], 64, 64),
+    ("conv2_1 64->128 @512x1024, 4 frames", 4, [(512, 1024)], 64, 128),
     ("dis P3 264->1024, 4 frames", 4, [(128, 256)], 264, 1024),
     ("head_out 268->256 pyramid, 4 frames", 4, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)], 268, 256),
 ]

@@ -54,6 +54,8 @@ int scan_abi_version(void);
  *                 1: for the 16x16x32 kernel (measured slower); 0: 8 waves.
  *   "conv_wg1024" 1 (default): the 128- / 256-channel forward / dgrad instances run 16 waves per workgroup; 0: 8 waves;
  *                 2: 16 waves only for the 256-channel tile on multi-level pyramids.  Same results bit for bit.
+ *   "conv_bn64_th16" 1 (default): convs with <= 64 output channels on single-level pyramids whose sizes are multiples of
+ *                 16 use 16x16-pixel tiles; 0: 8x16.  Same results bit for bit.
  *   "conv_tpb3"   bit 0 / bit 1: the 128- / 64-channel instance stages three taps per barrier (default 0; same
  *                 results bit for bit). */
 int scan_tune(const char* key, int value);

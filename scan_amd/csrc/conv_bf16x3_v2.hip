@@ -382,8 +382,9 @@ int g_scan_conv_wg1024 = 1;
 // count is not what bounds these kernels (as MI355X_MICROARCH.md "Barrier count is not the lever" predicts).
 int g_scan_conv_tpb3 = 0;
 // scan_tune "conv_bn64_th16": the <= 64-channel 3x3 instance on 16x16-pixel tiles (4 waves x 64 px x 64 ch: 48 MFMAs per
-// wave and barrier instead of 24) instead of 8x16 -- 1: single-level pyramids with H, W multiples of 16, 0: never.
-int g_scan_conv_bn64_th16 = 0;
+// wave and barrier instead of 24) instead of 8x16 -- 1 (default): single-level pyramids with H, W multiples of 16, 0:
+// never.  conv1_2 (64 -> 64 at 1024x2048, 4 frames) 2047 -> 1940 us, conv2_1 990 -> 981 us (tools/conv_bench.py).
+int g_scan_conv_bn64_th16 = 1;
 static int v2_instance(const scan_pyramid_t* od, int32_t Nout) {
   if (Nout <= 64) return 64;
   TileTab2 tt;

@@ -441,7 +441,8 @@ class Trainer:
         ops.begin_weight_epoch(self._split_plan)
         fcos_mod.reset_target_plan()
         for m in model.values():
-            m.train()
+            if not m.training:  # walking every sub-module costs ~0.1 ms of host time per model
+                m.train()
         self.grad_arena.zero_()
         B = len(il_s.image_sizes)
         inputs_ready = torch.cuda.Event()
@@ -526,7 +527,8 @@ class Trainer:
         ops.begin_weight_epoch(self._split_plan)  # parameters change once per iteration: reuse their bf16 planes within it
         fcos_mod.reset_target_plan()
         for m in model.values():
-            m.train()
+            if not m.training:  # walking every sub-module costs ~0.1 ms of host time per model
+                m.train()
         self.grad_arena.zero_()
         out = {}
         # (1) generator on source

@@ -217,16 +217,20 @@ class GRAPHModule(nn.Module):
             buf = torch.cat([pb * ex, ex], 1)
             dist.all_reduce(buf)
             pb = buf[:, :-1] / buf[:, -1:].clamp(min=1)
-        exist = pb.sum(-1).bool()
+        # The reference indexes with the boolean mask `exist` (P[exist, :, t] = ...), which costs a host<->device
+        # synchronisation per use (nonzero) in the middle of the forward pass -- the host then cannot enqueue ahead and
+        # the GPU idles through the small-kernel tier that follows.  Row-wise arithmetic on ALL classes and a masked
+        # select give the same rows: cosine_similarity works row by row, absent classes (pb = 0) keep their old value.
+        exist = pb.sum(-1).bool()[:, None]
         P = self.prototype
+        slot = it - 1 if it == self.prototype_iter else it
+        cur = P[:, :, slot]
+        m = F.cosine_similarity(cur, pb).unsqueeze(1)
+        upd = torch.where(exist, cur * m + pb * (1 - m), cur)
         if it == self.prototype_iter:
-            m = F.cosine_similarity(P[exist, :, it - 1], pb[exist]).unsqueeze(1)
             for i in range(it - 1):
                 P[:, :, i] = P[:, :, i + 1]
-            P[exist, :, it - 1] = P[exist, :, it - 1] * m + pb[exist] * (1 - m)
-        else:
-            m = F.cosine_similarity(P[exist, :, it], pb[exist]).unsqueeze(1)
-            P[exist, :, it] = P[exist, :, it] * m + pb[exist] * (1 - m)
+        P[:, :, slot] = upd
 
     def get_conded_weight(self):
         """reference condgraph.py:313-319: paradigm [K,256,T] -> RNN -> Conv2d(512,256,(T,1)) -> [K,256]."""

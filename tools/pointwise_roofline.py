@@ -156,6 +156,30 @@ def measure(dev, sizes=(M_CFG5, M_BIG), reps=10, K=9, only=None):
                          P(dxg), P(dg_), P(db_), 0, P(wsg), st()))
         del feat, dfe, dyg, dxg
         torch.cuda.empty_cache()
+        # ---- CKA class branches' output conv (a15): x [Mc, 8 x 128] -> one channel per class, 8 images of one level
+        Mc_target = min(M, 1 << 21)  # 8.6 GB of input at 2^21 rows: far beyond the last-level cache already
+        hw = Mc_target // n_img
+        h = 1
+        while h * h * 2 < hw:
+            h += 1
+        wd_ = hw // h
+        Mc = n_img * h * wd_
+        shape = ops.PyramidShape(n_img, [(h, wd_)])
+        xc = torch.relu(torch.randn((Mc, 1024), device=dev, generator=g))
+        wc = torch.randn((8, 9, 1024), device=dev, generator=g) * 0.03
+        bc = torch.randn(8, device=dev, generator=g)
+        yc = torch.empty((Mc, 8), device=dev)
+        wsc = torch.empty((query("scan_gconv3x3_to1_ws_floats", shape.ref(), 8, 128),), device=dev)
+        rec("gconv3x3_to1_fwd", Mc, Mc * (4096 + 32 + 2 * 288), "M(4096+32+576): x read, y written, 72 tap products written and read",
+            lambda: call("scan_gconv3x3_to1_forward", P(xc), shape.ref(), 8, 128, P(wc), P(bc), P(yc), 8, P(wsc), st()))
+        dyc = torch.randn((Mc, 8), device=dev, generator=g)
+        dxc = torch.empty_like(xc)
+        dwc = torch.zeros_like(wc)
+        rec("gconv3x3_to1_bwd", Mc, Mc * (8192 + 32), "M(8192+32): x and dy read, dx written (dw: 36 KB per workgroup)",
+            lambda: call("scan_gconv3x3_to1_backward", P(xc), P(dyc), 8, shape.ref(), 8, 128, P(wc), 1, P(dxc), P(dwc), 0,
+                         P(wsc), st()))
+        del xc, dxc, yc, dyc, wsc
+        torch.cuda.empty_cache()
     return out
 
 

@@ -20,6 +20,9 @@ GROUPS = [  # (substring of the kernel name, group key); conv keys = the symbols
     ("conv_bf16x3_v2_kernelILi128ELi16ELi1024ELi3", "conv_bf16x3_v2_kernel<128,16,1024,3>"),
     ("conv_bf16x3_v2_kernelILi128ELi16ELi512ELi3", "conv_bf16x3_v2_kernel<128,16,512,3>"),
     ("conv_bf16x3_v2_kernelILi64ELi8ELi256ELi3", "conv_bf16x3_v2_kernel<64,8,256,3>"),
+    ("conv_bf16x3_v2_kernelILi64ELi16ELi256ELi3", "conv_bf16x3_v2_kernel<64,16,256,3>"),
+    ("gconv_taps_kernel", "gconv_taps"), ("gconv_gather_kernel", "gconv_gather"), ("gconv_bwd_kernel", "gconv_bwd"),
+    ("weight_split_batched_kernel", "weight_split_batched"), ("sgd_multi_kernel", "sgd_multi"),
     ("conv_bf16x3_v2_kernelILi128ELi16ELi512ELi1", "conv_bf16x3_v2_kernel<128,16,512,1>"),
     ("conv_bf16x3_v2_kernelILi64ELi8ELi256ELi1", "conv_bf16x3_v2_kernel<64,8,256,1>"),
     ("conv3x3_bf16x3_kernelILi128ELi16ELi512ELi3", "conv3x3_bf16x3_fwd_dgrad_bn128"),

@@ -121,23 +121,36 @@ __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __re
       for (int r = 0; r < 16; ++r) {
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int64_t i = i0 + (wm * 2 + tm) * 32 + rr;
-        bool pred = false;
-        if (i < n && j < n) {
+        const bool valid = i < n && j < n;
+        double d2 = 0.0;
+        bool inband = false;
+        if (valid) {
           const double si = sq[i];
-          double d2 = si + sj - 2.0 * (double)acc[tm][tn][r];
+          d2 = si + sj - 2.0 * (double)acc[tm][tn][r];
           // worst-case fp32 accumulation error of the 256-term dot product: (K - 1) 2^-24 sum |a_k b_k|
           // <= 1.53e-5 (si + sj) / 2, doubled by the factor 2 in front of it
           const double band = 1.6e-5 * (si + sj) + 1e-9;
-          if (fabs(d2 - eps2) <= band) {
-            double e = 0.0;
-            for (int k = 0; k < D; ++k) {
-              const double df = (double)p[i * D + k] - (double)p[j * D + k];
-              e += df * df;
-            }
-            d2 = e;
-          }
-          pred = d2 <= eps2;
+          inband = fabs(d2 - eps2) <= band;
         }
+        // pairs inside the rounding band are decided in fp64 from the points themselves -- by the WHOLE wave, one
+        // pair at a time (coalesced reads of both rows, butterfly sum): a lane looping over D on its own while 63
+        // others wait made dense point sets (many pairs near eps) ~100x slower than the GEMM itself
+        unsigned long long todo = __ballot(inband);
+        while (todo) {
+          const int src = __ffsll((long long)todo) - 1;
+          todo &= todo - 1;
+          const int64_t ii = (int64_t)__shfl((int)(i - i0), src, 64) + i0;
+          const int64_t jj = (int64_t)__shfl((int)(j - j0), src, 64) + j0;
+          double e = 0.0;
+          for (int k = lane; k < D; k += 64) {
+            const double df = (double)p[ii * D + k] - (double)p[jj * D + k];
+            e += df * df;
+          }
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
+          if (lane == src) d2 = e;
+        }
+        const bool pred = valid && d2 <= eps2;
         colbits |= pred ? (1u << rr) : 0u;
         const unsigned long long m = __ballot(pred);
         // lanes 0..31 hold row i(lh = 0), lanes 32..63 row i + 4

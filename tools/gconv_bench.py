@@ -1,3 +1,8 @@
+"""Class-branch output conv of the CKA discriminators: grouped kernels (ops.gconv3x3_to1) vs the dense conv over the
+block-diagonal stacked weight, forward and backward, at the P3 / P4 / P6 sizes of the bench workload (4 frames).
+
+    python tools/gconv_bench.py
+"""
 import sys, os, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from scan_amd import ops

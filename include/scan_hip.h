@@ -56,6 +56,8 @@ int scan_abi_version(void);
  *                 2: 16 waves only for the 256-channel tile on multi-level pyramids.  Same results bit for bit.
  *   "conv_bn64_th16" 1 (default): convs with <= 64 output channels on single-level pyramids whose sizes are multiples of
  *                 16 use 16x16-pixel tiles; 0: 8x16.  Same results bit for bit.
+ *   "gconv_mfma"  1 (default): the grouped class-branch conv's tap products and data gradient run on the fp32 matrix
+ *                 cores; 0: on fp32 FMAs (same products, different summation order).
  *   "conv_tpb3"   bit 0 / bit 1: the 128- / 64-channel instance stages three taps per barrier (default 0; same
  *                 results bit for bit). */
 int scan_tune(const char* key, int value);
@@ -358,10 +360,18 @@ int scan_gconv3x3_to1_dgrad(const float* dy, int32_t Ns, const scan_pyramid_t* d
                             const float* mask, float* dx, void* stream);
 int scan_gconv3x3_to1_wgrad(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G, int32_t Cg,
                             float* dw, int32_t accumulate, float* ws, void* stream);
-/* both gradients from one pass over x (relu_mask != 0: dx *= (x > 0)) */
+/* both gradients (relu_mask != 0: dx *= (x > 0)) */
 int scan_gconv3x3_to1_backward(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G, int32_t Cg,
                                const float* w, int32_t relu_mask, float* dx, float* dw, int32_t accumulate, float* ws,
                                void* stream);
+/* forward that also leaves the ReLU mask of x as bits (relu_bits: M * G * 4 uint32; bit 4 j + e of word
+ * [(row * G + g) * 4 + q] = x[row][g * 128 + 16 j + 4 q + e] > 0), and the backward that masks dx with them instead of
+ * re-reading x for the mask. */
+int scan_gconv3x3_to1_forward_bits(const float* x, const scan_pyramid_t* d, int32_t G, int32_t Cg, const float* w,
+                                   const float* bias, float* y, int32_t Ns, float* ws, uint32_t* relu_bits, void* stream);
+int scan_gconv3x3_to1_backward_bits(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G,
+                                    int32_t Cg, const float* w, const uint32_t* relu_bits, float* dx, float* dw,
+                                    int32_t accumulate, float* ws, void* stream);
 
 /* ---- input pipeline: the step in front of the path ----
  * scan_resize_bilinear_u8 replaces torchvision F.resize on a PIL image = PIL Image.resize(size, BILINEAR), as

@@ -115,6 +115,9 @@ SIGNATURES = {
     "scan_gconv3x3_to1_wgrad": (ctypes.c_int, [c_vp, c_vp, c_i32, _PD, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "scan_gconv3x3_to1_backward": (ctypes.c_int, [c_vp, c_vp, c_i32, _PD, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp,
                                                   c_vp]),
+    "scan_gconv3x3_to1_forward_bits": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
+    "scan_gconv3x3_to1_backward_bits": (ctypes.c_int, [c_vp, c_vp, c_i32, _PD, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32,
+                                                       c_vp, c_vp]),
     "scan_resize_bilinear_u8": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp,
                                                c_i32, c_vp]),
     "scan_normalize_image_u8": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, ctypes.POINTER(c_f32),

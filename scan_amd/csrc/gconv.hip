@@ -201,6 +201,129 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float* __restrict_
   }
 }
 
+// ---- matrix-core versions (v_mfma_f32_16x16x4_f32, exact fp32 products like the VALU kernels) -----------------------
+// Forward taps as a GEMM per (16 consecutive pixels, group): [16 px x 128 ch] . [128 ch x 9 taps] -- the layout of the
+// dynamic-conv forward kernel: a lane holds eight float4 of ITS pixel row (channels 16 j + 4 q .. + 3), which are four
+// consecutive k-steps each, so the 128-long dot products need no cross-lane sums at all and a wave keeps 8 KiB of loads
+// in flight.  relu_bits (optional): bit 4 j + e of word [(row * G + g) * 4 + q] = (x[row][g * 128 + 16 j + 4 q + e] > 0),
+// the producer's ReLU mask for the backward pass (1/32 of re-reading x).
+typedef float f32x4g __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(256) void gconv_taps_mfma_kernel(const float* __restrict__ x, int64_t M, int G, int GC,
+                                                              const float* __restrict__ w, float* __restrict__ T,
+                                                              uint32_t* __restrict__ relu_bits) {
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 15, q = lane >> 4;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;  // a multiple of G (grid sizes are multiples of 2)
+  const int g = (int)(wave_id % G);
+  float4 bw[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    bw[j] = col < 9 ? *reinterpret_cast<const float4*>(w + ((int64_t)g * 9 + col) * GC + g * GC_G + 16 * j + 4 * q)
+                    : make_float4(0.f, 0.f, 0.f, 0.f);
+  const int64_t groups = (M + 15) / 16;
+  for (int64_t gidx = wave_id / G; gidx < groups; gidx += n_waves / G) {
+    const int64_t row = gidx * 16 + col;
+    float4 av[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      av[j] = row < M ? *reinterpret_cast<const float4*>(x + row * GC + g * GC_G + 16 * j + 4 * q)
+                      : make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4g acc = {0.f, 0.f, 0.f, 0.f};
+    uint32_t bits = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].x, bw[j].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].y, bw[j].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].z, bw[j].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j].w, bw[j].w, acc, 0, 0, 0);
+      bits |= (av[j].x > 0.f ? 1u : 0u) << (4 * j) | (av[j].y > 0.f ? 2u : 0u) << (4 * j) |
+              (av[j].z > 0.f ? 4u : 0u) << (4 * j) | (av[j].w > 0.f ? 8u : 0u) << (4 * j);
+    }
+    if (relu_bits != nullptr && row < M) relu_bits[(row * G + g) * 4 + q] = bits;
+    // C/D map (16x16): column = lane & 15 = tap, row = 4 * (lane >> 4) + reg = pixel of the group
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t orow = gidx * 16 + 4 * q + r;
+      if (col < 9 && orow < M) T[(orow * G + g) * 9 + col] = acc[r];
+    }
+  }
+}
+
+// Data gradient as a GEMM per (16 consecutive pixels, group): dx^T [128 ch x 16 px] = w^T [128 ch x 9 taps] . gy [9 x 16]
+// with gy[t][px] = dy[px - off(t)][g] gathered by the lanes (three per lane).  A lane ends up with four consecutive
+// channels of its pixel per 16-channel tile -- the float4 layout of the forward loads, so the ReLU bits of the forward
+// (or x itself) mask the result in place.
+__global__ __launch_bounds__(256) void gconv_dx_mfma_kernel(const float* __restrict__ dy, int Ns, scan_pyramid_t d, int G,
+                                                            int GC, const float* __restrict__ w,
+                                                            const float* __restrict__ xmask,
+                                                            const uint32_t* __restrict__ relu_bits,
+                                                            float* __restrict__ dx) {
+  const int64_t M = d.row_off[d.n_levels];
+  const int lane = threadIdx.x & 63;
+  const int col = lane & 15, q = lane >> 4;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  const int g = (int)(wave_id % G);
+  // A operand: row = channel `col` of tile, k = tap 4 s + q
+  float aw[8][3];
+#pragma unroll
+  for (int tile = 0; tile < 8; ++tile)
+#pragma unroll
+    for (int s_ = 0; s_ < 3; ++s_) {
+      const int t = 4 * s_ + q;
+      aw[tile][s_] = t < 9 ? w[((int64_t)g * 9 + t) * GC + g * GC_G + 16 * tile + col] : 0.f;
+    }
+  const int64_t groups = (M + 15) / 16;
+  for (int64_t gidx = wave_id / G; gidx < groups; gidx += n_waves / G) {
+    const int64_t row = gidx * 16 + col;  // B operand / output: this lane's pixel
+    float gy[3] = {0.f, 0.f, 0.f};
+    if (row < M) {
+      const RowCoord rc = decode_row(d, row);
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const int t = 4 * s_ + q;
+        if (t < 9) {
+          // y[p] took x[p + off(t)] * w[t], so x[row] feeds y[row - off(t)]
+          const int64_t p = neighbour_row(d, row, rc, 1 - t / 3, 1 - t % 3);
+          if (p >= 0) gy[s_] = dy[p * Ns + g];
+        }
+      }
+    }
+    uint32_t bits = 0xffffffffu;
+    float4 mk[8];
+    if (relu_bits != nullptr) {
+      if (row < M) bits = relu_bits[(row * G + g) * 4 + q];
+    } else if (xmask != nullptr) {
+#pragma unroll
+      for (int tile = 0; tile < 8; ++tile)
+        mk[tile] = row < M ? *reinterpret_cast<const float4*>(xmask + row * GC + g * GC_G + 16 * tile + 4 * q)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int tile = 0; tile < 8; ++tile) {
+      f32x4g acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[tile][s_], gy[s_], acc, 0, 0, 0);
+      // C/D map: column = lane & 15 = pixel, row = 4 * (lane >> 4) + reg = channel inside the tile
+      float4 o = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      if (relu_bits != nullptr) {
+        o.x = (bits >> (4 * tile + 0)) & 1u ? o.x : 0.f;
+        o.y = (bits >> (4 * tile + 1)) & 1u ? o.y : 0.f;
+        o.z = (bits >> (4 * tile + 2)) & 1u ? o.z : 0.f;
+        o.w = (bits >> (4 * tile + 3)) & 1u ? o.w : 0.f;
+      } else if (xmask != nullptr) {
+        o.x = mk[tile].x > 0.f ? o.x : 0.f;
+        o.y = mk[tile].y > 0.f ? o.y : 0.f;
+        o.z = mk[tile].z > 0.f ? o.z : 0.f;
+        o.w = mk[tile].w > 0.f ? o.w : 0.f;
+      }
+      if (row < M) *reinterpret_cast<float4*>(dx + row * GC + g * GC_G + 16 * tile + 4 * q) = o;
+    }
+  }
+}
+
 // slab [blocks][n] -> partial [parts][n]: part p sums its contiguous run of blocks in order (grid.y = parts)
 __global__ __launch_bounds__(256) void gconv_slab_partial_kernel(const float* __restrict__ slab, int blocks, int n,
                                                                  int per_part, float* __restrict__ partial) {
@@ -243,29 +366,57 @@ extern "C" int64_t scan_gconv3x3_to1_ws_floats(const scan_pyramid_t* d, int32_t 
   return taps > slab ? taps : slab;
 }
 
-extern "C" int scan_gconv3x3_to1_forward(const float* x, const scan_pyramid_t* d, int32_t G, int32_t Cg, const float* w,
-                                         const float* bias, float* y, int32_t Ns, float* ws, void* stream) {
+// scan_tune "gconv_mfma": 1 (default) = tap products and data gradient on v_mfma_f32_16x16x4_f32; 0 = the fp32 FMA
+// kernels (DPP half-wave sums forward, fused dx + dw pass backward).  Same products, different summation order.
+int g_scan_gconv_mfma = 1;
+
+static int gconv_wave_grid(int64_t M, int G) {
+  int64_t tasks = ((M + 15) / 16) * G;  // (16-pixel group, channel group) pairs, one per wave iteration
+  int64_t blocks = (tasks + 3) / 4;
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 2) blocks = 2;
+  return (int)((blocks + 1) / 2 * 2);   // even: 4 waves per block -> the wave count is a multiple of G <= 8
+}
+
+static int gconv_forward(const float* x, const scan_pyramid_t* d, int G, int Cg, const float* w, const float* bias, float* y,
+                         int Ns, float* ws, uint32_t* relu_bits, hipStream_t st) {
   if (gconv_check(d, G, Cg, "gconv3x3_to1_forward")) return -1;
   SCAN_CHECK_ARG(x && w && y && ws && Ns >= G, "gconv3x3_to1_forward: bad arguments (Ns=%d)", Ns);
   const int64_t M = d->row_off[d->n_levels];
   if (M == 0) return 0;
   const int GC = G * Cg, slots = 256 / (GC / 4);
-  hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(gconv_taps_kernel, dim3(grid_for((M + slots - 1) / slots, 1)), dim3(256), 0, st, x, M, G, GC, w, ws);
+  if (g_scan_gconv_mfma || relu_bits != nullptr) {
+    hipLaunchKernelGGL(gconv_taps_mfma_kernel, dim3(gconv_wave_grid(M, G)), dim3(256), 0, st, x, M, G, GC, w, ws, relu_bits);
+  } else {
+    hipLaunchKernelGGL(gconv_taps_kernel, dim3(grid_for((M + slots - 1) / slots, 1)), dim3(256), 0, st, x, M, G, GC, w, ws);
+  }
   SCAN_LAUNCH_CHECK("gconv_taps");
   hipLaunchKernelGGL(gconv_gather_kernel, dim3(grid_for(M * Ns, 256)), dim3(256), 0, st, ws, *d, G, bias, y, Ns);
   SCAN_LAUNCH_CHECK("gconv_gather");
   return 0;
 }
 
+extern "C" int scan_gconv3x3_to1_forward(const float* x, const scan_pyramid_t* d, int32_t G, int32_t Cg, const float* w,
+                                         const float* bias, float* y, int32_t Ns, float* ws, void* stream) {
+  return gconv_forward(x, d, G, Cg, w, bias, y, Ns, ws, nullptr, as_stream(stream));
+}
+
+// the same, also leaving the ReLU bit mask of x behind (relu_bits: M * G * 4 words) for scan_gconv3x3_to1_backward_bits
+extern "C" int scan_gconv3x3_to1_forward_bits(const float* x, const scan_pyramid_t* d, int32_t G, int32_t Cg,
+                                              const float* w, const float* bias, float* y, int32_t Ns, float* ws,
+                                              uint32_t* relu_bits, void* stream) {
+  SCAN_CHECK_ARG(relu_bits, "gconv3x3_to1_forward_bits: null bit mask");
+  return gconv_forward(x, d, G, Cg, w, bias, y, Ns, ws, relu_bits, as_stream(stream));
+}
+
 static int gconv_backward(const float* x, const float* dy, int Ns, const scan_pyramid_t* d, int G, int Cg, const float* w,
-                          int relu_mask, float* dx, float* dw, int accumulate, float* ws, hipStream_t st,
-                          const char* who) {
+                          int relu_mask, const uint32_t* relu_bits, float* dx, float* dw, int accumulate, float* ws,
+                          hipStream_t st, const char* who) {
   if (gconv_check(d, G, Cg, who)) return -1;
   SCAN_CHECK_ARG(dy && Ns >= G && (dx || dw), "%s: bad arguments (Ns=%d)", who, Ns);
   SCAN_CHECK_ARG(!dx || w, "%s: the data gradient needs the weights", who);
   SCAN_CHECK_ARG(!dw || (x && ws), "%s: the weight gradient needs x and a workspace", who);
-  SCAN_CHECK_ARG(!(dx && relu_mask) || x, "%s: the ReLU mask needs x", who);
+  SCAN_CHECK_ARG(!(dx && relu_mask && !relu_bits) || x, "%s: the ReLU mask needs x or its bit mask", who);
   const int64_t M = d->row_off[d->n_levels];
   if (M == 0) return 0;
   const int GC = G * Cg;
@@ -273,15 +424,23 @@ static int gconv_backward(const float* x, const float* dy, int Ns, const scan_py
   int64_t rpb = (M + blocks - 1) / blocks;
   if (rpb < 16) rpb = 16;  // small levels: fewer, fuller workgroups
   blocks = (int)((M + rpb - 1) / rpb);
-  if (dx && dw)
+  const bool mfma = g_scan_gconv_mfma || relu_bits != nullptr;
+  if (dx && mfma) {
+    hipLaunchKernelGGL(gconv_dx_mfma_kernel, dim3(gconv_wave_grid(M, G)), dim3(256), 0, st, dy, Ns, *d, G, GC, w,
+                       (relu_mask && !relu_bits) ? x : (const float*)nullptr, relu_bits, dx);
+    SCAN_LAUNCH_CHECK(who);
+    if (dw) hipLaunchKernelGGL((gconv_bwd_kernel<false, true>), dim3(blocks), dim3(256), 0, st, x, dy, Ns, *d, G, GC, w, 0,
+                               dx, rpb, ws);
+  } else if (dx && dw) {
     hipLaunchKernelGGL((gconv_bwd_kernel<true, true>), dim3(blocks), dim3(256), 0, st, x, dy, Ns, *d, G, GC, w, relu_mask, dx,
                        rpb, ws);
-  else if (dx)
+  } else if (dx) {
     hipLaunchKernelGGL((gconv_bwd_kernel<true, false>), dim3(blocks), dim3(256), 0, st, x, dy, Ns, *d, G, GC, w, relu_mask, dx,
                        rpb, ws);
-  else
+  } else {
     hipLaunchKernelGGL((gconv_bwd_kernel<false, true>), dim3(blocks), dim3(256), 0, st, x, dy, Ns, *d, G, GC, w, 0, dx, rpb,
                        ws);
+  }
   SCAN_LAUNCH_CHECK(who);
   if (dw) {
     // fixed-order two-level sum of the per-workgroup partials: 32 runs of consecutive blocks, then the 32 run sums
@@ -300,22 +459,31 @@ static int gconv_backward(const float* x, const float* dy, int Ns, const scan_py
 extern "C" int scan_gconv3x3_to1_dgrad(const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G, int32_t Cg,
                                        const float* w, const float* mask, float* dx, void* stream) {
   SCAN_CHECK_ARG(dx, "gconv3x3_to1_dgrad: null output");
-  return gconv_backward(mask, dy, Ns, d, G, Cg, w, mask != nullptr, dx, nullptr, 0, nullptr, as_stream(stream),
+  return gconv_backward(mask, dy, Ns, d, G, Cg, w, mask != nullptr, nullptr, dx, nullptr, 0, nullptr, as_stream(stream),
                         "gconv3x3_to1_dgrad");
 }
 
 extern "C" int scan_gconv3x3_to1_wgrad(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G,
                                        int32_t Cg, float* dw, int32_t accumulate, float* ws, void* stream) {
   SCAN_CHECK_ARG(dw, "gconv3x3_to1_wgrad: null output");
-  return gconv_backward(x, dy, Ns, d, G, Cg, nullptr, 0, nullptr, dw, accumulate, ws, as_stream(stream),
+  return gconv_backward(x, dy, Ns, d, G, Cg, nullptr, 0, nullptr, nullptr, dw, accumulate, ws, as_stream(stream),
                         "gconv3x3_to1_wgrad");
 }
 
-// both gradients from ONE pass over x (relu_mask != 0: dx is multiplied by (x > 0), the producer's deferred ReLU)
+// both gradients (relu_mask != 0: dx is multiplied by (x > 0), the producer's deferred ReLU)
 extern "C" int scan_gconv3x3_to1_backward(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d, int32_t G,
                                           int32_t Cg, const float* w, int32_t relu_mask, float* dx, float* dw,
                                           int32_t accumulate, float* ws, void* stream) {
   SCAN_CHECK_ARG(x && dx && dw, "gconv3x3_to1_backward: null pointer");
-  return gconv_backward(x, dy, Ns, d, G, Cg, w, relu_mask, dx, dw, accumulate, ws, as_stream(stream),
+  return gconv_backward(x, dy, Ns, d, G, Cg, w, relu_mask, nullptr, dx, dw, accumulate, ws, as_stream(stream),
                         "gconv3x3_to1_backward");
+}
+
+// both gradients with the ReLU mask taken from the forward's bit mask (x is read once, by the weight gradient)
+extern "C" int scan_gconv3x3_to1_backward_bits(const float* x, const float* dy, int32_t Ns, const scan_pyramid_t* d,
+                                               int32_t G, int32_t Cg, const float* w, const uint32_t* relu_bits, float* dx,
+                                               float* dw, int32_t accumulate, float* ws, void* stream) {
+  SCAN_CHECK_ARG(x && dx && dw && relu_bits, "gconv3x3_to1_backward_bits: null pointer");
+  return gconv_backward(x, dy, Ns, d, G, Cg, w, 1, relu_bits, dx, dw, accumulate, ws, as_stream(stream),
+                        "gconv3x3_to1_backward_bits");
 }

@@ -1041,7 +1041,8 @@ def cka_stacked_weights(branches, C, H, cs1):
 class _GroupedConvTo1(torch.autograd.Function):
     """conv3x3 [M, G*128] -> [M, Ns >= G], one output channel per group of 128 (the class branches' second conv);
     w = the stacked weight [G, G*128, 3, 3] (channels-last) whose diagonal blocks are the per-class weights.
-    mask_dx: x is a deferred-ReLU output (see _Conv2d)."""
+    mask_dx: x is a deferred-ReLU output (see _Conv2d) -- the forward then also leaves (x > 0) as a bit mask (1/32 of x)
+    so that the backward does not read x a second time for it."""
 
     @staticmethod
     def forward(ctx, x, w, bias, shape, G, mask_dx):
@@ -1051,15 +1052,21 @@ class _GroupedConvTo1(torch.autograd.Function):
         ns = pad4(G)
         y = x.new_empty((shape.rows, ns))
         ws = x.new_empty((query("scan_gconv3x3_to1_ws_floats", shape.ref(), G, 128),))
-        call("scan_gconv3x3_to1_forward", _ptr(x), shape.ref(), G, 128, _ptr(w), _ptr(bias), _ptr(y), ns, _ptr(ws),
-             _stream())
-        ctx.save_for_backward(x, w)
+        bits = None
+        if mask_dx and torch.is_grad_enabled() and x.requires_grad:
+            bits = torch.empty((shape.rows * G * 4,), dtype=torch.int32, device=x.device)
+            call("scan_gconv3x3_to1_forward_bits", _ptr(x), shape.ref(), G, 128, _ptr(w), _ptr(bias), _ptr(y), ns,
+                 _ptr(ws), _ptr(bits), _stream())
+        else:
+            call("scan_gconv3x3_to1_forward", _ptr(x), shape.ref(), G, 128, _ptr(w), _ptr(bias), _ptr(y), ns, _ptr(ws),
+                 _stream())
+        ctx.save_for_backward(x, w, bits)
         ctx.cfg = (shape, G, ns, mask_dx, bias is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, bits = ctx.saved_tensors
         shape, G, ns, mask_dx, has_bias = ctx.cfg
         dy = dy.contiguous()
         st = _stream()
@@ -1070,7 +1077,10 @@ class _GroupedConvTo1(torch.autograd.Function):
             dw = dwp.view(G, 3, 3, G * 128).permute(0, 3, 1, 2)
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
-        if dx is not None and dwp is not None:  # one pass over x for both
+        if dx is not None and dwp is not None and bits is not None:
+            call("scan_gconv3x3_to1_backward_bits", _ptr(x), _ptr(dy), ns, shape.ref(), G, 128, _ptr(w), _ptr(bits),
+                 _ptr(dx), _ptr(dwp), 0, _ptr(ws), st)
+        elif dx is not None and dwp is not None:
             call("scan_gconv3x3_to1_backward", _ptr(x), _ptr(dy), ns, shape.ref(), G, 128, _ptr(w), int(mask_dx), _ptr(dx),
                  _ptr(dwp), 0, _ptr(ws), st)
         elif dx is not None:

@@ -889,8 +889,18 @@ def test_cka_stacked_weights_equal_torch_construction(device, cf, channels_last)
         assert torch.equal(p.grad, 1 + r)
 
 
+@pytest.fixture(params=[1, 0], ids=["mfma", "fma"])
+def gconv_kernels(request):
+    """both implementations of the grouped class-branch conv (scan_tune "gconv_mfma")"""
+    from scan_amd import _lib
+    old = _lib.query("scan_tune", b"gconv_mfma", request.param)
+    assert old >= 0
+    yield request.param
+    _lib.query("scan_tune", b"gconv_mfma", old)
+
+
 @pytest.mark.parametrize("G,sizes", [(8, [(16, 24), (8, 12), (3, 5)]), (8, [(40, 64)]), (1, [(12, 20), (5, 7)]), (2, [(9, 9)])])
-def test_grouped_conv_to_one_channel_per_group(device, G, sizes):
+def test_grouped_conv_to_one_channel_per_group(device, G, sizes, gconv_kernels):
     """scan_gconv3x3_to1_*: the class branches' second conv (nn.Conv2d(128, 1, 3, padding=1) per class, reference
     fcos_head_discriminator_con.py:44-62) for all classes at once, against F.conv2d(groups=G) on the CPU -- forward,
     the ReLU-masked data gradient, the weight gradient (diagonal blocks only) and the bias gradient."""
@@ -932,6 +942,19 @@ def test_grouped_conv_to_one_channel_per_group(device, G, sizes):
         off = torch.cat([dw[c, :c * 128], dw[c, (c + 1) * 128:]], 0)
         assert float(off.abs().sum()) == 0  # exact zeros off the diagonal
     np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=2e-4, atol=1e-4)
+    # the C entry points that take the mask from x itself / apply none, against the bit-mask path above
+    from scan_amd import _lib
+    P, st = ops._ptr, ops._stream()
+    wsb = torch.empty((_lib.query("scan_gconv3x3_to1_ws_floats", shape.ref(), G, 128),), device=device)
+    wpk = wd.detach().permute(0, 2, 3, 1).contiguous()
+    xr_, gyr = rows.detach(), gy_rows.contiguous()
+    dx1, dx0, dwb = torch.empty_like(xr_), torch.empty_like(xr_), torch.zeros_like(wpk)
+    _lib.call("scan_gconv3x3_to1_backward", P(xr_), P(gyr), ops.pad4(G), shape.ref(), G, 128, P(wpk), 1, P(dx1), P(dwb), 0,
+              P(wsb), st)
+    _lib.call("scan_gconv3x3_to1_dgrad", P(gyr), ops.pad4(G), shape.ref(), G, 128, P(wpk), None, P(dx0), st)
+    assert (dx1 - rows.grad).abs().max().item() <= 1e-5 * max(1.0, rows.grad.abs().max().item())
+    assert (dx0 * (xr_ > 0) - rows.grad).abs().max().item() <= 1e-5 * max(1.0, rows.grad.abs().max().item())
+    assert (dwb.view(G, 3, 3, gc).permute(0, 3, 1, 2) - wd.grad).abs().max().item() <= 1e-5 * max(1.0, wd.grad.abs().max().item())
 
 
 def test_discriminator_grouped_branch_equals_dense_branch(device):

@@ -120,15 +120,19 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float* __restrict_
     wv[t] = DO_DX ? *reinterpret_cast<const float4*>(w + ((int64_t)g * 9 + t) * GC + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
     acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  // weight gradient alone: three pixels in flight per thread (the fused variant has no registers to spare)
+  constexpr int UN = (DO_DW && !DO_DX) ? 3 : GC_UNROLL;
   const int64_t qb = (int64_t)blockIdx.x * rows_per_block;
   const int64_t qe = qb + rows_per_block < M ? qb + rows_per_block : M;
   const bool need_x = DO_DW || relu_mask;
-  for (int64_t q0 = qb + slot; q0 < qe; q0 += GC_UNROLL * slots) {
-    float4 h[GC_UNROLL];
-    float gy[GC_UNROLL][9];
+  for (int64_t q0 = qb + slot; q0 < qe; q0 += UN * slots) {
+    float4 h[UN];
+    float gy[UN][9];
 #pragma unroll
-    for (int u = 0; u < GC_UNROLL; ++u) {
-      const int64_t q = q0 + u * slots;
+    for (int u = 0; u < UN; ++u) {
+      int64_t q = q0 + u * slots;
+      if (slots == 1)  // one pixel per workgroup iteration: the row decode below is wave-uniform -> scalar unit
+        q = ((int64_t)__builtin_amdgcn_readfirstlane((int)(q >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)q);
       h[u] = (q < qe && need_x) ? *reinterpret_cast<const float4*>(x + q * GC + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (q < qe) {
         const RowCoord rc = decode_row(d, q);
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float* __restrict_
       }
     }
 #pragma unroll
-    for (int u = 0; u < GC_UNROLL; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const int64_t q = q0 + u * slots;
       if (DO_DW) {
 #pragma unroll

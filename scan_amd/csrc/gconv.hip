@@ -140,11 +140,31 @@ __global__ __launch_bounds__(256) void gconv_bwd_kernel(const float* __restrict_
       h[u] = (q < qe && need_x) ? *reinterpret_cast<const float4*>(x + q * GC + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (q < qe) {
         const RowCoord rc = decode_row(d, q);
+        if (slots == 1) {
+          // one pixel per workgroup iteration: the wave's two groups (lanes 0..31 / 32..63) need two wave-uniform dy
+          // values per tap.  Lanes 0..17 fetch the 9 x 2 values with ONE load and every lane picks its own by
+          // v_readlane -- as nine same-address vector loads per KiB of x the gathers cost more address-unit time
+          // than the x stream itself (418 -> 234 us at P3 without them).
+          const int g0 = 2 * (int)(threadIdx.x >> 6);
+          const int l = threadIdx.x & 63;
+          const int tl = l % 9, gl = l / 9;
+          const int64_t pl = l < 18 ? neighbour_row(d, q, rc, 1 - tl / 3, 1 - tl % 3) : -1;
+          const float v = pl >= 0 ? dy[pl * Ns + g0 + gl] : 0.f;
+          const int vb = __builtin_bit_cast(int, v);
+          const bool hi = (l & 32) != 0;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-          // y[p] took x[p + off(t)] * w[t], so x[q] feeds y[q - off(t)]
-          const int64_t p = neighbour_row(d, q, rc, 1 - t / 3, 1 - t % 3);
-          gy[u][t] = p >= 0 ? dy[p * Ns + g] : 0.f;
+          for (int t = 0; t < 9; ++t) {
+            const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, t));
+            const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(vb, 9 + t));
+            gy[u][t] = hi ? b : a;
+          }
+        } else {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            // y[p] took x[p + off(t)] * w[t], so x[q] feeds y[q - off(t)]
+            const int64_t p = neighbour_row(d, q, rc, 1 - t / 3, 1 - t % 3);
+            gy[u][t] = p >= 0 ? dy[p * Ns + g] : 0.f;
+          }
         }
       } else {
 #pragma unroll

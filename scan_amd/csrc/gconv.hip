@@ -394,9 +394,13 @@ extern "C" int64_t scan_gconv3x3_to1_ws_floats(const scan_pyramid_t* d, int32_t 
   return taps > slab ? taps : slab;
 }
 
-// scan_tune "gconv_mfma": 1 (default) = tap products and data gradient on v_mfma_f32_16x16x4_f32; 0 = the fp32 FMA
-// kernels (DPP half-wave sums forward, fused dx + dw pass backward).  Same products, different summation order.
-int g_scan_gconv_mfma = 1;
+// scan_tune "gconv_mfma": 0 (default) = the fp32 FMA kernels (DPP half-wave sums forward; ONE backward pass over x that
+// yields dx and the dw partials); 1 = tap products and data gradient on v_mfma_f32_16x16x4_f32 with the ReLU mask kept
+// as bits by the forward.  Same products, different summation order.  Measured in the training step on one box
+// (3 alternating runs each): FMA 68.8 / 69.1 / 68.7 ms, matrix cores 69.1 / 70.3 / 68.7 ms -- the matrix-core kernels
+// are individually a little faster forward (147 vs 171 us at P3) but need two passes backward (dx 200 us + dw 235 us vs
+// 480 us fused), so nothing is gained; all of them sit at 2.3-3.7 TB/s, bound by bytes in flight, not by arithmetic.
+int g_scan_gconv_mfma = 0;
 
 static int gconv_wave_grid(int64_t M, int G) {
   int64_t tasks = ((M + 15) / 16) * G;  // (16-pixel group, channel group) pairs, one per wave iteration

@@ -889,7 +889,7 @@ def test_cka_stacked_weights_equal_torch_construction(device, cf, channels_last)
         assert torch.equal(p.grad, 1 + r)
 
 
-@pytest.fixture(params=[1, 0], ids=["mfma", "fma"])
+@pytest.fixture(params=[0, 1], ids=["fma", "mfma"])
 def gconv_kernels(request):
     """both implementations of the grouped class-branch conv (scan_tune "gconv_mfma")"""
     from scan_amd import _lib

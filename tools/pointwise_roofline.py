@@ -170,17 +170,14 @@ def measure(dev, sizes=(M_CFG5, M_BIG), reps=10, K=9, only=None):
         bc = torch.randn(8, device=dev, generator=g)
         yc = torch.empty((Mc, 8), device=dev)
         wsc = torch.empty((query("scan_gconv3x3_to1_ws_floats", shape.ref(), 8, 128),), device=dev)
-        bitc = torch.empty((Mc * 32,), dtype=torch.int32, device=dev)
-        rec("gconv3x3_to1_fwd", Mc, Mc * (4096 + 32 + 2 * 288 + 128),
-            "M(4096+32+576+128): x read, y written, 72 tap products written and read, ReLU bit mask written",
-            lambda: call("scan_gconv3x3_to1_forward_bits", P(xc), shape.ref(), 8, 128, P(wc), P(bc), P(yc), 8, P(wsc), P(bitc),
-                         st()))
+        rec("gconv3x3_to1_fwd", Mc, Mc * (4096 + 32 + 2 * 288), "M(4096+32+576): x read, y written, 72 tap products written and read",
+            lambda: call("scan_gconv3x3_to1_forward", P(xc), shape.ref(), 8, 128, P(wc), P(bc), P(yc), 8, P(wsc), st()))
         dyc = torch.randn((Mc, 8), device=dev, generator=g)
         dxc = torch.empty_like(xc)
         dwc = torch.zeros_like(wc)
-        rec("gconv3x3_to1_bwd", Mc, Mc * (8192 + 32 + 128), "M(8192+32+128): x, dy and the bit mask read, dx written (dw: 36 KB per workgroup)",
-            lambda: call("scan_gconv3x3_to1_backward_bits", P(xc), P(dyc), 8, shape.ref(), 8, 128, P(wc), P(bitc), P(dxc),
-                         P(dwc), 0, P(wsc), st()))
+        rec("gconv3x3_to1_bwd", Mc, Mc * (8192 + 32), "M(8192+32): x and dy read, dx written (dw: 36 KB per workgroup)",
+            lambda: call("scan_gconv3x3_to1_backward", P(xc), P(dyc), 8, shape.ref(), 8, 128, P(wc), 1, P(dxc), P(dwc), 0,
+                         P(wsc), st()))
         del xc, dxc, yc, dyc, wsc
         torch.cuda.empty_cache()
     return out

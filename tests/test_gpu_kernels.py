@@ -983,3 +983,25 @@ def test_discriminator_grouped_branch_equals_dense_branch(device):
             ops.GROUPED_CLS = ops.BATCHED = True
     for a, b in zip(*res):
         assert (a - b).abs().max().item() <= 2e-4 * max(b.abs().max().item(), 1e-6), (a.shape, (a - b).abs().max().item())
+
+
+def test_grouped_conv_adjoint_identities_full_size(device, gconv_kernels):
+    """size-independent properties at the bench size (P3, 4 frames, 8 classes): the data gradient is the adjoint of the
+    forward map in x, the weight gradient its adjoint in w -- <conv(x, w), g> = <x, dgrad(g, w)> = <w, wgrad(x, g)>
+    (bias off), in fp64 on the host from fp32 device results."""
+    from scan_amd import ops
+    g = torch.Generator(device=device).manual_seed(9)
+    G, shape = 8, ops.PyramidShape(4, [(128, 256)])
+    x = torch.randn((shape.rows, G * 128), device=device, generator=g).requires_grad_(True)
+    w = torch.zeros((G, G * 128, 3, 3), device=device)
+    for c in range(G):
+        w[c, c * 128:(c + 1) * 128] = torch.randn((128, 3, 3), device=device, generator=g) / 30
+    w = w.contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    gy = torch.randn((shape.rows, 8), device=device, generator=g)
+    y = ops.gconv3x3_to1(x, w, None, shape, G, mask_dx=False)
+    y.backward(gy)
+    lhs = float((y.detach().double() * gy.double()).sum())
+    via_x = float((x.detach().double() * x.grad.double()).sum())
+    via_w = float((w.detach().double() * w.grad.double()).sum())
+    scale = float((y.detach().double().abs() * gy.double().abs()).sum())
+    assert abs(lhs - via_x) <= 2e-6 * scale and abs(lhs - via_w) <= 2e-6 * scale, (lhs, via_x, via_w, scale)

@@ -1005,3 +1005,38 @@ def test_grouped_conv_adjoint_identities_full_size(device, gconv_kernels):
     via_w = float((w.detach().double() * w.grad.double()).sum())
     scale = float((y.detach().double().abs() * gy.double().abs()).sum())
     assert abs(lhs - via_x) <= 2e-6 * scale and abs(lhs - via_w) <= 2e-6 * scale, (lhs, via_x, via_w, scale)
+
+
+def test_new_entry_points_reject_bad_arguments(device):
+    """error behaviour of the round-2 entry points: a non-zero return with a message (RuntimeError on the Python side),
+    never a launch on bad geometry"""
+    from scan_amd import _lib, ops
+    P, st = ops._ptr, ops._stream()
+    shape = ops.PyramidShape(1, [(4, 4)])
+    x = torch.zeros((16, 3 * 128), device=device)
+    w = torch.zeros((3, 9, 3 * 128), device=device)
+    y = torch.zeros((16, 4), device=device)
+    ws = torch.zeros((1 << 16,), device=device)
+    with pytest.raises(RuntimeError, match="G=3"):
+        _lib.call("scan_gconv3x3_to1_forward", P(x), shape.ref(), 3, 128, P(w), None, P(y), 4, P(ws), st)
+    with pytest.raises(RuntimeError, match="128 channels per group"):
+        _lib.call("scan_gconv3x3_to1_forward", P(x), shape.ref(), 2, 64, P(w), None, P(y), 4, P(ws), st)
+    with pytest.raises(RuntimeError, match="Ns"):
+        _lib.call("scan_gconv3x3_to1_forward", P(x), shape.ref(), 2, 128, P(w), None, P(y), 1, P(ws), st)
+    with pytest.raises(RuntimeError, match="null"):
+        _lib.call("scan_gconv3x3_to1_backward", None, P(y), 4, shape.ref(), 2, 128, P(w), 1, P(x), P(w), 0, P(ws), st)
+    br = (_lib.CkaBranch * 17)()
+    with pytest.raises(RuntimeError, match="Cf=17"):
+        _lib.call("scan_cka_stack_weights", br, 17, 256, 128, 1, 1, 1, 1, 1, 276, 17 * 128, P(w), P(w), P(w), P(w), st)
+    br1 = (_lib.CkaBranch * 1)()
+    with pytest.raises(RuntimeError, match="null pointer in branch 0"):
+        _lib.call("scan_cka_stack_weights", br1, 1, 256, 128, 1, 1, 1, 1, 1, 260, 128, P(w), P(w), P(w), P(w), st)
+    seg = (_lib.SgdSegment * 1)()
+    with pytest.raises(RuntimeError, match="n_segs=0"):
+        _lib.call("scan_sgd_momentum_multi", seg, 0, 0.9, st)
+    seg[0].n = 8
+    with pytest.raises(RuntimeError, match="null pointer in segment 0"):
+        _lib.call("scan_sgd_momentum_multi", seg, 1, 0.9, st)
+    with pytest.raises(RuntimeError, match="from_sums"):
+        _lib.call("scan_groupnorm_relu_forward_from_sums", P(x), shape.ref(), 256, 32, None, 1e-5, P(x), P(x), 1, P(x), P(x), st)
+    assert _lib.query("scan_tune", b"no_such_knob", 1) == -1

@@ -56,6 +56,9 @@ int scan_abi_version(void);
  *                 2: 16 waves only for the 256-channel tile on multi-level pyramids.  Same results bit for bit.
  *   "conv_bn64_th16" 1 (default): convs with <= 64 output channels on single-level pyramids whose sizes are multiples of
  *                 16 use 16x16-pixel tiles; 0: 8x16.  Same results bit for bit.
+ *   "wgrad_wgs"   768 (default): workgroups a bf16x3 weight-gradient launch aims at (tiles x split-K slabs); swept again on
+ *                 the second-generation kernel: 512 / 640 / 896 / 1024 / 1280 / 1536 are 2...25 % slower on the 256- and
+ *                 512-channel layers.
  *   "gconv_mfma"  0 (default): the grouped class-branch conv runs on fp32 FMAs; 1: tap products and data gradient on the
  *                 fp32 matrix cores (same products, different summation order; measured no faster in the step).
  *   "conv_tpb3"   bit 0 / bit 1: the 128- / 64-channel instance stages three taps per barrier (default 0; same

@@ -1381,6 +1381,8 @@ __global__ void bias_slab_reduce_kernel(const float* __restrict__ bs, int splits
 extern "C" void scan_slab_reduce_launch(const float* slab, int splits, int64_t n, float* dw, int accumulate,
                                         hipStream_t st);
 
+// scan_tune "wgrad_wgs": workgroups a weight-gradient launch aims at (tiles x splits), see the sweep quoted in wgrad3_plan
+int g_scan_wgrad_wgs = 768;
 static void wgrad3_plan(const scan_pyramid_t* d, int Cs, int Cout, ChunkTab* ct, int* n_tiles, int* c_tiles,
                         int* splits, int* cps, int KX = 3) {
   ct->chunk_off[0] = 0;
@@ -1399,7 +1401,7 @@ static void wgrad3_plan(const scan_pyramid_t* d, int Cs, int Cout, ChunkTab* ct,
   // ~3 workgroups per CU in total.  Swept on the device (tower layer, us): 256 -> 499, 512 -> 428, 768 -> 355,
   // 1024 -> 414, 1536 -> 411, 2304 -> 486: fewer splits lengthen each workgroup's serial chunk chain, more splits
   // cost slab traffic and leave partial rounds
-  long long s = 768 / *n_tiles;
+  long long s = g_scan_wgrad_wgs / *n_tiles;
   if (s < 1) s = 1;
   const long long smax = (chunks + 7) / 8;
   if (s > smax) s = smax;

@@ -28,6 +28,7 @@ extern int g_scan_wgrad_v3;
 extern int g_scan_conv_bn64_th16;
 extern int g_scan_gconv_mfma;
 extern int g_scan_wgrad_wgs;
+extern int g_scan_conv_glds;
 
 extern "C" int scan_tune(const char* key, int value) {
   if (key == nullptr) return -1;
@@ -42,6 +43,7 @@ extern "C" int scan_tune(const char* key, int value) {
   if (strcmp(key, "conv_bn64_th16") == 0) slot = &g_scan_conv_bn64_th16;
   if (strcmp(key, "gconv_mfma") == 0) slot = &g_scan_gconv_mfma;
   if (strcmp(key, "wgrad_wgs") == 0) slot = &g_scan_wgrad_wgs;
+  if (strcmp(key, "conv_glds") == 0) slot = &g_scan_conv_glds;
   if (slot == nullptr) return -1;
   const int old = *slot;
   *slot = value;

@@ -61,7 +61,14 @@ __device__ __forceinline__ int swz(int idx) { return (idx >> 1) & 2; }
 // conv; 2: source = output / 2 on even coordinates, zero elsewhere: its data gradient), like the first kernel.
 // TPB: taps staged per barrier (1, or 3 = one ky row of the 3x3: the weight tiles of three taps share one barrier
 // interval, 4 barriers per 32-channel chunk instead of 10 -- fits for BN <= 128: 2 x 3 x 16 KB + the 41 KB patch)
-template <int BN, int TH, int NT, int KS, int TPB = 1>
+// GL: the weight tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4) instead of through registers: no staging
+// registers, no ds_write pass, and the next tap's tile is in flight while the matrix cores work on the current one (the
+// slot swizzle moves to the per-lane SOURCE address: the DMA writes a wave's 64 x 16 bytes contiguously).  Needs whole
+// tiles: Nout % BN == 0 and Csw % 32 == 0 (masked lanes would leave stale LDS behind).
+typedef __attribute__((address_space(3))) void* v2_lds_ptr;
+typedef const __attribute__((address_space(1))) void* v2_glb_ptr;
+
+template <int BN, int TH, int NT, int KS, int TPB = 1, bool GL = false>
 __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
     const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
@@ -182,6 +189,23 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
     }
   };
 
+  auto issue_b = [&](int cc, int grp, int buf) {
+#pragma unroll
+    for (int tt = 0; tt < TPB; ++tt) {
+      const int tap = grp * TPB + tt;
+#pragma unroll
+      for (int i = 0; i < BSEG; ++i) {
+        const int slot = tid + NT * i;
+        const int plane = slot / (BN * 4);
+        const int rem = slot - plane * BN * 4;   // destination slot inside the plane: row * 4 + dslot
+        const int row = rem >> 2, seg = (rem & 3) ^ swz(row);  // source k-group of that slot (swz is an involution)
+        const __bf16* g = (plane ? wl : wh) + ((int64_t)(n0 + row) * NTAPS + tap) * Csw + cc * V2_CK + 8 * seg;
+        __bf16* dst = Bs + (((buf * TPB + tt) * 2 + plane) * BN) * 32 + (rem - lane) * 8;  // the wave's first slot
+        __builtin_amdgcn_global_load_lds((v2_glb_ptr)g, (v2_lds_ptr)dst, 16, 0, 0);
+      }
+    }
+  };
+
   // ---- MFMA roles
   const int wm = wid / WN_WAVES, wn = wid % WN_WAVES;
   const int lr = lane & 15, kg = lane >> 4;
@@ -194,49 +218,79 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
+  auto taps_mma = [&](int grp, int buf) {
+#pragma unroll
+    for (int tt = 0; tt < TPB; ++tt) {
+      const int tap = grp * TPB + tt;
+      const int ky = tap / KS, kx = tap - KS * ky;
+      const int pxs = lr + kx;  // patch column of this lane's pixel
+      const int p_off = ((wm * TM + ky) * PWK + pxs) * 32 + ((kg ^ swz(pxs)) << 3);
+      const __bf16* bh = Bs + ((buf * TPB + tt) * 2 + 0) * BN * 32 + w_off;
+      const __bf16* bl = Bs + ((buf * TPB + tt) * 2 + 1) * BN * 32 + w_off;
+      bf16x8 ph[TM], pl[TM];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        ph[tm] = *reinterpret_cast<const bf16x8*>(Ah + p_off + tm * PWK * 32);
+        pl[tm] = *reinterpret_cast<const bf16x8*>(Al + p_off + tm * PWK * 32);
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+        const bf16x8 whv = *reinterpret_cast<const bf16x8*>(bh + tn * 16 * 32);
+        const bf16x8 wlv = *reinterpret_cast<const bf16x8*>(bl + tn * 16 * 32);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, pl[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlv, ph[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, ph[tm], acc[tm][tn], 0, 0, 0);
+      }
+    }
+  };
+
   load_a(0);
-  load_b(0, 0);
-  for (int cc = 0; cc < nchunks; ++cc) {
-    __syncthreads();  // every wave is done reading the previous chunk's patch
-    store_a();
-    if (cc + 1 < nchunks) load_a(cc + 1);
+  if constexpr (GL) {
+    issue_b(0, 0, 0);
+    for (int cc = 0; cc < nchunks; ++cc) {
+      __syncthreads();  // every wave is done reading the previous chunk's patch
+      store_a();
+      if (NGRP == 1 && cc + 1 < nchunks) load_a(cc + 1);
 #pragma unroll 1
-    for (int grp = 0; grp < NGRP; ++grp) {
-      const int buf = (cc * NGRP + grp) & 1;
-      store_b(buf);
-      if (grp < NGRP - 1)
-        load_b(cc, grp + 1);
-      else if (cc + 1 < nchunks)
-        load_b(cc + 1, 0);
-      __syncthreads();
-#pragma unroll
-      for (int tt = 0; tt < TPB; ++tt) {
-        const int tap = grp * TPB + tt;
-        const int ky = tap / KS, kx = tap - KS * ky;
-        const int pxs = lr + kx;  // patch column of this lane's pixel
-        const int p_off = ((wm * TM + ky) * PWK + pxs) * 32 + ((kg ^ swz(pxs)) << 3);
-        const __bf16* bh = Bs + ((buf * TPB + tt) * 2 + 0) * BN * 32 + w_off;
-        const __bf16* bl = Bs + ((buf * TPB + tt) * 2 + 1) * BN * 32 + w_off;
-        bf16x8 ph[TM], pl[TM];
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          ph[tm] = *reinterpret_cast<const bf16x8*>(Ah + p_off + tm * PWK * 32);
-          pl[tm] = *reinterpret_cast<const bf16x8*>(Al + p_off + tm * PWK * 32);
-        }
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-          const bf16x8 whv = *reinterpret_cast<const bf16x8*>(bh + tn * 16 * 32);
-          const bf16x8 wlv = *reinterpret_cast<const bf16x8*>(bl + tn * 16 * 32);
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, pl[tm], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlv, ph[tm], acc[tm][tn], 0, 0, 0);
-#pragma unroll
-          for (int tm = 0; tm < TM; ++tm)
-            acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, ph[tm], acc[tm][tn], 0, 0, 0);
-        }
+      for (int grp = 0; grp < NGRP; ++grp) {
+        const int buf = (cc * NGRP + grp) & 1;
+        // an LDS-DMA counts on vmcnt and the compiler does not wait for it on its own: this wave's pieces of the tile
+        // (issued one tap ago) must have landed before the barrier publishes the tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();  // this tap's weight tile is complete for everyone; the patch is visible
+        // the other buffer was last read one tap ago: the next tap's tile goes there while this one is multiplied
+        if (grp < NGRP - 1)
+          issue_b(cc, grp + 1, buf ^ 1);
+        else if (cc + 1 < nchunks)
+          issue_b(cc + 1, 0, buf ^ 1);
+        // the next chunk's patch: fetched one tap before it is needed (the barrier above drains every outstanding
+        // load, so an earlier prefetch would only stall an earlier tap)
+        if (NGRP > 1 && grp == NGRP - 2 && cc + 1 < nchunks) load_a(cc + 1);
+        taps_mma(grp, buf);
+      }
+    }
+  } else {
+    load_b(0, 0);
+    for (int cc = 0; cc < nchunks; ++cc) {
+      __syncthreads();  // every wave is done reading the previous chunk's patch
+      store_a();
+      if (cc + 1 < nchunks) load_a(cc + 1);
+#pragma unroll 1
+      for (int grp = 0; grp < NGRP; ++grp) {
+        const int buf = (cc * NGRP + grp) & 1;
+        store_b(buf);
+        if (grp < NGRP - 1)
+          load_b(cc, grp + 1);
+        else if (cc + 1 < nchunks)
+          load_b(cc + 1, 0);
+        __syncthreads();
+        taps_mma(grp, buf);
       }
     }
   }
@@ -347,7 +401,7 @@ static void make_tiles_v2(const scan_pyramid_t* d, TileTab2* tt, int TH) {
   }
 }
 
-template <int BN, int TH, int NT, int KS, int TPB = 1>
+template <int BN, int TH, int NT, int KS, int TPB = 1, bool GL = false>
 static void launch_v2(const float* x, const scan_pyramid_t* od, int32_t Cs, const __bf16* h, const __bf16* l, int32_t Csw,
                       const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns, int32_t relu,
                       hipStream_t st, double* gn_ws, const scan_pyramid_t* sd, int map) {
@@ -359,11 +413,11 @@ static void launch_v2(const float* x, const scan_pyramid_t* od, int32_t Cs, cons
   const size_t sh = (size_t)(2 * (TH + 2 * HALO) * (V2_TW + 2 * HALO) * 32 + 4 * TPB * BN * 32) * sizeof(__bf16);
   static bool done = false;
   if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB, GL>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     done = true;
   }
-  hipLaunchKernelGGL((conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB>), dim3(tiles * n_tiles), dim3(NT), sh, st, x, *od, Cs, h,
+  hipLaunchKernelGGL((conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB, GL>), dim3(tiles * n_tiles), dim3(NT), sh, st, x, *od, Cs, h,
                      l, Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *sd, map, gn_ws);
 }
 
@@ -381,6 +435,9 @@ int g_scan_conv_wg1024 = 1;
 // three workgroups per CU).  Default 0: measured +-1 % on every layer (profiles/r02_conv_instances.txt) -- the barrier
 // count is not what bounds these kernels (as MI355X_MICROARCH.md "Barrier count is not the lever" predicts).
 int g_scan_conv_tpb3 = 0;
+// scan_tune "conv_glds": 1 = the 16-wave 128- / 256-channel 3x3 instances stage their weight tiles by LDS-DMA
+// (global_load_lds_dwordx4) when the launch has whole tiles (Nout % tile == 0, Csw % 32 == 0); 0 = through registers.
+int g_scan_conv_glds = 1;
 // scan_tune "conv_bn64_th16": the <= 64-channel 3x3 instance on 16x16-pixel tiles (4 waves x 64 px x 64 ch: 48 MFMAs per
 // wave and barrier instead of 24) instead of 8x16 -- 1 (default): single-level pyramids with H, W multiples of 16, 0:
 // never.  conv1_2 (64 -> 64 at 1024x2048, 4 frames) 2047 -> 1940 us, conv2_1 990 -> 981 us (tools/conv_bench.py).
@@ -411,7 +468,10 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
         launch_v2<64, 8, 256, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       break;
     case 256:
-      if (g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1))
+      if ((g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1)) && g_scan_conv_glds && Csw % 32 == 0 &&
+          Nout % 256 == 0)
+        launch_v2<256, 16, 1024, 3, 1, true>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else if (g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1))
         launch_v2<256, 16, 1024, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       else
         launch_v2<256, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
@@ -419,6 +479,8 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
     default:
       if (g_scan_conv_wg1024 == 1 && (g_scan_conv_tpb3 & 1))
         launch_v2<128, 16, 1024, 3, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else if (g_scan_conv_wg1024 == 1 && g_scan_conv_glds && Csw % 32 == 0 && Nout % 128 == 0)
+        launch_v2<128, 16, 1024, 3, 1, true>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       else if (g_scan_conv_wg1024 == 1)
         launch_v2<128, 16, 1024, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       else if (g_scan_conv_tpb3 & 1)

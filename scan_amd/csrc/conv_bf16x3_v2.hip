@@ -437,6 +437,9 @@ int g_scan_conv_wg1024 = 1;
 int g_scan_conv_tpb3 = 0;
 // scan_tune "conv_glds": 1 = the 16-wave 128- / 256-channel 3x3 instances stage their weight tiles by LDS-DMA
 // (global_load_lds_dwordx4) when the launch has whole tiles (Nout % tile == 0, Csw % 32 == 0); 0 = through registers.
+// Same-process A/B per layer (tools/conv_bench.py, us): towers over P3..P7 608 -> 556, conv3_x 1530 -> 1431, conv4_x
+// 1431 -> 1349 (458 TFLOP/s); neutral on the 128-channel instance; the 64-channel instance gets slower (1906 -> 2040)
+// and stays on registers.  Training step, three alternating runs on one box: 70.6 / 70.3 / 71.2 -> 69.3 / 69.2 / 69.4 ms.
 int g_scan_conv_glds = 1;
 // scan_tune "conv_bn64_th16": the <= 64-channel 3x3 instance on 16x16-pixel tiles (4 waves x 64 px x 64 ch: 48 MFMAs per
 // wave and barrier instead of 24) instead of 8x16 -- 1 (default): single-level pyramids with H, W multiples of 16, 0:

@@ -166,6 +166,10 @@ def unpack_weight_grad(dw, weight):
 CONV_MODE = "bf16x3"
 
 
+def _round32(c):
+    return (c + 31) // 32 * 32
+
+
 def _round8(c):
     return (c + 7) // 8 * 8
 
@@ -262,10 +266,13 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
     scan_conv1x1_bf16x3's map).  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
     st = _stream()
     O, T, cs_w = wp.shape
+    # plane rows are zero-padded to whole 32-channel K chunks for the 3x3 kernels: the LDS-DMA weight path needs whole
+    # chunks (a 264-channel input then takes it too); 1x1 planes keep the 8-element granule
+    rnd = _round32 if T == 9 else _round8
     if mode == 0:
-        rows, csw, nout = O, _round8(cs_w), O
+        rows, csw, nout = O, rnd(cs_w), O
     else:
-        rows, csw, nout = cs_w, _round8(max(O, cs_src)), cs_w
+        rows, csw, nout = cs_w, rnd(max(O, cs_src)), cs_w
     hit = None
     if cache_key is not None and SPLIT_EPOCH is not None:
         key = (cache_key, mode, csw)

@@ -61,8 +61,10 @@ int scan_abi_version(void);
  *                 512-channel layers.
  *   "gconv_mfma"  0 (default): the grouped class-branch conv runs on fp32 FMAs; 1: tap products and data gradient on the
  *                 fp32 matrix cores (same products, different summation order; measured no faster in the step).
- *   "conv_tpb3"   bit 0 / bit 1: the 128- / 64-channel instance stages three taps per barrier (default 0; same
- *                 results bit for bit). */
+ *   "conv_tpb3"   bit 0 (default on) / bit 1: the 128- / 64-channel instance stages three taps per barrier (same
+ *                 results bit for bit).
+ *   "conv_glds"   1 (default): the 16-wave 128- / 256-channel 3x3 instances stage weight tiles by LDS-DMA
+ *                 (global_load_lds_dwordx4) on whole tiles; 0: through registers.  Same results bit for bit. */
 int scan_tune(const char* key, int value);
 
 /* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels;

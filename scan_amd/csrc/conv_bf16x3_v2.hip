@@ -431,10 +431,11 @@ extern int g_scan_conv_bn256;
 // leave 8-wave workgroups short of work to hide latency), single-level layers +1...3 %, none slower.
 int g_scan_conv_wg1024 = 1;
 // scan_tune "conv_tpb3": stage the three taps of a ky row per barrier (4 barriers per 32-channel chunk instead of 10)
-// -- bit 0: the 128-channel 3x3 instance, bit 1: the 64-channel one (196 instead of 140 registers: two instead of
-// three workgroups per CU).  Default 0: measured +-1 % on every layer (profiles/r02_conv_instances.txt) -- the barrier
-// count is not what bounds these kernels (as MI355X_MICROARCH.md "Barrier count is not the lever" predicts).
-int g_scan_conv_tpb3 = 0;
+// -- bit 0 (default on): the 128-channel 3x3 instance, bit 1: the 64-channel one (196 instead of 140 registers: two
+// instead of three workgroups per CU).  Register-staged it measured +-1 % on every layer
+// (profiles/r02_conv_instances.txt); with the weight tiles on LDS-DMA (no staging registers for three taps) the
+// 128-channel instance gains 2 % (FCOS towers 285 -> 278 us, conv2_2 1679 -> 1640, conv5_x 378 -> 372).
+int g_scan_conv_tpb3 = 1;
 // scan_tune "conv_glds": 1 = the 16-wave 128- / 256-channel 3x3 instances stage their weight tiles by LDS-DMA
 // (global_load_lds_dwordx4) when the launch has whole tiles (Nout % tile == 0, Csw % 32 == 0); 0 = through registers.
 // Same-process A/B per layer (tools/conv_bench.py, us): towers over P3..P7 608 -> 556, conv3_x 1530 -> 1431, conv4_x
@@ -480,7 +481,9 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
         launch_v2<256, 16, 512, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       break;
     default:
-      if (g_scan_conv_wg1024 == 1 && (g_scan_conv_tpb3 & 1))
+      if (g_scan_conv_wg1024 == 1 && (g_scan_conv_tpb3 & 1) && g_scan_conv_glds && Csw % 32 == 0 && Nout % 128 == 0)
+        launch_v2<128, 16, 1024, 3, 3, true>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else if (g_scan_conv_wg1024 == 1 && (g_scan_conv_tpb3 & 1))
         launch_v2<128, 16, 1024, 3, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       else if (g_scan_conv_wg1024 == 1 && g_scan_conv_glds && Csw % 32 == 0 && Nout % 128 == 0)
         launch_v2<128, 16, 1024, 3, 1, true>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);

@@ -233,10 +233,23 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
         ph[tm] = *reinterpret_cast<const bf16x8*>(Ah + p_off + tm * PWK * 32);
         pl[tm] = *reinterpret_cast<const bf16x8*>(Al + p_off + tm * PWK * 32);
       }
+#ifdef SCAN_EXP_PF  // timing experiment (make exp_pf): weight fragments of channel tile tn + 1 are read before the MFMAs of
+      // tile tn.  Measured against the default build, alternating processes on one box: 256-channel instance -1 % (towers
+      // 614 -> 624 us, conv3_x 1485 -> 1495), 128-channel instance +2 % (FCOS towers 291 -> 285) -- not adopted.
+      bf16x8 whn = *reinterpret_cast<const bf16x8*>(bh), wln = *reinterpret_cast<const bf16x8*>(bl);
+#endif
 #pragma unroll
       for (int tn = 0; tn < TN; ++tn) {
+#ifdef SCAN_EXP_PF
+        const bf16x8 whv = whn, wlv = wln;
+        if (tn + 1 < TN) {
+          whn = *reinterpret_cast<const bf16x8*>(bh + (tn + 1) * 16 * 32);
+          wln = *reinterpret_cast<const bf16x8*>(bl + (tn + 1) * 16 * 32);
+        }
+#else
         const bf16x8 whv = *reinterpret_cast<const bf16x8*>(bh + tn * 16 * 32);
         const bf16x8 wlv = *reinterpret_cast<const bf16x8*>(bl + tn * 16 * 32);
+#endif
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, pl[tm], acc[tm][tn], 0, 0, 0);

@@ -41,16 +41,43 @@ PEAK_FP32_MFMA_TFLOPS = 157.3
 PEAK_BF16X3_TFLOPS = 2500.0 / 3.0
 
 
+def csrc_sha1():
+    """sha1 over the kernel sources (scan_amd/csrc/*.hip, *.h, *.cpp): what a committed PMC pass is valid for."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(glob.glob(os.path.join(ROOT, "scan_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "scan_amd", "csrc", "*.h"))
+                    + glob.glob(os.path.join(ROOT, "scan_amd", "csrc", "*.cpp"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()
+
+
 def pmc_traffic(kernel_name):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
-    (profiles/r02_pmc_traffic.json, written by tools/pmc_summarize.py; FETCH_SIZE doubled per the gfx950 correction),
-    keyed by the kernel symbol.  None if not recorded."""
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command (profiles/rNN_pmc_traffic.json,
+    written by tools/pmc_summarize.py; FETCH_SIZE doubled per the gfx950 correction), keyed by the kernel symbol.
+    The file is stamped with the commit and the kernel-source hash it was taken at: a pass taken on OTHER kernel sources
+    is not reported (traffic = None, the note says why), so the figure cannot go stale silently.
+    Returns (bytes or None, provenance dict)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))
+    if not files:
+        return None, {"traffic_source": None}
+    path = files[-1]
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as f:
-            rec = json.load(f).get(kernel_name)
-        return rec["hbm_bytes"] if rec else None
+        with open(path) as f:
+            d = json.load(f)
     except Exception:
-        return None
+        return None, {"traffic_source": os.path.relpath(path, ROOT), "traffic_note": "unreadable"}
+    meta = d.get("_meta", {})
+    prov = {"traffic_source": os.path.relpath(path, ROOT), "traffic_commit": meta.get("commit"),
+            "traffic_csrc_sha1": meta.get("csrc_sha1")}
+    if meta.get("csrc_sha1") != csrc_sha1():
+        prov["traffic_note"] = "PMC pass is from other kernel sources than this build (csrc sha1 differs): not reported"
+        return None, prov
+    rec = d.get(kernel_name)
+    prov["traffic_note"] = "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at that commit"
+    return (rec["hbm_bytes"] if rec else None), prov
 
 
 # timer record name (scan_amd/ops.py) -> kernel symbol as rocprofv3 lists it: forward and data-gradient launches of
@@ -152,11 +179,34 @@ def _free_port():
         return s_.getsockname()[1]
 
 
+def visible_gpus():
+    """GPUs this process tree may use, counted WITHOUT opening the GPU: kfd topology nodes with SIMDs (CPU nodes have
+    simd_count 0), cut down by ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES.  None if sysfs has
+    no kfd topology (then the caller falls back to torch.cuda.device_count())."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(l.split(None, 1) for l in f.read().splitlines() if " " in l)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a torch.distributed.run environment: become the launcher.  Nothing here
-    initialises the GPU (device_count() does not), the ranks are fresh child processes."""
-    import torch
-    n_vis = torch.cuda.device_count()
+    opens the GPU (devices are counted from sysfs), the ranks are fresh child processes."""
+    n_vis = visible_gpus()
+    if n_vis is None:
+        import torch
+        n_vis = torch.cuda.device_count()
     if n_vis < a.gpus and not a.launch_check:
         raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible -- refusing to measure fewer ranks than asked for"
                          % (a.gpus, n_vis))
@@ -189,6 +239,9 @@ def main():
                     help="target pass with DBSCAN node sampling + GST losses (reference: once val AP50 > INITIAL_AP50); "
                          "the headline metric uses False like the reference's first phase")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-companions", action="store_true",
+                    help="skip the companion legs of the line (strict fp32-MFMA steps, the three-phase schedule, inference)")
+    ap.add_argument("--strict-steps", type=int, default=10, help="timed steps of the strict fp32-MFMA companion leg")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run everything on one stream (no side-stream overlap): what the per-kernel roofline "
                          "figures and the rocprof summaries under profiles/ are taken with")
@@ -301,6 +354,89 @@ def main():
     ksum = ops.kernel_timer.summary()
     finite = all(bool(torch.isfinite(v)) for v in losses.values())
 
+    # ---- companion legs (N = 1, headline model only): same frames, same trainer, outside the timed region
+    strict = three_phase = infer = None
+    if world == 1 and not a.no_companions and not a.forward_target:
+        # (a) the SAME step with every convolution on the exact fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32 /
+        # 16x16x4_f32 = an fp32 fma chain, the reference's arithmetic): what the headline costs without the bf16 split
+        set_serial(a.serial_streams)
+        ops.CONV_MODE = "fp32"
+        try:
+            for _ in range(2):
+                trainer.step(imgs_s, tg, imgs_t)
+            torch.cuda.synchronize()
+            t0s = time.time()
+            for _ in range(a.strict_steps):
+                ls = trainer.step(imgs_s, tg, imgs_t)
+            torch.cuda.synchronize()
+            dts = (time.time() - t0s) / a.strict_steps
+            set_serial(True)
+            trainer.step(imgs_s, tg, imgs_t)
+            torch.cuda.synchronize()
+            ops.kernel_timer.enabled = True
+            ops.kernel_timer.reset()
+            trainer.step(imgs_s, tg, imgs_t)
+            torch.cuda.synchronize()
+            ops.kernel_timer.enabled = False
+            ks = by_symbol(ops.kernel_timer.summary())
+            sdom = max(ks.items(), key=lambda kv: kv[1]["total_ms"])
+            strict = {"dtype": "f32 (exact fp32 MFMA, v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
+                      "ms_per_step": round(dts * 1e3, 2), "pairs_per_s": round(B / dts, 4), "steps": a.strict_steps,
+                      "dominant_kernel": sdom[0], "dominant_tflops": round(sdom[1]["tflops"], 2),
+                      "frac_of_157.3": round(sdom[1]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
+                      "dominant_avg_launch_ms": round(sdom[1]["avg_ms"], 4), "dominant_launches": sdom[1]["launches"],
+                      "losses_finite": all(bool(torch.isfinite(v)) for v in ls.values())}
+        finally:
+            ops.CONV_MODE = "bf16x3"
+            set_serial(a.serial_streams)
+        # (b) the reference's three-phase schedule (source forward/backward, target forward/backward as separate
+        # pyramids): what do_train runs when source and target batches pad to different sizes
+        trainer.paired = False
+        try:
+            for _ in range(2):
+                trainer.step(imgs_s, tg, imgs_t)
+            torch.cuda.synchronize()
+            t0p = time.time()
+            for _ in range(a.steps):
+                trainer.step(imgs_s, tg, imgs_t)
+            torch.cuda.synchronize()
+            dtp = (time.time() - t0p) / a.steps
+            three_phase = {"ms_per_step": round(dtp * 1e3, 2), "pairs_per_s": round(B / dtp, 4), "steps": a.steps,
+                           "note": "Trainer.step with paired=False: the schedule real ragged batches take"}
+        finally:
+            trainer.paired = True
+        # (c) inference on the same frames (engine.inference: backbone + middle head + FCOS head + post-processing +
+        # batched NMS, TEST.MODE of the yaml), and the NMS launch alone on the last image's candidate set
+        import scan_amd.modeling.fcos as fcos_mod
+        frames = imgs_t
+        for _ in range(2):
+            dets = engine.inference(model, frames)
+        torch.cuda.synchronize()
+        n_inf = max(3, a.steps)
+        t0i = time.time()
+        for _ in range(n_inf):
+            dets = engine.inference(model, frames)
+        torch.cuda.synchronize()
+        dti = (time.time() - t0i) / n_inf
+        nms_rec = fcos_mod.last_nms_record()
+        infer = {"images_per_s": round(B / dti, 3), "ms_per_batch": round(dti * 1e3, 2), "batch": B,
+                 "test_mode": mcfg["test_mode"], "detections_per_image": [int(len(d[0])) for d in dets]}
+        if nms_rec is not None:
+            boxes_n, scores_n, labels_n, thr = nms_rec
+            n_c = int(boxes_n.shape[0])
+            if n_c > 0:
+                for _ in range(3):
+                    ops.nms_by_label(boxes_n, scores_n, labels_n, thr)
+                torch.cuda.synchronize()
+                t0n = time.time()
+                for _ in range(20):
+                    ops.nms_by_label(boxes_n, scores_n, labels_n, thr)
+                torch.cuda.synchronize()
+                infer["nms_us_per_image"] = round((time.time() - t0n) / 20 * 1e6, 1)
+            infer["n_candidates"] = n_c
+        for m_ in model.values():
+            m_.train()
+
     if rank == 0:
         pairs = B * world * a.steps
         value = pairs / dt
@@ -308,9 +444,9 @@ def main():
         roof = None
         if dom:
             name, r = dom
+            traffic, prov = pmc_traffic(name)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(r["tflops"], 2), "peak": round(peak_for(name), 1),
-                    "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_for(name), 4), "traffic": pmc_traffic(name),
-                    "traffic_note": "HBM bytes per launch, rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes (profiles/r02_pmc_traffic.json)",
+                    "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_for(name), 4), "traffic": traffic,
                     "peak_note": "algorithmic fp32-equivalent FLOPs; bf16x3 kernels spend 3 bf16 MFMAs per product, "
                                  "peak = 2.5 PFLOP/s dense bf16 / 3",
                     "launches": r["launches"], "avg_launch_ms": round(r["avg_ms"], 4),
@@ -321,6 +457,7 @@ def main():
                                              "launches": v["launches"],
                                              "share_of_serial_step": round(v["total_ms"] / (dtr * 1e3), 3)}
                                          for k, v in ksum.items()}}
+            roof.update(prov)
         pointwise = None
         if not a.no_pointwise and world == 1:
             from tools import pointwise_roofline
@@ -348,7 +485,10 @@ def main():
             "value": round(value, 4),
             "unit": "image pairs/s (1 source + 1 target frame per pair)", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
-            "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": a.scaling, "vs_baseline": None,
+            "dtype": "bf16x3 (fp32 storage + fp32 accumulate; every conv operand split hi+lo into 2 bf16, 3 bf16 MFMAs per "
+                     "product = 16 significand bits per operand; strict fp32-MFMA figure: strict_fp32)",
+            "data": "synthetic",
             "config": {"workload": "SCAN %s %s DA iteration, %d src + %d tgt frames/GPU at %dx%d, "
                                    "forward_target=%s, procedural weights" % (a.model.upper(), body, B, B, H, W, a.forward_target),
                        "arithmetic": "fp32 storage and accumulation; 3x3 convs split each fp32 operand hi+lo into "
@@ -358,6 +498,7 @@ def main():
                        "collective_backend": dist.get_backend() if dist.is_initialized() else None,
                        "losses_finite": finite},
             "roofline": roof, "roofline_pointwise": pointwise, "cpu_baseline": cpu,
+            "strict_fp32": strict, "three_phase_schedule": three_phase, "inference": infer,
         }
         # RCCL prints a version banner through C stdio, which is still buffered here when stdout is a pipe: push it
         # out first so the JSON line is the LAST line on stdout

@@ -66,6 +66,8 @@ int scan_abi_version(void);
  *   "conv_glds"   1 (default): the 16-wave 128- / 256-channel 3x3 instances stage weight tiles by LDS-DMA
  *                 (global_load_lds_dwordx4) on whole tiles; 0: through registers.  Same results bit for bit. */
 int scan_tune(const char* key, int value);
+/* read-only: the current value of a knob (nothing is written), -1 for an unknown key */
+int scan_tune_get(const char* key);
 
 /* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels;
  * 1128 / 1256 = the 128- / 256-channel tile on 16-wave workgroups. */

@@ -715,6 +715,8 @@ def main():
         gen_step(a.check, H=256, W=512, name="step_ft_256x512", forward_target=True)
     if "step_pad" in todo:  # ragged batch, zero-padded to 352x512 by to_image_list(.., 32)
         gen_step(a.check, name="step_pad_333x500", sizes=[(333, 500), (320, 480)])
+    if "step_cfg2" in todo:  # BASELINE.json configs[1], the bench workload itself: 2 src + 2 tgt frames at 1024x2048
+        gen_step(a.check, H=1024, W=2048, N=2, name="step_cfg2_1024x2048")
     if "step_cfg5" in todo:  # BASELINE.json configs[4] frame: 1333x2666 padded to 1344x2688
         gen_step(a.check, name="step_cfg5_1333x2666", sizes=[(1333, 2666)])
     if "step_s2c" in todo:  # BASELINE.json configs[2]: Sim10k->Cityscapes, NUM_CLASSES 2, TRANSFER_CFG (None,)

@@ -9,9 +9,36 @@
 
 // ------------------------------------------------------------------ bf16 hi / lo planes of many weights
 // job layout (int64 x SCAN_SPLIT_JOB_WORDS, device memory): w, wh, wl, O, T, Cs, mode, rows, Csw, first block
+//
+// HBM-bound byte work: 4 B read + 4 B written per plane element.  Both modes move 16 bytes per lane on the plane side
+// (8 bf16) and float4 on the weight side:
+//   mode 0 (forward planes, out[o][t][c]): a thread owns 8 consecutive plane elements of one row -- two float4 reads
+//          (the row is contiguous in the weight), one 16-byte store per plane.
+//   mode 1 (data-gradient planes, out[c][T-1-t][o]: flip + transpose): per tap a [O][Cs] -> [Cs][O] transpose.  Read
+//          along c and written along o directly, consecutive lanes were T*Cs floats apart on the read side and stored
+//          2-byte scalars: PMC showed 16x the algorithmic bytes fetched (profiles/r02_pmc_traffic.json).  Now a
+//          workgroup moves a 64 (o) x 64 (c) tile of one tap through LDS: float4 reads along c (256 B per weight row),
+//          a conflict-free transposed LDS read (pitch 65), 16-byte stores along o.
+// Same element arithmetic as weight_split_kernel (conv_bf16x3.hip): bit-identical planes.
 #define SPLIT_ELEMS_PER_BLOCK 2048
+#define SPLIT_TILE 64
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split8_store(const float (&v)[8], __bf16* __restrict__ wh, __bf16* __restrict__ wl,
+                                             int64_t i) {
+  bf16x8_t h, l;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const __bf16 hk = (__bf16)v[k];
+    h[k] = hk;
+    l[k] = (__bf16)(v[k] - (float)hk);
+  }
+  *reinterpret_cast<bf16x8_t*>(wh + i) = h;
+  *reinterpret_cast<bf16x8_t*>(wl + i) = l;
+}
 
 __global__ __launch_bounds__(256) void weight_split_batched_kernel(const int64_t* __restrict__ jobs, int n_jobs) {
+  __shared__ float tile[SPLIT_TILE][SPLIT_TILE + 1];
   // the job of this block: last job whose first block <= blockIdx.x (jobs are few: a short scan by every thread)
   int j = 0;
   for (int i = 1; i < n_jobs; ++i)
@@ -22,31 +49,76 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const int64_t
   __bf16* __restrict__ wl = reinterpret_cast<__bf16*>(job[2]);
   const int O = (int)job[3], T = (int)job[4], Cs = (int)job[5], mode = (int)job[6], rows = (int)job[7],
             Csw = (int)job[8];
-  const int64_t total = (int64_t)rows * T * Csw;
-  const int64_t base = ((int64_t)blockIdx.x - job[9]) * SPLIT_ELEMS_PER_BLOCK;
-#pragma unroll
-  for (int k = 0; k < SPLIT_ELEMS_PER_BLOCK / 256; ++k) {
-    const int64_t i = base + k * 256 + threadIdx.x;
-    if (i >= total) break;
+  const int64_t blk = (int64_t)blockIdx.x - job[9];
+  const int tid = threadIdx.x;
+  if (mode == 0) {
+    // plane rows are Csw (a multiple of 8) long, so an 8-element group never straddles two rows
+    const int64_t total = (int64_t)rows * T * Csw;
+    const int64_t i = blk * SPLIT_ELEMS_PER_BLOCK + (int64_t)tid * 8;
+    if (i >= total) return;
     const int col = (int)(i % Csw);
-    const int64_t rt = i / Csw;
-    const int tt = (int)(rt % T);
-    const int row = (int)(rt / T);
-    float v = 0.f;
-    if (mode == 0) {
-      if (col < Cs) v = w[((int64_t)row * T + tt) * Cs + col];
+    const int64_t rt = i / Csw;  // row * T + tt
+    const float* src = w + rt * Cs + col;
+    float v[8];
+    if (col + 8 <= Cs && (Cs & 3) == 0) {
+      const float4 a = *reinterpret_cast<const float4*>(src);
+      const float4 b = *reinterpret_cast<const float4*>(src + 4);
+      v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+      v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
     } else {
-      if (col < O) v = w[((int64_t)col * T + (T - 1 - tt)) * Cs + row];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] = (col + k < Cs) ? src[k] : 0.f;
     }
-    const __bf16 h = (__bf16)v;
-    wh[i] = h;
-    wl[i] = (__bf16)(v - (float)h);
+    split8_store(v, wh, wl, i);
+    return;
+  }
+  // mode 1: block -> (tap tt of the OUTPUT, c tile, o tile)
+  const int tiles_o = (Csw + SPLIT_TILE - 1) / SPLIT_TILE, tiles_c = (rows + SPLIT_TILE - 1) / SPLIT_TILE;
+  const int to = (int)(blk % tiles_o);
+  const int tc = (int)((blk / tiles_o) % tiles_c);
+  const int tt = (int)(blk / ((int64_t)tiles_o * tiles_c));
+  const int o0 = to * SPLIT_TILE, c0 = tc * SPLIT_TILE;
+  {  // read: 16 lanes x float4 along c per weight row, 16 rows per pass
+    const int cl = (tid & 15) * 4, ol = tid >> 4;
+#pragma unroll
+    for (int p = 0; p < SPLIT_TILE / 16; ++p) {
+      const int o = o0 + ol + 16 * p, c = c0 + cl;
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (o < O && c < Cs) {
+        const float* src = w + ((int64_t)o * T + (T - 1 - tt)) * Cs + c;
+        if (c + 4 <= Cs && (Cs & 3) == 0) {
+          a = *reinterpret_cast<const float4*>(src);
+        } else {
+          a.x = src[0];
+          if (c + 1 < Cs) a.y = src[1];
+          if (c + 2 < Cs) a.z = src[2];
+          if (c + 3 < Cs) a.w = src[3];
+        }
+      }
+      float* t = &tile[ol + 16 * p][cl];
+      t[0] = a.x; t[1] = a.y; t[2] = a.z; t[3] = a.w;
+    }
+  }
+  __syncthreads();
+  {  // write: 8 lanes x 8 bf16 along o per plane row, 32 rows per pass; LDS address (o8 + k) * 65 + c: conflict-free
+    const int o8 = (tid & 7) * 8, cl = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < SPLIT_TILE / 32; ++p) {
+      const int c = c0 + cl + 32 * p, o = o0 + o8;
+      if (c < rows && o < Csw) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = tile[o8 + k][cl + 32 * p];
+        split8_store(v, wh, wl, ((int64_t)c * T + tt) * Csw + o);
+      }
+    }
   }
 }
 
 extern "C" int64_t scan_weight_split_job_blocks(int32_t O, int32_t T, int32_t Cs, int32_t mode, int32_t Csw) {
-  const int64_t rows = mode == 0 ? O : Cs;
-  return (rows * T * Csw + SPLIT_ELEMS_PER_BLOCK - 1) / SPLIT_ELEMS_PER_BLOCK;
+  if (mode == 0) return ((int64_t)O * T * Csw + SPLIT_ELEMS_PER_BLOCK - 1) / SPLIT_ELEMS_PER_BLOCK;
+  const int64_t tiles_o = (Csw + SPLIT_TILE - 1) / SPLIT_TILE, tiles_c = (Cs + SPLIT_TILE - 1) / SPLIT_TILE;
+  return tiles_o * tiles_c * T;
 }
 
 extern "C" int scan_weight_split_batched(const int64_t* jobs, int32_t n_jobs, int64_t total_blocks, void* stream) {

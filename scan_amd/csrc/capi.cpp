@@ -29,9 +29,9 @@ extern int g_scan_conv_bn64_th16;
 extern int g_scan_gconv_mfma;
 extern int g_scan_wgrad_wgs;
 extern int g_scan_conv_glds;
+extern int g_scan_wgrad_exp;
 
-extern "C" int scan_tune(const char* key, int value) {
-  if (key == nullptr) return -1;
+static int* tune_slot(const char* key) {
   int* slot = nullptr;
   if (strcmp(key, "conv_bn256") == 0) slot = &g_scan_conv_bn256;
   if (strcmp(key, "conv_v2") == 0) slot = &g_scan_conv_v2;
@@ -44,8 +44,22 @@ extern "C" int scan_tune(const char* key, int value) {
   if (strcmp(key, "gconv_mfma") == 0) slot = &g_scan_gconv_mfma;
   if (strcmp(key, "wgrad_wgs") == 0) slot = &g_scan_wgrad_wgs;
   if (strcmp(key, "conv_glds") == 0) slot = &g_scan_conv_glds;
+  if (strcmp(key, "wgrad_exp") == 0) slot = &g_scan_wgrad_exp;
+  return slot;
+}
+
+extern "C" int scan_tune(const char* key, int value) {
+  if (key == nullptr) return -1;
+  int* slot = tune_slot(key);
   if (slot == nullptr) return -1;
   const int old = *slot;
   *slot = value;
   return old;
+}
+
+// read-only: the current value of a knob, -1 for an unknown key (nothing is written)
+extern "C" int scan_tune_get(const char* key) {
+  if (key == nullptr) return -1;
+  const int* slot = tune_slot(key);
+  return slot == nullptr ? -1 : *slot;
 }

@@ -898,7 +898,11 @@ __device__ __forceinline__ void wgrad_mma_v2(const __bf16* Ah, const __bf16* Al,
 
 // NT = 512: 8 waves = 2 (o) x 4 (c), each 64 o x 32 c; NT = 1024: 16 waves = 4 x 4, each 32 o x 32 c (48 accumulator
 // registers, <= 128 registers per lane: four waves per SIMD to hide the staging phases and the transposed-read latency)
-template <int KX, int S, int NT>
+// EXP != 0: TIMING ABLATIONS ONLY (wrong results), selected by scan_tune "wgrad_exp" and never by default:
+//   1 every split-K slab walks the chunk range of slab 0 (operands hot in L2: what the memory side costs);
+//   2 no MFMA phase (loads + staging + barriers only);  3 loads and staging for the first chunk only (MFMA phase +
+//   barriers only);  4 global loads for the first chunk only, the split + LDS writes stay (what waiting for loads costs).
+template <int KX, int S, int NT, int EXP = 0>
 __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v2_kernel(
     const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
     float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
@@ -924,7 +928,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v2_k
   const int o_tile = tile / KX;
   const int o0 = o_tile * 128, c0 = c_tile * 128;
   const long long total_chunks = ct.chunk_off[d.n_levels];
-  const long long ch_begin = (long long)split * chunks_per_split;
+  const long long ch_begin = EXP == 1 ? 0 : (long long)split * chunks_per_split;
   long long ch_end = ch_begin + chunks_per_split;
   if (ch_end > total_chunks) ch_end = total_chunks;
   const bool do_bias = (bias_slab != nullptr) && ky == HALO && c_tile == 0;
@@ -1028,11 +1032,12 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v2_k
   const __bf16* Bh = Al + WK * WROW;
   const __bf16* Bl = Bh + (WK + KX - 1) * WROW;
   for (long long ch = ch_begin; ch < ch_end; ++ch) {
-    store_chunk();
-    if (ch + 1 < ch_end) load_chunk(ch + 1);
+    if (EXP != 3 || ch == ch_begin) store_chunk();
+    if (EXP != 3 && EXP != 4 && ch + 1 < ch_end) load_chunk(ch + 1);
     __syncthreads();
     // wave-uniform skips of dead tiles (third c tile of Cin = 264 / 265; Cout = 8 / 5 / 1 heads)
-    if (TOMAX == 4 && c_act && o_left > 32)
+    if (EXP == 2) {
+    } else if (TOMAX == 4 && c_act && o_left > 32)
       wgrad_mma_v2<TOMAX, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
     else if (c_act && o_left > 16)
       wgrad_mma_v2<2, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
@@ -1330,6 +1335,8 @@ int g_scan_wgrad_v2 = 2;
 int g_scan_wgrad_wg1024 = 2;
 // scan_tune "wgrad_v3": 1 = the double-buffered, staggered 16x16x32 weight-gradient kernel for the 3x3 convs
 int g_scan_wgrad_v3 = 0;
+// scan_tune "wgrad_exp": timing ablations of the 16x16x32 weight-gradient kernel (wrong results; see the kernel)
+int g_scan_wgrad_exp = 0;
 static inline bool wgrad_use_v2(int Cs) { return g_scan_wgrad_v2 == 1 || (g_scan_wgrad_v2 == 2 && Cs % 128 == 0); }
 // 2 = the 16x16x32 weight-gradient kernel, 1 = the 32x32x16 one, for an input channel stride Cs (bench.py labels)
 extern "C" int scan_conv_wgrad_bf16x3_generation(int32_t Cs) { return wgrad_use_v2(Cs) ? 2 : 1; }
@@ -1457,7 +1464,22 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
       done2 = true;
     }
-    if (g_scan_wgrad_wg1024 == 1)
+    if (g_scan_wgrad_exp >= 1 && g_scan_wgrad_exp <= 4) {
+      static bool donex = false;
+      if (!donex) {
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1, 512, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1, 512, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1, 512, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<3, 1, 512, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        donex = true;
+      }
+#define SCAN_WG_EXP(E) hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<3, 1, 512, E>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout, Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d)
+      if (g_scan_wgrad_exp == 1) SCAN_WG_EXP(1);
+      else if (g_scan_wgrad_exp == 2) SCAN_WG_EXP(2);
+      else if (g_scan_wgrad_exp == 3) SCAN_WG_EXP(3);
+      else SCAN_WG_EXP(4);
+#undef SCAN_WG_EXP
+    } else if (g_scan_wgrad_wg1024 == 1)
       hipLaunchKernelGGL((conv_wgrad_bf16x3_v2_kernel<3, 1, 1024>), dim3(nt * sp), dim3(1024), sh, st, x, *d, Cs, dy, Cout,
                          Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
     else

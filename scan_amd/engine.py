@@ -171,8 +171,10 @@ class FlatGroup:
         self._order = wts + bss  # layout of the flat buffers
         self._named_order = [n for n, _ in params]  # the reference optimizer's parameter order
         off = 0
-        for _, p in wts + bss:
+        self.offset = {}  # parameter name -> (offset, numel) in the flat buffers
+        for pname, p in wts + bss:
             n = p.numel()
+            self.offset[pname] = (off, n)
             stride = p.data.stride()
             view = self.flat_p[off:off + n].as_strided(p.shape, stride)
             view.copy_(p.data)
@@ -196,7 +198,9 @@ class FlatGroup:
             yield name, p, self.flat_m[off:off + n].as_strided(p.shape, p.data.stride())
             off += n
 
-    def optimizer_state_dict(self):
+    def optimizer_state_dict(self, lr_factor=1.0):
+        """lr_factor: the scheduler's current factor -- torch's param_groups hold the SCHEDULED lr next to
+        ``initial_lr`` (what WarmupMultiStepLR leaves in a checkpoint the reference writes)."""
         by_name = {name: (p, m) for name, p, m in self._logical()}
         state, groups = {}, []
         for i, name in enumerate(self._named_order):
@@ -204,7 +208,8 @@ class FlatGroup:
             bias = "bias" in name
             if not self.first and m is not None:
                 state[i] = {"momentum_buffer": m.detach().clone().contiguous().cpu()}
-            groups.append({"lr": self.lr * (self.bias_lr_factor if bias else 1.0),
+            base = self.lr * (self.bias_lr_factor if bias else 1.0)
+            groups.append({"lr": base * lr_factor, "initial_lr": base,
                            "weight_decay": self.wd_bias if bias else self.wd, "momentum": self.momentum, "dampening": 0,
                            "nesterov": False, "params": [i]})
         return {"state": state, "param_groups": groups}
@@ -262,6 +267,36 @@ def warmup_factor(iteration, warmup_iters=1000, factor=1.0 / 3, steps=(60000, 80
     return f * gamma ** sum(1 for s in steps if s <= iteration)
 
 
+def _transfer_active(model):
+    """True when a forward_target iteration CAN yield the GST loss (TRANSFER_CFG set).  Whether it does depends on the
+    rank's own target batch (DBSCAN may sample no node), and comm.reduce_loss_dict stacks the scalars in sorted-key
+    order: a key present on one rank only would mis-size the reduce.  The step therefore always emits
+    ``consistency_loss_gt`` in that configuration -- a zero scalar (no gradient) when this rank sampled nothing."""
+    t = model["middle_head"].transfer_cfg
+    return bool(t) and t[0] is not None
+
+
+def _merge_ranges(rngs):
+    out = []
+    for a, b in sorted(rngs):
+        if out and a <= out[-1][1]:
+            out[-1] = (out[-1][0], max(out[-1][1], b))
+        else:
+            out.append((a, b))
+    return out
+
+
+def _complement(rngs, lo, hi):
+    out, cur = [], lo
+    for a, b in rngs:
+        if a > cur:
+            out.append((cur, a))
+        cur = max(cur, b)
+    if cur < hi:
+        out.append((cur, hi))
+    return out
+
+
 # trainable parameters of a sub-model that get no gradient on this path (see FlatGroup: skip)
 NO_GRAD_PARAMS = {"middle_head": ("cond_2.",)}
 
@@ -300,8 +335,13 @@ class Trainer:
                                  gamma=sv["gamma"], method=sv["warmup_method"])
         self.iteration = 0
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
-        self.comm_stream = torch.cuda.Stream() if self.distributed else None
+        self.comm_stream = torch.cuda.Stream() if self.distributed and dev0.type == "cuda" else None
+        if hasattr(model["backbone"], "record_grad_marks"):
+            model["backbone"].record_grad_marks = bool(self.distributed)
         self._pending = []
+        self._bucket_list = None
+        self._issued, self._ready = 0, set()
+        self.collective_log = []  # (lo, hi) of every gradient all-reduce issued, in order (tests; cleared per step)
         self._split_plan = ops.SplitPlan()  # the conv weights re-split at the start of every iteration, in one launch
         # The five CKA discriminators are independent; P4..P7 have 16 K ... 256 pixel rows, far too few tiles to
         # fill 256 CUs, so they run on side HIP streams next to P3 (autograd replays each backward on the stream
@@ -320,20 +360,121 @@ class Trainer:
         """all-reduce the flat gradient buffers of sub-models whose gradients are final, on the side stream."""
         if not self.distributed:
             return
+        lo = min(self.arena_range[k][0] for k in keys)
+        hi = max(self.arena_range[k][1] for k in keys)
+        assert sum(b - a for a, b in (self.arena_range[k] for k in keys)) == hi - lo, "keys must be contiguous in the arena"
+        self._allreduce_range(lo, hi, after_side_streams)
+
+    def _allreduce_range(self, lo, hi, after_side_streams=False):
+        """average grad_arena[lo:hi] over the ranks on the side stream.  The kernels that wrote the range (weight
+        gradients go straight into the arena, bypassing AccumulateGrad) were launched on the current stream -- or on
+        the side streams (after_side_streams) -- before this call: the comm stream is ordered after them."""
+        if not self.distributed or hi <= lo:
+            return
+        ws = dist.get_world_size()
+        self.collective_log.append((lo, hi))
+        if self.comm_stream is None:  # host tensors (the gloo tests of the bucket logic): no streams to order
+            g = self.grad_arena[lo:hi]
+            g.div_(ws)
+            dist.all_reduce(g)
+            return
         self.comm_stream.wait_stream(torch.cuda.current_stream())
         if after_side_streams:  # kernels that accumulate into these buffers were queued on the side streams
             for s in self.dis_streams.values():
                 self.comm_stream.wait_stream(s)
             if self.tgt_stream is not None:
                 self.comm_stream.wait_stream(self.tgt_stream)
-        ws = dist.get_world_size()
-        lo = min(self.arena_range[k][0] for k in keys)
-        hi = max(self.arena_range[k][1] for k in keys)
-        assert sum(b - a for a, b in (self.arena_range[k] for k in keys)) == hi - lo, "keys must be contiguous in the arena"
         with torch.cuda.stream(self.comm_stream):
             g = self.grad_arena[lo:hi]
             g.div_(ws)
             self._pending.append(dist.all_reduce(g, async_op=True))
+
+    # ---- gradient buckets: the ranges of the arena in the order they become final during the backward, the SAME list
+    # on every rank and in both schedules (a collective sequence must not depend on a rank's batch shapes)
+    def _buckets(self):
+        """[(name, [(lo, hi), ...], after_side_streams)]: FCOS head | discriminators | middle head | backbone by
+        stage, last first (conv5, conv4 + FPN, then conv3 + all biases).  A backbone without stage marks (ResNet) is one
+        bucket."""
+        if self._bucket_list is not None:
+            return self._bucket_list
+        ar = self.arena_range
+        dis = [k for k in self.groups if k.startswith("dis_")]
+        out = [("fcos", [ar["fcos"]], True)]
+        if dis:
+            out.append(("dis", [(min(ar[k][0] for k in dis), max(ar[k][1] for k in dis))], True))
+        rest = [k for k in self.groups if k != "fcos" and k not in dis and k != "backbone"]
+        for k in rest:
+            out.append((k, [ar[k]], False))
+        if "backbone" in self.groups:
+            g, base = self.groups["backbone"], ar["backbone"][0]
+            stages = getattr(self.model["backbone"], "grad_stage_params", None)
+            if stages:  # [(mark name, [parameter names final when the mark's gradient arrives])], backward order
+                for mark, names in stages:
+                    rngs = _merge_ranges([(base + g.offset[n][0], base + g.offset[n][0] + g.offset[n][1])
+                                          for n in names if n in g.offset])
+                    if rngs:
+                        out.append(("backbone:" + mark, rngs, False))
+                covered = _merge_ranges([r for nm, rs, _ in out if nm.startswith("backbone:") for r in rs])
+                restr = _complement(covered, ar["backbone"][0], ar["backbone"][1])
+                out.append(("backbone:rest", restr, False))
+            else:
+                out.append(("backbone:rest", [ar["backbone"]], False))
+        self._bucket_list = out
+        return out
+
+    def _begin_buckets(self):
+        self._issued = 0
+        self._ready = set()
+
+    def _bucket_ready(self, name):
+        """a bucket's gradients are final.  Issue it -- and any following bucket that became ready out of order -- only
+        when every earlier bucket has been issued: the collective sequence is then the canonical one on every rank
+        whichever hooks fire (a hook that never fires is made up for by _flush_buckets after the backward)."""
+        if not self.distributed:
+            return
+        self._ready.add(name)
+        bl = self._buckets()
+        while self._issued < len(bl) and bl[self._issued][0] in self._ready:
+            _, rngs, side = bl[self._issued]
+            for lo, hi in rngs:
+                self._allreduce_range(lo, hi, side)
+            self._issued += 1
+
+    def _flush_buckets(self):
+        """after the backward (and _join_streams): everything not reduced yet, in canonical order."""
+        if not self.distributed:
+            return
+        bl = self._buckets()
+        while self._issued < len(bl):
+            _, rngs, side = bl[self._issued]
+            for lo, hi in rngs:
+                self._allreduce_range(lo, hi, side)
+            self._issued += 1
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+        if self.comm_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    def _hook_ready(self, tensor, name):
+        """issue bucket ``name`` when the gradient w.r.t. ``tensor`` has been computed (every backward node between the
+        losses and ``tensor`` has been launched by then)."""
+        if not self.distributed or tensor is None or not tensor.requires_grad:
+            return
+
+        def _h(grad):
+            self._bucket_ready(name)
+            return grad
+
+        tensor.register_hook(_h)
+
+    def _hook_backbone_marks(self):
+        """hooks on the marks the backbone's last forward left (modeling/backbone.py: VGG16FPN.grad_marks)."""
+        bb = self.model["backbone"]
+        for mark, t in getattr(bb, "grad_marks", {}).items():
+            self._hook_ready(t, "middle_head" if mark == "out" else "backbone:" + mark)
+        if hasattr(bb, "grad_marks"):
+            bb.grad_marks = {}
 
     def _discriminators(self, feats, maps, shape, label, domain, tag):
         """con_dis_lambda * dis_CON(feat[l], label, act_maps[l]) for the five levels (reference trainer.py:314-333,
@@ -392,7 +533,20 @@ class Trainer:
         """reference DetectronCheckpointer.save (utils/checkpoint.py:141-301): the model state_dicts plus
         optimizer_<sub-model> (torch.optim.SGD layout) and the iteration, so training resumes where it stopped."""
         from . import checkpoint
-        extra = {"optimizer_" + k: g.optimizer_state_dict() for k, g in self.groups.items()}
+        extra = {"optimizer_" + k: g.optimizer_state_dict(warmup_factor(self.iteration, **self.sched[k]))
+                 for k, g in self.groups.items()}
+        # scheduler_<sub-model> like DetectronCheckpointer (utils/checkpoint.py:247-295): WarmupMultiStepLR.state_dict()
+        # is the scheduler's __dict__ minus the optimizer; load_checkpoint reads last_epoch back
+        for k, g in self.groups.items():
+            sc = self.sched[k]
+            n_groups = len(g._named_order)
+            extra["scheduler_" + k] = {
+                "milestones": list(sc["steps"]), "gamma": sc["gamma"], "warmup_factor": sc["factor"],
+                "warmup_iters": sc["warmup_iters"], "warmup_method": sc["method"], "last_epoch": self.iteration,
+                "base_lrs": [g.lr * (g.bias_lr_factor if "bias" in n else 1.0) for n in g._named_order],
+                "_step_count": self.iteration + 1,
+                "_last_lr": [g.lr * (g.bias_lr_factor if "bias" in n else 1.0)
+                             * warmup_factor(self.iteration, **sc) for n in g._named_order][:n_groups]}
         mh = self.model["middle_head"]
         return checkpoint.save(self.model, save_dir, name, iteration=self.iteration,
                                proto_counter=mh.counter_rnn.counter, **extra)
@@ -462,6 +616,8 @@ class Trainer:
         losses = {"node_loss_gs": node_loss, "act_loss_gs": act_loss}
         if consistency is not None:
             losses["consistency_loss_gt"] = consistency
+        elif forward_target and _transfer_active(model):
+            losses["consistency_loss_gt"] = feats.new_zeros(())  # rank-invariant key set, see _transfer_active
         main = torch.cuda.current_stream()
         # the FCOS head (source rows) is independent of the discriminators: it takes the side stream the three-phase
         # schedule uses for the target forward and fills the tails of the P3 discriminator's kernels (~1.2 ms)
@@ -486,34 +642,32 @@ class Trainer:
             main.wait_stream(side)
         if fstream is not None:
             main.wait_stream(fstream)
-        dis_keys = [k for k in self.groups if k.startswith("dis_")]
         if self.distributed:
             # the backward reaches `feats` (and `maps`) only after every consumer -- the five discriminators and the
             # FCOS head -- has back-propagated: their gradient buffers (114 of the 199 MB) are final then and are
-            # reduced while the middle head and the backbone still run their backward
+            # reduced while the middle head and the backbone still run their backward; the middle head's buffer
+            # follows when the gradient reaches the backbone's output, the backbone's stage by stage (conv5, then
+            # conv4 + FPN) as the marks the backbone left on its stage outputs receive theirs
+            del self.collective_log[:]
+            self._begin_buckets()
             pending = {"n": 2}
 
             def _heads_done(grad):
                 pending["n"] -= 1
                 if pending["n"] == 0:
-                    self._allreduce_async(["fcos"], after_side_streams=True)
-                    self._allreduce_async(dis_keys)
+                    self._bucket_ready("fcos")
+                    self._bucket_ready("dis")
                 return grad
 
             feats.register_hook(_heads_done)
             maps.register_hook(_heads_done)
+            if not getattr(model["backbone"], "grad_marks", None):
+                self._hook_ready(rows, "middle_head")
+            self._hook_backbone_marks()
         sum(losses.values()).backward()
         self._join_streams()
         losses["zero_gt"] = feats.new_zeros(())
-        if self.distributed and pending["n"] > 0:  # a hook did not fire (no gradient path): reduce the heads now
-            self._allreduce_async(["fcos"])
-            self._allreduce_async(dis_keys)
-        self._allreduce_async([k for k in self.groups if k != "fcos" and k not in dis_keys])
-        if self.distributed:
-            for w in self._pending:
-                w.wait()
-            self._pending = []
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._flush_buckets()
         self._optimizer_step()
         return losses
 
@@ -557,7 +711,10 @@ class Trainer:
         out.update(loss_dict)
         out.update(ld)
         del loss_dict, feat_s, maps_s
-        self._allreduce_async(["fcos"])  # the target pass adds nothing to the FCOS head
+        if self.distributed:
+            del self.collective_log[:]
+            self._begin_buckets()
+            self._bucket_ready("fcos")  # the target pass adds nothing to the FCOS head
         # (3) target pass + discriminators on target
         if tgt is None:
             tgt = forward_detector(model, images_t, None, mode="target", forward_target=forward_target)
@@ -565,19 +722,32 @@ class Trainer:
             torch.cuda.current_stream().wait_stream(self.tgt_stream)
         loss_dict, feat_t, maps_t, shape = tgt
         ld = {k + "_gt": v for k, v in loss_dict.items()}
+        if forward_target and _transfer_active(model) and "consistency_loss_gt" not in ld:
+            ld["consistency_loss_gt"] = feat_t["P3"].new_zeros(())  # rank-invariant key set, see _transfer_active
         ld.update(self._discriminators(feat_t, maps_t, shape, 0.0, "target", "dt"))
+        if self.distributed:
+            # the same bucket list in the same order as step_paired: ranks holding differently shaped batches may take
+            # different schedules without mismatching a collective.  In this schedule the last contributions arrive
+            # with the target backward, so the hooks sit on the target pass's tensors.
+            pending = {"n": 2 * len(LEVELS)}
+
+            def _heads_done(grad):
+                pending["n"] -= 1
+                if pending["n"] == 0:
+                    self._bucket_ready("dis")
+                return grad
+
+            for lvl in LEVELS:
+                for t in (feat_t[lvl], maps_t[lvl]):
+                    if t.requires_grad:
+                        t.register_hook(_heads_done)
+                    else:
+                        pending["n"] -= 1
+            self._hook_backbone_marks()
         sum(v for k, v in ld.items() if k != "zero_gt").backward()
         self._join_streams()
         out.update(ld)
-        # same three ranges in the same order as step_paired ([fcos], [discriminators], [middle head + backbone]): ranks
-        # holding differently shaped batches may take different schedules without mismatching a collective
-        self._allreduce_async([k for k in self.groups if k.startswith("dis_")])
-        self._allreduce_async([k for k in self.groups if k != "fcos" and not k.startswith("dis_")])
-        if self.distributed:
-            for w in self._pending:
-                w.wait()
-            self._pending = []
-            torch.cuda.current_stream().wait_stream(self.comm_stream)
+        self._flush_buckets()
         self._optimizer_step()
         return out
 
@@ -685,8 +855,8 @@ def do_train(trainer, loader_source, loader_target, max_iter, val_dataset=None, 
                 trainer.save_checkpoint(save_dir, "model_{}_{:07d}".format(gate.best, it))
             for m in trainer.model.values():
                 m.train()
-        elif gate is None and checkpoint_period and it % checkpoint_period == 0 and save_dir is not None \
-                and comm.is_main_process():
+        elif (gate is None or not getattr(gate, "adapt_val_on", True)) and checkpoint_period \
+                and it % checkpoint_period == 0 and save_dir is not None and comm.is_main_process():
             trainer.save_checkpoint(save_dir, "model_{:07d}".format(it))
         if it == max_iter:
             if save_dir is not None and comm.is_main_process():

@@ -118,6 +118,21 @@ class VGG16FPN(nn.Module):
         super().__init__()
         self.body = VGGBody()
         self.fpn = FPN()
+        # data parallelism (engine.Trainer): tensors whose gradient marks the point of the backward at
+        # which a stage's parameter gradients are final, so their slice of the gradient arena can be all-reduced while
+        # the earlier stages still back-propagate.  Filled per forward when record_grad_marks is set (the trainer
+        # clears it after the step: the entries keep the autograd graph alive).
+        #   "out": the pyramid handed to the middle head -> the middle head's gradients are final
+        #   "c4":  stage-4 output (conv5_1 and fpn_inner4 have back-propagated) -> conv5_x weights
+        #   "c3":  stage-3 output (conv4_1 and fpn_inner3 have back-propagated) -> conv4_x and every FPN weight
+        self.record_grad_marks = False
+        self.grad_marks = {}
+        self.grad_stage_params = [
+            ("c4", ["body.features.%d.weight" % i for i in VGG_STAGES[4]]),
+            ("c3", ["body.features.%d.weight" % i for i in VGG_STAGES[3]]
+             + ["fpn.fpn_inner%d.weight" % l for l in (3, 4, 5)] + ["fpn.fpn_layer%d.weight" % l for l in (3, 4, 5)]
+             + ["fpn.top_blocks.p6.weight", "fpn.top_blocks.p7.weight"]),
+        ]
 
     def forward(self, images, rows=None, shape=None):
         """images [N,3,H,W]; or rows [N*H*W, 4] + its one-level PyramidShape (data.BatchCollator writes the batch in
@@ -127,7 +142,10 @@ class VGG16FPN(nn.Module):
                 raise RuntimeError("scan_amd backbone runs only on the GPU (HIP); no CPU fallback")
             rows, shape = ops.nchw_to_rows(images, 4)
         outs = self.body(rows, shape)
-        return self.fpn(outs[2], outs[3], outs[4])
+        out = self.fpn(outs[2], outs[3], outs[4])
+        if self.record_grad_marks and torch.is_grad_enabled():
+            self.grad_marks = {"out": out[0], "c4": outs[3][0], "c3": outs[2][0]}
+        return out
 
 
 def build_backbone(cfg=None):

@@ -232,6 +232,15 @@ class FCOSLossComputation:
         return cls_loss, reg_loss, ctr_loss
 
 
+_last_nms = [None]
+
+
+def last_nms_record():
+    """(boxes, scores, labels, threshold) of the most recent per-image NMS launch of the post-processor -- bench.py
+    re-times the NMS kernel alone on a real candidate set with it.  None before the first inference."""
+    return _last_nms[0]
+
+
 class FCOSPostProcessor:
     """reference inference.py:20-194; per-class NMS runs on the device (scan_nms)."""
 
@@ -296,6 +305,7 @@ class FCOSPostProcessor:
             # per-class NMS (reference inference.py:160-176 loops classes and calls boxlist_nms on each) as ONE
             # class-aware launch: a box is suppressed only by a kept, higher-scored box of the SAME label, which is
             # exactly greedy NMS run per class; output order = class-major, original index ascending within a class
+            _last_nms[0] = (boxes, scores, labels, self.nms_thresh)
             keep = ops.nms_by_label(boxes, scores, labels, self.nms_thresh).to(dev)
             keep = keep[torch.argsort(labels[keep], stable=True)]
             rb, rs, rl = boxes[keep], scores[keep], labels[keep]

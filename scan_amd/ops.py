@@ -1060,8 +1060,7 @@ class _GroupedConvTo1(torch.autograd.Function):
         y = x.new_empty((shape.rows, ns))
         ws = x.new_empty((query("scan_gconv3x3_to1_ws_floats", shape.ref(), G, 128),))
         bits = None
-        mfma = query("scan_tune", b"gconv_mfma", 1)  # read the knob: set, then put back what was there
-        query("scan_tune", b"gconv_mfma", mfma)
+        mfma = query("scan_tune_get", b"gconv_mfma")  # read-only: no write to the launch-selection state
         if mfma == 1 and mask_dx and torch.is_grad_enabled() and x.requires_grad:
             bits = torch.empty((shape.rows * G * 4,), dtype=torch.int32, device=x.device)
             call("scan_gconv3x3_to1_forward_bits", _ptr(x), shape.ref(), G, 128, _ptr(w), _ptr(bias), _ptr(y), ns,

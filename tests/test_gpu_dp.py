@@ -17,28 +17,38 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 STEPS, H, W = 2, 128, 128
 
 
-def _run(rank, world, same_shard, dev_index=0):
+def _batch(shard, dev):
+    from scan_amd import synth
+    return (synth.synth_images(1, H, W, 11 + 10 * shard).to(dev), synth.synth_targets(1, H, W, 8, 6, 13 + 10 * shard),
+            synth.synth_images(1, H, W, 12 + 10 * shard).to(dev))
+
+
+def _run(rank, world, same_shard, dev_index=0, steps=STEPS, mixed_schedules=False):
     from scan_amd import engine, synth
     dev = torch.device("cuda", dev_index)
     torch.cuda.set_device(dev)
     model = engine.build_model(9, device=dev, attn_dropout=0.0)
     engine.load_procedural_weights(model)
     trainer = engine.Trainer(model, distributed=True if world > 1 else None)
+    if mixed_schedules:  # rank 0: source + target frames as one pyramid; rank 1: the reference's three phases
+        trainer.paired = rank == 0
     shard = 0 if same_shard else rank
     imgs_s = synth.synth_images(1, H, W, 11 + 10 * shard).to(dev)
     imgs_t = synth.synth_images(1, H, W, 12 + 10 * shard).to(dev)
     tg = synth.synth_targets(1, H, W, 8, 6, 13 + 10 * shard)
-    for _ in range(STEPS):
+    for _ in range(steps):
         losses = trainer.step(imgs_s, tg, imgs_t)
     torch.cuda.synchronize()
     assert all(bool(torch.isfinite(v)) for v in losses.values())
     out = {k: g.flat_p.detach().cpu().clone() for k, g in trainer.groups.items()}
+    if world > 1:
+        out["collective_log"] = torch.tensor(trainer.collective_log, dtype=torch.int64)
     out["momentum_backbone"] = trainer.groups["backbone"].flat_m.detach().cpu().clone()
     out["prototype"] = model["middle_head"].prototype.detach().cpu().clone()
     return out
 
 
-def _worker(rank, world, port, same_shard, outdir, backend="gloo"):
+def _worker(rank, world, port, same_shard, outdir, backend="gloo", steps=STEPS, mixed_schedules=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -49,17 +59,19 @@ def _worker(rank, world, port, same_shard, outdir, backend="gloo"):
     else:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        torch.save(_run(rank, world, same_shard, rank if backend == "nccl" else 0),
+        torch.save(_run(rank, world, same_shard, rank if backend == "nccl" else 0, steps, mixed_schedules),
                    os.path.join(outdir, "rank%d.pt" % rank))
         dist.barrier()
     finally:
         dist.destroy_process_group()
 
 
-def _spawn(same_shard, outdir, backend="gloo"):
+def _spawn(same_shard, outdir, backend="gloo", steps=STEPS, mixed_schedules=False):
     ctx = mp.get_context("spawn")
-    port = 29600 + os.getpid() % 2000 + (1 if same_shard else 0) + (2 if backend == "nccl" else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, same_shard, str(outdir), backend)) for r in range(2)]
+    port = 29600 + os.getpid() % 2000 + (1 if same_shard else 0) + (2 if backend == "nccl" else 0) \
+        + (4 if mixed_schedules else 0) + (8 if steps != STEPS else 0)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, same_shard, str(outdir), backend, steps, mixed_schedules))
+             for r in range(2)]
     for p in procs:
         p.start()
     for p in procs:
@@ -97,3 +109,70 @@ def test_two_ranks_rccl(device, tmp_path, same_shard):
         ref = _run(0, 1, True)
         for k in ref:
             assert torch.allclose(a[k], ref[k], rtol=1e-4, atol=5e-6), (k, (a[k] - ref[k]).abs().max().item())
+
+
+def test_two_ranks_equal_one_process_accumulating_both_shards(device, tmp_path):
+    """SURVEY.md 8(e) parity clause (b): an N-rank run equals ONE process that accumulates the gradients of the same
+    shards.  Two ranks (different shards, one optimizer step) against a single process that back-propagates shard 0 and
+    shard 1 separately, averages the two gradient arenas and applies the same fused SGD step.  The paradigm buffer is
+    part of the state: the single process feeds the middle head the rank-averaged class means the two ranks exchange
+    (condgraph.update_prototype_nx1_rnn), taken from a recording pass -- the class means depend on the parameters and
+    the shard only, not on the paradigm buffer."""
+    from scan_amd import engine
+    a, b = _spawn(False, tmp_path, steps=1)
+    dev = torch.device("cuda", 0)
+
+    def fresh():
+        model = engine.build_model(9, device=dev, attn_dropout=0.0)
+        engine.load_procedural_weights(model)
+        return model, engine.Trainer(model)
+
+    # pass 1: the per-shard class means
+    pbs = []
+    for shard in (0, 1):
+        model, trainer = fresh()
+        mh = model["middle_head"]
+        orig = mh.update_prototype_nx1_rnn
+        mh.update_prototype_nx1_rnn = lambda pb, _o=orig: (pbs.append(pb.detach().clone()), _o(pb))[1]
+        trainer._optimizer_step = lambda: None
+        trainer.step(*_batch(shard, dev))
+        del model, trainer
+    ex = [pb.sum(-1).bool().float()[:, None] for pb in pbs]
+    pb_avg = (pbs[0] * ex[0] + pbs[1] * ex[1]) / (ex[0] + ex[1]).clamp(min=1)
+    # pass 2: one model, both shards' gradients from the SAME initial state, then one optimizer step on their mean
+    model, trainer = fresh()
+    mh = model["middle_head"]
+    orig = mh.update_prototype_nx1_rnn
+    mh.update_prototype_nx1_rnn = lambda pb, _o=orig: _o(pb_avg)
+    real_step = trainer._optimizer_step
+    trainer._optimizer_step = lambda: None
+    proto0, counter0 = mh.prototype.clone(), mh.counter_rnn.counter
+    grads = []
+    for shard in (0, 1):
+        mh.prototype.copy_(proto0)
+        mh.counter_rnn.counter = counter0
+        trainer.step(*_batch(shard, dev))
+        grads.append(trainer.grad_arena.clone())
+    trainer.grad_arena.copy_((grads[0] + grads[1]) / 2)
+    real_step()
+    torch.cuda.synchronize()
+    for k, g in trainer.groups.items():
+        assert torch.equal(a[k], b[k]), k
+        ref = g.flat_p.detach().cpu()
+        # one lr-sized step: the parameters moved by ~1e-3 * grad; the bar is 1e-5 on the parameters themselves
+        assert torch.allclose(a[k], ref, rtol=1e-5, atol=1e-6), (k, (a[k] - ref).abs().max().item())
+    assert torch.allclose(a["prototype"], mh.prototype.detach().cpu(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(a["momentum_backbone"], trainer.groups["backbone"].flat_m.cpu(), rtol=1e-4, atol=1e-7)
+
+
+def test_two_ranks_mixed_schedules_issue_the_same_collectives(device, tmp_path):
+    """rank 0 takes Trainer.step_paired, rank 1 the three-phase schedule (what happens when the ranks' batches pad to
+    different shapes): the gradient all-reduces must pair up -- same ranges, same order -- and, with the same shard on
+    both ranks, the result equals the single-process run."""
+    a, b = _spawn(True, tmp_path, mixed_schedules=True)
+    assert torch.equal(a["collective_log"], b["collective_log"]) and a["collective_log"].shape[0] >= 7
+    ref = _run(0, 1, True)
+    for k in ref:
+        # the two schedules sum in different orders: equal to rounding, not bit for bit
+        assert torch.allclose(a[k], b[k], rtol=1e-4, atol=5e-6), (k, (a[k] - b[k]).abs().max().item())
+        assert torch.allclose(a[k], ref[k], rtol=1e-4, atol=5e-6), (k, (a[k] - ref[k]).abs().max().item())

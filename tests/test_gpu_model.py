@@ -19,6 +19,31 @@ def _digest(g):
     return [flat.sum().item(), flat.abs().sum().item()] + flat[idx].tolist()
 
 
+def _check_all_gradient_digests(gold, model, mode, rt, tag):
+    """EVERY parameter-gradient digest the fixture holds (sum and abs-sum, error relative to the abs-sum) within
+    ``rt``; the two smallest discriminator levels get twice the bar in bf16x3 mode (a handful of rows: one ReLU
+    decision flipped by the operand split moves their digests by ~1e-3).  Prints the six worst entries."""
+    worst, errs = (0.0, None), []
+    for mk, m in model.items():
+        for name, p in m.named_parameters():
+            ref = gold["grad_digest"][mk].get(name)
+            if ref is None:
+                assert not p.requires_grad or name.startswith("cond_2"), (mk, name)
+                continue
+            mine = _digest(p.grad)
+            if ref[1] / p.numel() < 1e-7:
+                assert mine[1] / p.numel() < 1e-6, (mk, name, mine[1])
+                continue
+            err = max(abs(mine[1] - ref[1]), abs(mine[0] - ref[0])) / max(ref[1], 1e-3)
+            small = mode == "bf16x3" and mk in ("dis_P6_CON", "dis_P7_CON")
+            worst = max(worst, (err / (2.0 if small else 1.0), mk + "/" + name))
+            errs.append((err, mk + "/" + name))
+    errs.sort(reverse=True)
+    print("%s %s: %d gradient digests, worst errors (sum / abs-sum, relative to abs-sum): %s" % (
+        tag, mode, len(errs), ", ".join("%.2e %s" % e for e in errs[:6])))
+    assert worst[0] <= rt, (tag, mode, worst)
+
+
 @pytest.fixture(scope="module", params=["fp32", "bf16x3"])
 def step_result(device, gold_dir, request):
     from scan_amd import engine, ops, synth
@@ -273,28 +298,9 @@ def test_step_mid_size_all_gradients_match_reference(device, gold_dir):
         for k, ref in gold["losses"].items():
             v = float(losses[k])
             assert abs(v - ref) <= LOSS_RTOL * abs(ref) if ref != 0.0 else v == 0.0, (mode, k, v, ref)
-        worst, errs = (0.0, None), []
-        for mk, m in model.items():
-            for name, p in m.named_parameters():
-                ref = gold["grad_digest"][mk].get(name)
-                if ref is None:
-                    assert not p.requires_grad or name.startswith("cond_2"), (mk, name)
-                    continue
-                mine = _digest(p.grad)
-                if ref[1] / p.numel() < 1e-7:
-                    assert mine[1] / p.numel() < 1e-6, (mk, name, mine[1])
-                    continue
-                err = max(abs(mine[1] - ref[1]), abs(mine[0] - ref[0])) / max(ref[1], 1e-3)
-                # the two smallest levels (8x16 and 4x8 pixels here) see 128 / 32 rows: one ReLU decision flipped by
-                # the operand split moves their digests by ~1e-3, and which ones flip varies with the summation order
-                # of the run (fp64 atomics): measured 2.0e-3 ... 3.3e-3 over runs -> twice the bar for those two
-                small = mode == "bf16x3" and mk in ("dis_P6_CON", "dis_P7_CON")
-                worst = max(worst, (err / (2.0 if small else 1.0), mk + "/" + name))
-                errs.append((err, mk + "/" + name))
-        errs.sort(reverse=True)
-        print("step_mid %s: worst gradient digest errors (sum / abs-sum, relative to abs-sum): %s" % (
-            mode, ", ".join("%.2e %s" % e for e in errs[:6])))
-        assert worst[0] <= rt, (mode, worst)
+        # the two smallest levels (8x16 and 4x8 pixels here) see 128 / 32 rows: measured 2.0e-3 ... 3.3e-3 over runs
+        # (which ReLU decisions flip varies with the summation order of the fp64 atomics) -> twice the bar for those two
+        _check_all_gradient_digests(gold, model, mode, rt, "step_mid")
 
 
 def test_two_steps_run_and_update(device):
@@ -410,6 +416,8 @@ def test_step_other_sizes_match_reference(device, gold_dir, name, paired):
             p = dict(model[mk].named_parameters())[name_]
             mine = _digest(p.grad)
             assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mode, mk, name_, mine[1], ref[1])
+        if H * W >= 512 * 1024:  # real level sizes (cfg1: 100x200 ... 7x13): EVERY digest of the fixture, the step_mid bars
+            _check_all_gradient_digests(gold, model, mode, 2e-3 if mode == "fp32" else 3e-3, name)
 
 
 @pytest.mark.parametrize("name,ft", [("step_s2c_128x256", False), ("step_s2c_ft_256x512", True)])
@@ -488,6 +496,40 @@ def test_step_padded_batches_match_reference(device, gold_dir, name):
         ref = gold["grad_digest"][mk][name_]
         mine = _digest(dict(model[mk].named_parameters())[name_].grad)
         assert abs(mine[1] - ref[1]) <= 5e-3 * ref[1], (mk, name_, mine[1], ref[1])
+    if gold["H"] * gold["W"] >= 512 * 1024:  # configs[4] frame: every digest of the fixture (bf16x3 mode, the default)
+        _check_all_gradient_digests(gold, model, "bf16x3", 3e-3, name)
+
+
+def test_step_bench_shape_matches_reference(device, gold_dir):
+    """BASELINE.json configs[1] -- the bench workload itself: 2 source + 2 target frames at 1024x2048 (levels
+    128x256 ... 8x16), fixture written by the reference (oracle/make_golden.py --only step_cfg2).  Both conv modes, all
+    16 losses within 1e-4, EVERY parameter-gradient digest of every sub-model, the paradigm buffer after the update."""
+    from scan_amd import engine, ops, synth
+    gold = json.load(open(os.path.join(gold_dir, "step_cfg2_1024x2048.json")))
+    H, W, N = gold["H"], gold["W"], gold["N"]
+    assert (H, W, N) == (1024, 2048, 2)
+    gz = np.load(os.path.join(gold_dir, "step_cfg2_1024x2048.npz"))
+    for mode, rt in (("fp32", 2e-3), ("bf16x3", 3e-3)):
+        ops.CONV_MODE = mode
+        try:
+            model = engine.build_model(9, device=device, attn_dropout=0.0)
+            engine.load_procedural_weights(model)
+            trainer = engine.Trainer(model, base_lr=0.0)
+            losses = trainer.step(synth.synth_images(N, H, W, gold["seeds"]["src"]).to(device),
+                                  synth.synth_targets(N, H, W, 8, 12, gold["seeds"]["boxes"]),
+                                  synth.synth_images(N, H, W, gold["seeds"]["tgt"]).to(device))
+            torch.cuda.synchronize()
+        finally:
+            ops.CONV_MODE = "bf16x3"
+        assert set(gold["losses"]) <= set(losses)
+        for k, ref in gold["losses"].items():
+            v = float(losses[k])
+            assert abs(v - ref) <= LOSS_RTOL * abs(ref) if ref != 0.0 else v == 0.0, (mode, k, v, ref)
+        _check_all_gradient_digests(gold, model, mode, rt, "step_cfg2_1024x2048")
+        np.testing.assert_allclose(model["middle_head"].prototype.cpu().numpy(), gz["prototype_after"], rtol=1e-4,
+                                   atol=1e-5 if mode == "fp32" else 1e-4)
+        del trainer, model
+        torch.cuda.empty_cache()
 
 
 def test_step_resnet50_matches_reference(device, gold_dir):

@@ -65,9 +65,26 @@ def read(path, counter):
     return acc
 
 
+def meta():
+    """what the passes are valid for: the commit checked out (if a git tree is here) and the hash of the kernel sources
+    (bench.py reports the traffic only while that hash matches the build it runs on)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    commit = os.environ.get("SCAN_COMMIT")
+    if not commit:
+        try:
+            commit = subprocess.check_output(["git", "-C", root, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+        except Exception:
+            commit = None
+    return {"commit": commit, "csrc_sha1": bench.csrc_sha1()}
+
+
 def main():
     fe, wr = read(sys.argv[1], "FETCH_SIZE"), read(sys.argv[2], "WRITE_SIZE")
-    out = {"_note": __doc__.split("\n\n")[-1].replace("\n", " ")}
+    out = {"_note": __doc__.split("\n\n")[-1].replace("\n", " "), "_meta": meta()}
     for _, key in GROUPS:
         if key not in fe or key not in wr or key in out:
             continue

@@ -63,6 +63,15 @@ int scan_abi_version(void);
  *                 fp32 matrix cores (same products, different summation order; measured no faster in the step).
  *   "conv_tpb3"   bit 0 (default on) / bit 1: the 128- / 64-channel instance stages three taps per barrier (same
  *                 results bit for bit).
+ *   "wgrad_v4"    2 (default): every bf16x3 weight-gradient launch runs the fourth-generation kernel (wave-uniform chunk
+ *                 walk in scalar registers, range-checked buffer loads with per-lane constant offsets: no per-chunk
+ *                 address arithmetic or predication); 1: only the launches "wgrad_v2" sends to the 16x16x32 kernel
+ *                 (bit-identical to it); 0: the round-2 kernels.
+ *   "wgrad_il"    1 (default): that kernel issues the next K chunk's loads one per MFMA block inside the MFMA phase;
+ *                 2 / 3: two / three per block; 0: together before the barrier.  Same results.
+ *   "wgrad_v5"    1: the fourth generation's staging in the double-buffered, staggered structure of "wgrad_v3"
+ *                 (default 0: measured slower).
+ *   "wgrad_exp"   1..4: timing ablations of the second-generation kernel (WRONG results; profiles/r03_wgrad_exp.txt).
  *   "conv_glds"   1 (default): the 16-wave 128- / 256-channel 3x3 instances stage weight tiles by LDS-DMA
  *                 (global_load_lds_dwordx4) on whole tiles; 0: through registers.  Same results bit for bit. */
 int scan_tune(const char* key, int value);

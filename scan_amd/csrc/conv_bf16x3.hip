@@ -898,6 +898,48 @@ __device__ __forceinline__ void wgrad_mma_v2(const __bf16* Ah, const __bf16* Al,
 
 // NT = 512: 8 waves = 2 (o) x 4 (c), each 64 o x 32 c; NT = 1024: 16 waves = 4 x 4, each 32 o x 32 c (48 accumulator
 // registers, <= 128 registers per lane: four waves per SIMD to hide the staging phases and the transposed-read latency)
+// wgrad_mma_v2 with a hook after every (k-step, tap, column tile) block of MFMAs: the fourth-generation kernel issues the
+// NEXT chunk's buffer loads there, one per block, so that the texture-address path works through them while the matrix
+// pipe is busy (issued together before the barrier, the 72 wave-instructions of a workgroup queue up behind each other
+// and the MFMA phase starts late: profiles/r03_wgrad_v4_ab.txt)
+template <int TO, int KX, int TOMAX, typename F>
+__device__ __forceinline__ void wgrad_mma_v2_hook(const __bf16* Ah, const __bf16* Al, const __bf16* Bh, const __bf16* Bl,
+                                                  int row_lane, int col4, int a_col, int b_col,
+                                                  f32x4v (&acc)[KX][TOMAX][2], F&& hook) {
+  int blk = 0;
+#pragma unroll
+  for (int s = 0; s < WK / 32; ++s) {
+    const int ra0 = 32 * s + row_lane, ra1 = ra0 + 4;
+    bf16x8 ah[TO], al[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+      const int c = a_col + 16 * t + col4;
+      const int o0 = wsw(ra0, c), o1 = wsw(ra1, c);
+      ah[t] = tr_read8_v2(Ah + o0, Ah + o1);
+      al[t] = tr_read8_v2(Al + o0, Al + o1);
+    }
+#pragma unroll
+    for (int kx = 0; kx < KX; ++kx) {
+      const int rb0 = ra0 + kx, rb1 = ra1 + kx;
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        const int c = b_col + 16 * tc + col4;
+        const int o0 = wsw(rb0, c), o1 = wsw(rb1, c);
+        const bf16x8 bh = tr_read8_v2(Bh + o0, Bh + o1);
+        const bf16x8 bl = tr_read8_v2(Bl + o0, Bl + o1);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[to], bh, acc[kx][to][tc], 0, 0, 0);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[to], bl, acc[kx][to][tc], 0, 0, 0);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[to], bh, acc[kx][to][tc], 0, 0, 0);
+        hook(blk);
+        ++blk;
+      }
+    }
+  }
+}
+
 // EXP != 0: TIMING ABLATIONS ONLY (wrong results), selected by scan_tune "wgrad_exp" and never by default:
 //   1 every split-K slab walks the chunk range of slab 0 (operands hot in L2: what the memory side costs);
 //   2 no MFMA phase (loads + staging + barriers only);  3 loads and staging for the first chunk only (MFMA phase +
@@ -1047,6 +1089,296 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v2_k
   }
 
   // C/D map of 16x16: column = lane & 15 = input channel c, row = 4 * (lane >> 4) + reg = output channel o
+  float* out = slab + (long long)split * Nout * T * Cs;
+#pragma unroll
+  for (int kx = 0; kx < KX; ++kx)
+#pragma unroll
+    for (int to = 0; to < TOMAX; ++to)
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        const int c = c0 + b_col + 16 * tc + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + a_col + 16 * to + 4 * kg + r;
+          if (o < Nout && c < Cs) out[((long long)o * T + ky * KX + kx) * Cs + c] = acc[kx][to][tc][r];
+        }
+      }
+
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(smem_raw);  // [RG][128]
+    *reinterpret_cast<float4*>(red + rr * 128 + 4 * q4) = bsum;
+    __syncthreads();
+    if (tid < 128) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) sum += red[g * 128 + tid];
+      if (o0 + tid < Nout) bias_slab[(long long)split * Nout + o0 + tid] = sum;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fourth generation of the weight-gradient kernel: the 16x16x32 kernel above (same tiles, same LDS image, same K order,
+// bit-identical slabs) with the K-chunk STAGING rewritten for instruction count.
+//
+// What the ablations of the second generation showed (scan_tune "wgrad_exp", profiles/r03_wgrad_exp.txt; conv3_x, us):
+// whole kernel 1690; MFMA phase + barriers alone 1100; loads + staging alone 772; data hot in L2: 1612.  The two phases
+// did not overlap although the next chunk's loads are issued before the MFMA phase -- because issuing them cost ~700
+// instructions per wave and chunk: 64-bit divisions to decode the chunk index into (level, image, row, segment), one
+// exec-masked branch per load for the edge conditions, 64-bit address arithmetic per lane.  All eight waves run that
+// code between the same two barriers, so the matrix cores idle for its whole length.  Here
+//   * the chunk position (level, image, row, segment) is wave-uniform state advanced by a few scalar instructions per
+//     chunk (the divisions run once per workgroup);
+//   * both operands are fetched with buffer loads whose descriptor (base = first pixel of the chunk's row segment,
+//     num_records = bytes up to its last valid pixel) is rebuilt per chunk from scalars: the hardware range check
+//     returns zeros beyond the row end / for rows outside the image (num_records = 0), so no load is predicated;
+//   * a lane's byte offsets inside a chunk are the same for every chunk (pixel k, channel column 4 q4) and live in
+//     registers; columns beyond the channel count carry an out-of-range offset.
+// Per chunk and lane: NA + NB buffer_load_dwordx4 with constant offsets, one v_cndmask (left image edge), no address
+// arithmetic.  Needs Ns % 4 == 0, Cs % 4 == 0 and row segments below 2 GiB (64 pixels x channels x 4 B).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ int lvl_pick(const int32_t (&a)[SCAN_MAX_LEVELS], int l) {
+  int v = a[0];
+#pragma unroll
+  for (int i = 1; i < SCAN_MAX_LEVELS; ++i) v = (l == i) ? a[i] : v;
+  return v;
+}
+__device__ __forceinline__ long long lvl_pick64(const int64_t (&a)[SCAN_MAX_LEVELS + 1], int l) {
+  long long v = a[0];
+#pragma unroll
+  for (int i = 1; i < SCAN_MAX_LEVELS; ++i) v = (l == i) ? (long long)a[i] : v;
+  return v;
+}
+
+// buffer descriptor from wave-uniform inputs, made PROVABLY uniform for the compiler (cdna_hip_programming.md T20): a
+// descriptor it cannot prove uniform gets a waterfall loop around every load
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const float* base, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  float* p = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int KX, int S, int NT, int IL = 0>
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_v4_kernel(
+    const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
+    float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
+    int chunks_per_split, int splits, scan_pyramid_t xd) {
+  constexpr int HALO = KX / 2, T = KX * KX;
+  constexpr int RG = NT / 32;                         // pixel-row groups of the staging roles
+  constexpr int NA = WK / RG;                         // dY float4 per thread per chunk
+  constexpr int NB = (WK + KX - 1 + RG - 1) / RG;     // X float4 per thread per chunk
+  constexpr int WO = NT / 256;                        // waves along o
+  constexpr int TOMAX = 128 / (16 * WO);              // 16-row o tiles per wave
+  constexpr unsigned BAD = 0x80000000u;               // a byte offset beyond every descriptor: the load returns zeros
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  const int qq = L >> 3;
+  // integer division runs on the vector ALU: pin the (wave-uniform) quotients back into scalar registers so that
+  // everything derived from them -- the chunk walk, the buffer descriptors -- stays scalar
+  int tile = __builtin_amdgcn_readfirstlane(qq % n_tiles);
+  const int split = __builtin_amdgcn_readfirstlane(qq / n_tiles) * 8 + xcd;
+  const int c_tile = __builtin_amdgcn_readfirstlane(tile % c_tiles);
+  tile = __builtin_amdgcn_readfirstlane(tile / c_tiles);
+  const int ky = __builtin_amdgcn_readfirstlane(tile % KX);
+  const int o_tile = __builtin_amdgcn_readfirstlane(tile / KX);
+  const int o0 = o_tile * 128, c0 = c_tile * 128;
+  const long long total_chunks = ct.chunk_off[d.n_levels];
+  const long long ch_begin = (long long)split * chunks_per_split;
+  long long ch_end = ch_begin + chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  const bool do_bias = (bias_slab != nullptr) && ky == HALO && c_tile == 0;
+
+  // ---- per-lane byte offsets inside a chunk: constant for the whole kernel
+  const int q4 = tid & 31, rr = tid >> 5;
+  unsigned offa[NA], offb[NB];
+  {
+    const int o = o0 + 4 * q4, c = c0 + 4 * q4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) offa[i] = (o < Ns) ? (unsigned)(((rr + RG * i) * Ns + o) * 4) : BAD;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
+      offb[i] = (c < Cs && j < WK + KX - 1) ? (unsigned)((S * j * Cs + c) * 4) : BAD;
+    }
+  }
+
+  // ---- wave-uniform chunk position: level, image, row, row segment (the divisions run once)
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+    if (i < d.n_levels && ch_begin >= ct.chunk_off[i]) lvl = i;
+  int segs = lvl_pick(ct.segs, lvl), H = lvl_pick(d.h, lvl), W = lvl_pick(d.w, lvl);
+  long long row0 = lvl_pick64(d.row_off, lvl);
+  int seg, n, y;
+  {
+    const long long r = (ch_begin < ch_end ? ch_begin : 0) - ct.chunk_off[lvl];
+    const long long rowl = r / segs;
+    // the 64-bit divisions run on the vector ALU: bring the (wave-uniform) results back to scalar registers, or every
+    // address and descriptor derived from them stays in VGPRs and each buffer load gets a waterfall loop
+    seg = __builtin_amdgcn_readfirstlane((int)(r - rowl * segs));
+    n = __builtin_amdgcn_readfirstlane((int)(rowl / H));
+    y = __builtin_amdgcn_readfirstlane((int)(rowl - (long long)(rowl / H) * H));
+  }
+
+  float4 ra[NA], rb[NB];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  __amdgpu_buffer_rsrc_t ra_src, rb_src;
+  bool left_edge = false;
+  // descriptors of the chunk at (lvl, n, y, seg): scalar work only.  live = false: zero records, every load of the
+  // "chunk" returns zeros without touching memory (the interleaved variant issues its loads unconditionally, also
+  // behind the last chunk, so that the MFMA phase has no control flow in it)
+  auto prepare_loads = [&](bool live = true) {
+    const int x0 = seg * WK;
+    const long long rowbase = row0 + ((long long)n * H + y) * W;
+    const int kmax = (W - x0 < WK) ? W - x0 : WK;
+    ra_src = uniform_rsrc(dy + (rowbase + x0) * Ns, live ? kmax * Ns * 4 : 0);
+    const float* bbase;
+    int nrec;
+    if (KX == 1) {
+      const int Hx = lvl_pick(xd.h, lvl), Wx = lvl_pick(xd.w, lvl);
+      const long long xrow = lvl_pick64(xd.row_off, lvl) + ((long long)n * Hx + (long long)S * y) * Wx;
+      bbase = x + (xrow + (long long)S * x0) * Cs;
+      nrec = ((kmax - 1) * S + 1) * Cs * 4;
+    } else {
+      const int yy = y + ky - HALO;
+      const int jmax = (W - x0 + HALO < WK + KX - 1) ? W - x0 + HALO : WK + KX - 1;
+      bbase = x + (rowbase + (long long)(ky - HALO) * W + x0 - HALO) * Cs;  // never dereferenced where it lies outside
+      nrec = (yy >= 0 && yy < H) ? jmax * Cs * 4 : 0;
+    }
+    rb_src = uniform_rsrc(bbase, live ? nrec : 0);
+    left_edge = seg == 0;
+  };
+  auto issue_one = [&](int k) {  // load k of the NA + NB of a chunk
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+      if (k == i) ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra_src, (int)offa[i], 0, 0));
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      if (k == NA + i) {
+        unsigned off = offb[i];
+        if (KX > 1 && i == 0) off = (left_edge && rr < HALO) ? BAD : off;  // pixel x0 - HALO + j left of the image
+        rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb_src, (int)off, 0, 0));
+      }
+  };
+  auto issue_loads = [&]() {
+    prepare_loads();
+#pragma unroll
+    for (int k = 0; k < NA + NB; ++k) issue_one(k);
+  };
+  auto advance = [&]() {
+    if (++seg == segs) {
+      seg = 0;
+      if (++y == H) {
+        y = 0;
+        if (++n == d.n_images) {
+          n = 0;
+          ++lvl;
+          segs = lvl_pick(ct.segs, lvl);
+          H = lvl_pick(d.h, lvl);
+          W = lvl_pick(d.w, lvl);
+          row0 = lvl_pick64(d.row_off, lvl);
+        }
+      }
+    }
+  };
+  auto store_chunk = [&]() {
+    __bf16* Ah = sm;
+    __bf16* Al = Ah + WK * WROW;
+    __bf16* Bh = Al + WK * WROW;
+    __bf16* Bl = Bh + (WK + KX - 1) * WROW;
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int off = wsw(rr + RG * i, 4 * q4);
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(Ah + off) = hi;
+      *reinterpret_cast<bf16x4*>(Al + off) = lo;
+      if (do_bias) {
+        bsum.x += ra[i].x;
+        bsum.y += ra[i].y;
+        bsum.z += ra[i].z;
+        bsum.w += ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
+      if (j < WK + KX - 1) {
+        const int off = wsw(j, 4 * q4);
+        split4(rb[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(Bh + off) = hi;
+        *reinterpret_cast<bf16x4*>(Bl + off) = lo;
+      }
+    }
+  };
+
+  const int wm = wid % WO, wn = wid / WO;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int row_lane = 8 * kg + (lr >> 2), col4 = 4 * (lane & 3);
+  const int a_col = wm * (16 * TOMAX), b_col = wn * 32;
+  const bool c_act = c0 + b_col < Cs;
+  const int o_left = Nout - (o0 + a_col);
+
+  f32x4v acc[KX][TOMAX][2];
+#pragma unroll
+  for (int a = 0; a < KX; ++a)
+#pragma unroll
+    for (int b = 0; b < TOMAX; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  if (ch_begin < ch_end) issue_loads();
+  const __bf16* Ah = sm;
+  const __bf16* Al = Ah + WK * WROW;
+  const __bf16* Bh = Al + WK * WROW;
+  const __bf16* Bl = Bh + (WK + KX - 1) * WROW;
+  for (long long ch = ch_begin; ch < ch_end; ++ch) {
+    store_chunk();
+    const bool more = ch + 1 < ch_end;
+    if (IL) {
+      if (more) advance();
+      prepare_loads(more);
+    } else if (more) {
+      advance();
+      issue_loads();
+    }
+    __syncthreads();
+    if (IL) {
+      // one load after each of the first NA + NB MFMA blocks (12 blocks for the 3x3, 4 for the 1x1: the rest follow the
+      // last block); the sched_barrier keeps the compiler from gathering them at either end of the phase
+      constexpr int NBLK = (WK / 32) * KX * 2, ILD = IL > 0 ? IL : 1;
+      auto hook = [&](int blk) {
+#pragma unroll
+        for (int k = 0; k < NA + NB; ++k)
+          if (k / ILD == blk || (blk == NBLK - 1 && k / ILD >= NBLK)) issue_one(k);  // IL loads per block
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      if (TOMAX == 4 && c_act && o_left > 32) {
+        wgrad_mma_v2_hook<TOMAX, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc, hook);
+      } else if (c_act && o_left > 16) {
+        wgrad_mma_v2_hook<2, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc, hook);
+      } else if (c_act && o_left > 0) {
+        wgrad_mma_v2_hook<1, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc, hook);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NA + NB; ++k) issue_one(k);
+      }
+    } else if (TOMAX == 4 && c_act && o_left > 32)
+      wgrad_mma_v2<TOMAX, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    else if (c_act && o_left > 16)
+      wgrad_mma_v2<2, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    else if (c_act && o_left > 0)
+      wgrad_mma_v2<1, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    __syncthreads();
+  }
+
   float* out = slab + (long long)split * Nout * T * Cs;
 #pragma unroll
   for (int kx = 0; kx < KX; ++kx)
@@ -1322,6 +1654,249 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_wgrad_bf16x3_v3_k
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Fifth generation: the fourth generation's staging (scalar chunk walk, range-checked buffer loads) in the third
+// generation's structure -- unpadded swizzled LDS image, TWO stages, one barrier per chunk, the two waves of a SIMD
+// running "split + write chunk k+1, fetch chunk k+2" and "MFMAs of chunk k" in opposite order.  With the staging down
+// to a few dozen instructions the overlap the third generation was built for becomes visible (it measured slower in
+// round 2 because both halves of a SIMD pair spent most of a chunk in address arithmetic).  Same K order: bit-identical
+// slabs.
+// ------------------------------------------------------------------------------------------------
+template <int KX, int S, int NT>
+__global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_v5_kernel(
+    const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
+    float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
+    int chunks_per_split, int splits, scan_pyramid_t xd) {
+  constexpr int HALO = KX / 2, T = KX * KX;
+  constexpr int RG = NT / 32;                         // pixel-row groups of the staging roles
+  constexpr int NA = WK / RG;                         // dY float4 per thread per chunk
+  constexpr int NB = (WK + KX - 1 + RG - 1) / RG;     // X float4 per thread per chunk
+  constexpr int WO = NT / 256;                        // waves along o
+  constexpr int TOMAX = 128 / (16 * WO);              // 16-row o tiles per wave
+  constexpr unsigned BAD = 0x80000000u;               // a byte offset beyond every descriptor: the load returns zeros
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  const int qq = L >> 3;
+  // integer division runs on the vector ALU: pin the (wave-uniform) quotients back into scalar registers so that
+  // everything derived from them -- the chunk walk, the buffer descriptors -- stays scalar
+  int tile = __builtin_amdgcn_readfirstlane(qq % n_tiles);
+  const int split = __builtin_amdgcn_readfirstlane(qq / n_tiles) * 8 + xcd;
+  const int c_tile = __builtin_amdgcn_readfirstlane(tile % c_tiles);
+  tile = __builtin_amdgcn_readfirstlane(tile / c_tiles);
+  const int ky = __builtin_amdgcn_readfirstlane(tile % KX);
+  const int o_tile = __builtin_amdgcn_readfirstlane(tile / KX);
+  const int o0 = o_tile * 128, c0 = c_tile * 128;
+  const long long total_chunks = ct.chunk_off[d.n_levels];
+  const long long ch_begin = (long long)split * chunks_per_split;
+  long long ch_end = ch_begin + chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  const bool do_bias = (bias_slab != nullptr) && ky == HALO && c_tile == 0;
+
+  // ---- per-lane byte offsets inside a chunk: constant for the whole kernel
+  const int q4 = tid & 31, rr = tid >> 5;
+  unsigned offa[NA], offb[NB];
+  {
+    const int o = o0 + 4 * q4, c = c0 + 4 * q4;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) offa[i] = (o < Ns) ? (unsigned)(((rr + RG * i) * Ns + o) * 4) : BAD;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
+      offb[i] = (c < Cs && j < WK + KX - 1) ? (unsigned)((S * j * Cs + c) * 4) : BAD;
+    }
+  }
+
+  // ---- wave-uniform chunk position: level, image, row, row segment (the divisions run once)
+  int lvl = 0;
+#pragma unroll
+  for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+    if (i < d.n_levels && ch_begin >= ct.chunk_off[i]) lvl = i;
+  int segs = lvl_pick(ct.segs, lvl), H = lvl_pick(d.h, lvl), W = lvl_pick(d.w, lvl);
+  long long row0 = lvl_pick64(d.row_off, lvl);
+  int seg, n, y;
+  {
+    const long long r = (ch_begin < ch_end ? ch_begin : 0) - ct.chunk_off[lvl];
+    const long long rowl = r / segs;
+    // the 64-bit divisions run on the vector ALU: bring the (wave-uniform) results back to scalar registers, or every
+    // address and descriptor derived from them stays in VGPRs and each buffer load gets a waterfall loop
+    seg = __builtin_amdgcn_readfirstlane((int)(r - rowl * segs));
+    n = __builtin_amdgcn_readfirstlane((int)(rowl / H));
+    y = __builtin_amdgcn_readfirstlane((int)(rowl - (long long)(rowl / H) * H));
+  }
+
+  float4 ra[NA], rb[NB];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto issue_loads = [&]() {  // the chunk at (lvl, n, y, seg)
+    const int x0 = seg * WK;
+    const long long rowbase = row0 + ((long long)n * H + y) * W;
+    const int kmax = (W - x0 < WK) ? W - x0 : WK;
+    {
+      const float* base = dy + (rowbase + x0) * Ns;
+      const __amdgpu_buffer_rsrc_t ra_src = uniform_rsrc(base, kmax * Ns * 4);
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra_src, (int)offa[i], 0, 0));
+    }
+    const float* bbase;
+    int nrec;
+    if (KX == 1) {
+      const int Hx = lvl_pick(xd.h, lvl), Wx = lvl_pick(xd.w, lvl);
+      const long long xrow = lvl_pick64(xd.row_off, lvl) + ((long long)n * Hx + (long long)S * y) * Wx;
+      bbase = x + (xrow + (long long)S * x0) * Cs;
+      nrec = ((kmax - 1) * S + 1) * Cs * 4;
+    } else {
+      const int yy = y + ky - HALO;
+      const int jmax = (W - x0 + HALO < WK + KX - 1) ? W - x0 + HALO : WK + KX - 1;
+      bbase = x + (rowbase + (long long)(ky - HALO) * W + x0 - HALO) * Cs;  // never dereferenced where it lies outside
+      nrec = (yy >= 0 && yy < H) ? jmax * Cs * 4 : 0;
+    }
+    const __amdgpu_buffer_rsrc_t rb_src = uniform_rsrc(bbase, nrec);
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      unsigned off = offb[i];
+      if (KX > 1 && i == 0) off = (seg == 0 && rr < HALO) ? BAD : off;  // pixel x0 - HALO + j left of the image
+      rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb_src, (int)off, 0, 0));
+    }
+  };
+  auto advance = [&]() {
+    if (++seg == segs) {
+      seg = 0;
+      if (++y == H) {
+        y = 0;
+        if (++n == d.n_images) {
+          n = 0;
+          ++lvl;
+          segs = lvl_pick(ct.segs, lvl);
+          H = lvl_pick(d.h, lvl);
+          W = lvl_pick(d.w, lvl);
+          row0 = lvl_pick64(d.row_off, lvl);
+        }
+      }
+    }
+  };
+  auto store_chunk = [&](int stage) {
+    __bf16* Ah = sm + stage * W3STAGE(KX);
+    __bf16* Al = Ah + WK * W3ROW;
+    __bf16* Bh = Al + WK * W3ROW;
+    __bf16* Bl = Bh + (WK + KX - 1) * W3ROW;
+    bf16x4 hi, lo;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int off = wsw3(rr + RG * i, 4 * q4);
+      split4(ra[i], hi, lo);
+      *reinterpret_cast<bf16x4*>(Ah + off) = hi;
+      *reinterpret_cast<bf16x4*>(Al + off) = lo;
+      if (do_bias) {
+        bsum.x += ra[i].x;
+        bsum.y += ra[i].y;
+        bsum.z += ra[i].z;
+        bsum.w += ra[i].w;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int j = rr + RG * i;
+      if (j < WK + KX - 1) {
+        const int off = wsw3(j, 4 * q4);
+        split4(rb[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(Bh + off) = hi;
+        *reinterpret_cast<bf16x4*>(Bl + off) = lo;
+      }
+    }
+  };
+
+  const int wm = wid % WO, wn = wid / WO;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int row_lane = 8 * kg + (lr >> 2), col4 = 4 * (lane & 3);
+  const int a_col = wm * (16 * TOMAX), b_col = wn * 32;
+  const bool c_act = c0 + b_col < Cs;
+  const int o_left = Nout - (o0 + a_col);
+
+  f32x4v acc[KX][TOMAX][2];
+#pragma unroll
+  for (int a = 0; a < KX; ++a)
+#pragma unroll
+    for (int b = 0; b < TOMAX; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  auto mma = [&](int stage) {
+    const __bf16* Ah = sm + stage * W3STAGE(KX);
+    const __bf16* Al = Ah + WK * W3ROW;
+    const __bf16* Bh = Al + WK * W3ROW;
+    const __bf16* Bl = Bh + (WK + KX - 1) * W3ROW;
+    if (TOMAX == 4 && c_act && o_left > 32)
+      wgrad_mma_v3<TOMAX, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    else if (c_act && o_left > 16)
+      wgrad_mma_v3<2, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+    else if (c_act && o_left > 0)
+      wgrad_mma_v3<1, KX, TOMAX>(Ah, Al, Bh, Bl, row_lane, col4, a_col, b_col, acc);
+  };
+  // convert chunk ch + 1 (in registers since the previous iteration) into `stage`, then fetch chunk ch + 2
+  auto stage_next = [&](long long ch, int stage) {
+    if (ch + 1 < ch_end) {
+      store_chunk(stage);
+      if (ch + 2 < ch_end) {
+        advance();
+        issue_loads();
+      }
+    }
+  };
+  const bool late = wid >= NT / 128;  // the SIMD partner of wave w is wave w + 4: the two run the halves in opposite order
+  if (ch_begin < ch_end) {
+    issue_loads();
+    store_chunk(0);
+    if (ch_begin + 1 < ch_end) {
+      advance();
+      issue_loads();
+    }
+  }
+  __syncthreads();
+  for (long long ch = ch_begin; ch < ch_end; ++ch) {
+    const int cur = (int)(ch - ch_begin) & 1;
+    if (!late) {
+      stage_next(ch, cur ^ 1);
+      mma(cur);
+    } else {
+      mma(cur);
+      stage_next(ch, cur ^ 1);
+    }
+    __syncthreads();  // stage cur is free for chunk ch + 2, stage cur ^ 1 is complete
+  }
+
+  float* out = slab + (long long)split * Nout * T * Cs;
+#pragma unroll
+  for (int kx = 0; kx < KX; ++kx)
+#pragma unroll
+    for (int to = 0; to < TOMAX; ++to)
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        const int c = c0 + b_col + 16 * tc + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + a_col + 16 * to + 4 * kg + r;
+          if (o < Nout && c < Cs) out[((long long)o * T + ky * KX + kx) * Cs + c] = acc[kx][to][tc][r];
+        }
+      }
+
+  if (do_bias) {
+    float* red = reinterpret_cast<float*>(smem_raw);  // [RG][128]
+    *reinterpret_cast<float4*>(red + rr * 128 + 4 * q4) = bsum;
+    __syncthreads();
+    if (tid < 128) {
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < RG; ++g) sum += red[g * 128 + tid];
+      if (o0 + tid < Nout) bias_slab[(long long)split * Nout + o0 + tid] = sum;
+    }
+  }
+}
+
+
 // scan_tune "wgrad_v2": 1 = always the 16x16x32 weight-gradient kernel, 0 = always the 32x32x16 one, 2 (default) = by
 // shape.  Same-process A/B per layer (profiles/r02_wgrad_ab.txt): +3...11 % where the input channels fill whole
 // 128-wide tiles (256 -> 256 towers 758 -> 683 us, conv3_x 1785 -> 1706, conv4_x 1716 -> 1667), -1...3 % on the
@@ -1337,6 +1912,15 @@ int g_scan_wgrad_wg1024 = 2;
 int g_scan_wgrad_v3 = 0;
 // scan_tune "wgrad_exp": timing ablations of the 16x16x32 weight-gradient kernel (wrong results; see the kernel)
 int g_scan_wgrad_exp = 0;
+// scan_tune "wgrad_v4": 2 (default) = every bf16x3 weight-gradient launch takes the fourth generation (scalar chunk walk +
+// buffer loads); 1 = only the launches that took the 16x16x32 kernel (bit-identical results; the 264 / 268-channel inputs
+// and the 64-channel layers stay on the 32x32x16 kernel); 0 = off.  Same-process A/B: profiles/r03_wgrad_v4_ab.txt
+int g_scan_wgrad_v4 = 2;
+// scan_tune "wgrad_v5": 1 = the 3x3 launches of the fourth generation take the double-buffered, staggered fifth
+int g_scan_wgrad_v5 = 0;
+// scan_tune "wgrad_il": n > 0 = the fourth-generation 3x3 kernel issues the next chunk's loads n at a time between the MFMA
+// blocks of the current chunk instead of together before the barrier (0)
+int g_scan_wgrad_il = 1;
 static inline bool wgrad_use_v2(int Cs) { return g_scan_wgrad_v2 == 1 || (g_scan_wgrad_v2 == 2 && Cs % 128 == 0); }
 // 2 = the 16x16x32 weight-gradient kernel, 1 = the 32x32x16 one, for an input channel stride Cs (bench.py labels)
 extern "C" int scan_conv_wgrad_bf16x3_generation(int32_t Cs) { return wgrad_use_v2(Cs) ? 2 : 1; }
@@ -1455,6 +2039,43 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
     }
     hipLaunchKernelGGL((conv_wgrad_bf16x3_v3_kernel<3, 1, 512>), dim3(nt * sp), dim3(512), sh3, st, x, *d, Cs, dy, Cout,
                        Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+  } else if (g_scan_wgrad_v5 && g_scan_wgrad_v4 && Cs % 4 == 0 && Cout_s % 4 == 0 && g_scan_wgrad_exp == 0 &&
+             (g_scan_wgrad_v4 == 2 || wgrad_use_v2(Cs))) {
+    const size_t sh5 = (size_t)2 * W3STAGE(3) * sizeof(__bf16);
+    static bool done6 = false;
+    if (!done6) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v5_kernel<3, 1, 512>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh5);
+      done6 = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_bf16x3_v5_kernel<3, 1, 512>), dim3(nt * sp), dim3(512), sh5, st, x, *d, Cs, dy, Cout,
+                       Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+  } else if (g_scan_wgrad_v4 && Cs % 4 == 0 && Cout_s % 4 == 0 && (g_scan_wgrad_v4 == 2 || wgrad_use_v2(Cs)) &&
+             g_scan_wgrad_exp == 0) {
+    static bool done5 = false;
+    if (!done5) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v4_kernel<3, 1, 512>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v4_kernel<3, 1, 512, 1>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v4_kernel<3, 1, 512, 2>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v4_kernel<3, 1, 512, 3>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      done5 = true;
+    }
+    if (g_scan_wgrad_il == 1)
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v4_kernel<3, 1, 512, 1>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy,
+                         Cout, Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+    else if (g_scan_wgrad_il == 2)
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v4_kernel<3, 1, 512, 2>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy,
+                         Cout, Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+    else if (g_scan_wgrad_il == 3)
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v4_kernel<3, 1, 512, 3>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy,
+                         Cout, Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+    else
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v4_kernel<3, 1, 512>), dim3(nt * sp), dim3(512), sh, st, x, *d, Cs, dy, Cout,
+                         Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
   } else if (wgrad_use_v2(Cs)) {
     static bool done2 = false;
     if (!done2) {
@@ -1542,7 +2163,22 @@ extern "C" int scan_conv1x1_wgrad_bf16x3(const float* x, const scan_pyramid_t* x
     done = true;
   }
   float* bias_slab = db ? ws + (int64_t)sp * Cout * Cs : nullptr;
-  if (wgrad_use_v2(Cs)) {
+  if (g_scan_wgrad_v4 && Cs % 4 == 0 && Cout_s % 4 == 0 && (g_scan_wgrad_v4 == 2 || wgrad_use_v2(Cs))) {
+    static bool done5 = false;
+    if (!done5) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v4_kernel<1, 1, 512>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v4_kernel<1, 2, 512>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+      done5 = true;
+    }
+    if (stride == 1)
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v4_kernel<1, 1, 512>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
+                         Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *xd);
+    else
+      hipLaunchKernelGGL((conv_wgrad_bf16x3_v4_kernel<1, 2, 512>), dim3(nt * sp), dim3(512), sh, st, x, *yd, Cs, dy, Cout,
+                         Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *xd);
+  } else if (wgrad_use_v2(Cs)) {
     static bool done2 = false;
     if (!done2) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v2_kernel<1, 1, 512>),

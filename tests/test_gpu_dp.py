@@ -169,10 +169,13 @@ def test_two_ranks_mixed_schedules_issue_the_same_collectives(device, tmp_path):
     """rank 0 takes Trainer.step_paired, rank 1 the three-phase schedule (what happens when the ranks' batches pad to
     different shapes): the gradient all-reduces must pair up -- same ranges, same order -- and, with the same shard on
     both ranks, the result equals the single-process run."""
-    a, b = _spawn(True, tmp_path, mixed_schedules=True)
+    # ONE optimizer step: the two schedules sum in different orders, and at this frame size (levels down to 1x1 pixel)
+    # a second step amplifies first-step rounding differences to ~1e-3 relative (DESIGN.md 4, "chaotic at rounding
+    # level") -- after one step the comparison with the single-process run is a rounding-level one
+    a, b = _spawn(True, tmp_path, steps=1, mixed_schedules=True)
     assert torch.equal(a["collective_log"], b["collective_log"]) and a["collective_log"].shape[0] >= 7
-    ref = _run(0, 1, True)
+    ref = _run(0, 1, True, steps=1)
     for k in ref:
-        # the two schedules sum in different orders: equal to rounding, not bit for bit
-        assert torch.allclose(a[k], b[k], rtol=1e-4, atol=5e-6), (k, (a[k] - b[k]).abs().max().item())
+        # both ranks hold the same averaged gradients: identical parameters whatever schedule produced their shares
+        assert torch.equal(a[k], b[k]), (k, (a[k] - b[k]).abs().max().item())
         assert torch.allclose(a[k], ref[k], rtol=1e-4, atol=5e-6), (k, (a[k] - ref[k]).abs().max().item())

@@ -53,6 +53,15 @@ __device__ __forceinline__ void split4_v2(const float4 v, bf16x4& hi, bf16x4& lo
   lo[3] = (__bf16)(v.w - (float)hi[3]);
 }
 
+// buffer descriptor from wave-uniform inputs, made PROVABLY uniform for the compiler (cdna_hip_programming.md T20): a
+// descriptor it cannot prove uniform gets a waterfall loop around every load
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc_v2(const float* base, int bytes) {
+  const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  float* p = reinterpret_cast<float*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(p, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
 // 16-byte slot swizzle of a 64-byte row: k-group kg of row idx lives at slot kg ^ swz(idx)
 __device__ __forceinline__ int swz(int idx) { return (idx >> 1) & 2; }
 
@@ -112,34 +121,56 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
   const int n0 = n_tile * BN;
   const int nchunks = (Cs + V2_CK - 1) / V2_CK;
 
-  // ---- halo patch staging: NPATCH pixels x 8 float4, ASLOTS per thread, prefetched one chunk ahead in registers
-  float4 ra[ASLOTS];
-  auto load_a = [&](int cc) {
-    const int c0 = cc * V2_CK;
+  // ---- halo patch staging: NPATCH pixels x 8 float4, ASLOTS per thread, prefetched one chunk ahead in registers.
+  // Range-checked buffer loads: a lane's byte offset from the tile's first patch pixel is the same for every K chunk
+  // (the chunk is the scalar offset of the load), pixels outside the image carry an offset beyond the descriptor and
+  // read zeros -- no predication, no per-chunk address arithmetic, no 64-bit per-lane pointers held across the K loop
+  // (the round-2 version spilled to scratch at the 128-register cap of the 16-wave instances and the compiler put a
+  // vmcnt(0) wait right behind the first load of every chunk).
+  constexpr unsigned BAD = 0x80000000u;
+  unsigned voff[ASLOTS], voff_last[ASLOTS];
+  const int c_tail = Cs - (nchunks - 1) * V2_CK;  // channels of the last chunk (1..32)
+  __amdgpu_buffer_rsrc_t a_src;
+  {
+    const bool mapped = KS == 1 && map != 0;
+    const int Hs = mapped ? sd.h[lvl] : H, Ws = mapped ? sd.w[lvl] : W;
+    int64_t base_row;
+    if (!mapped)
+      base_row = rowbase + (int64_t)(ty0 - HALO) * W + (tx0 - HALO);
+    else if (map == 1)
+      base_row = sd.row_off[lvl] + ((int64_t)img * Hs + 2 * ty0) * Ws + 2 * tx0;
+    else
+      base_row = sd.row_off[lvl] + ((int64_t)img * Hs + (ty0 >> 1)) * Ws + (tx0 >> 1);
+    a_src = uniform_rsrc_v2(src + base_row * Cs, 0x7ffffff0);
 #pragma unroll
     for (int i = 0; i < ASLOTS; ++i) {
       const int slot = tid + NT * i;
-      const int q = slot >> 3, c = c0 + 4 * (slot & 7);
+      const int q = slot >> 3, c4 = slot & 7;
       const int py = q / PWK, px = q - py * PWK;
       const int y = ty0 - HALO + py, x = tx0 - HALO + px;
-      bool ok = (slot < NPATCH * 8) && y >= 0 && y < H && x >= 0 && x < W && c < Cs;
-      int64_t row = rowbase + (int64_t)y * W + x;
-      if (KS == 1 && map != 0) {
-        const int Hs = sd.h[lvl], Ws = sd.w[lvl];
-        int sy, sx;
+      bool ok = (slot < NPATCH * 8) && y >= 0 && y < H && x >= 0 && x < W;
+      int pix = py * W + px;
+      if (mapped) {
         if (map == 1) {
-          sy = 2 * y;
-          sx = 2 * x;
+          ok = ok && 2 * y < Hs && 2 * x < Ws;
+          pix = 2 * py * Ws + 2 * px;
         } else {
-          ok = ok && ((y | x) & 1) == 0;
-          sy = y >> 1;
-          sx = x >> 1;
+          ok = ok && ((y | x) & 1) == 0 && (y >> 1) < Hs && (x >> 1) < Ws;
+          pix = (py >> 1) * Ws + (px >> 1);
         }
-        ok = ok && sy < Hs && sx < Ws;
-        row = sd.row_off[lvl] + ((int64_t)img * Hs + sy) * Ws + sx;
       }
-      ra[i] = ok ? *reinterpret_cast<const float4*>(src + row * Cs + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      voff[i] = ok ? (unsigned)((pix * Cs + 4 * c4) * 4) : BAD;
+      voff_last[i] = (4 * c4 < c_tail) ? voff[i] : BAD;
     }
+  }
+  float4 ra[ASLOTS];
+  auto load_a = [&](int cc) {
+    const int soff = cc * (V2_CK * 4);
+    const bool last = cc == nchunks - 1;
+#pragma unroll
+    for (int i = 0; i < ASLOTS; ++i)
+      ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_src, (int)(last ? voff_last[i] : voff[i]),
+                                                                                soff, 0));
   };
   auto store_a = [&]() {
 #pragma unroll
@@ -189,19 +220,36 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
     }
   };
 
+  // LDS-DMA of the weight tiles as buffer loads: a lane's byte offset inside its plane (row n0 + row, source k-group of
+  // its destination slot) is constant, the (chunk, tap) position is the scalar offset -- no 64-bit per-lane pointers
+  // (they were what the 16-wave instances spilled to scratch), no per-tap address arithmetic
+  static_assert(!GL || BSEG <= 2, "the LDS-DMA path keeps at most two descriptors");
+  unsigned boff[BSEG > 0 ? BSEG : 1];
+#pragma unroll
+  for (int i = 0; i < BSEG; ++i) {
+    const int slot = tid + NT * i;
+    const int plane = slot / (BN * 4);       // wave-uniform: BN * 4 is a multiple of 64
+    const int rem = slot - plane * BN * 4;   // destination slot inside the plane: row * 4 + dslot
+    const int row = rem >> 2, seg = (rem & 3) ^ swz(row);  // source k-group of that slot (swz is an involution)
+    boff[i] = (unsigned)((((n0 + row) * NTAPS) * Csw + 8 * seg) * 2);
+  }
+  // descriptor of the plane slot i of this wave reads from (hi / lo): one per slot, the slot's plane is wave-uniform
+  const __amdgpu_buffer_rsrc_t b_src0 =
+      uniform_rsrc_v2(reinterpret_cast<const float*>((tid / (BN * 4)) ? wl : wh), 0x7ffffff0);
+  const __amdgpu_buffer_rsrc_t b_src1 =
+      uniform_rsrc_v2(reinterpret_cast<const float*>(((tid + NT) / (BN * 4)) ? wl : wh), 0x7ffffff0);
   auto issue_b = [&](int cc, int grp, int buf) {
 #pragma unroll
     for (int tt = 0; tt < TPB; ++tt) {
       const int tap = grp * TPB + tt;
+      const int soff = (tap * Csw + cc * V2_CK) * 2;
 #pragma unroll
       for (int i = 0; i < BSEG; ++i) {
         const int slot = tid + NT * i;
         const int plane = slot / (BN * 4);
-        const int rem = slot - plane * BN * 4;   // destination slot inside the plane: row * 4 + dslot
-        const int row = rem >> 2, seg = (rem & 3) ^ swz(row);  // source k-group of that slot (swz is an involution)
-        const __bf16* g = (plane ? wl : wh) + ((int64_t)(n0 + row) * NTAPS + tap) * Csw + cc * V2_CK + 8 * seg;
+        const int rem = slot - plane * BN * 4;
         __bf16* dst = Bs + (((buf * TPB + tt) * 2 + plane) * BN) * 32 + (rem - lane) * 8;  // the wave's first slot
-        __builtin_amdgcn_global_load_lds((v2_glb_ptr)g, (v2_lds_ptr)dst, 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(i == 0 ? b_src0 : b_src1, (v2_lds_ptr)dst, 16, (int)boff[i], soff, 0, 0);
       }
     }
   };

@@ -271,6 +271,39 @@ int64_t scan_groupnorm_ws_floats(const scan_pyramid_t* d, int32_t C, int32_t G);
 int scan_groupnorm_relu_backward(const float* x, const float* beta, const float* dy, const scan_pyramid_t* d, int32_t C,
                                  int32_t G, const float* stats, const float* gamma, int32_t relu, float* dx,
                                  float* dgamma, float* dbeta, int32_t accumulate, float* ws, void* stream);
+/* The same three with y (forward) / dy (backward) as a column slice of a wider row-major matrix: ldy / lddy = its row
+ * stride in floats (a multiple of 4, >= C), the slice starts at the pointer.  The reference concatenates the tower output
+ * with the act maps (torch.cat, fcos_head_discriminator_con.py:104-118); here the tower's last GroupNorm writes straight
+ * into the first C columns of that matrix and reads its gradient from the same columns of the conv's data gradient. */
+int scan_groupnorm_relu_forward_ld(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G, const float* stats,
+                                   const float* gamma, const float* beta, int32_t relu, float* y, int32_t ldy,
+                                   void* stream);
+int scan_groupnorm_relu_forward_from_sums_ld(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
+                                             const float* sums, float eps, const float* gamma, const float* beta,
+                                             int32_t relu, float* y, int32_t ldy, float* stats, void* stream);
+int scan_groupnorm_relu_backward_ld(const float* x, const float* beta, const float* dy, int32_t lddy,
+                                    const scan_pyramid_t* d, int32_t C, int32_t G, const float* stats, const float* gamma,
+                                    int32_t relu, float* dx, float* dgamma, float* dbeta, int32_t accumulate, float* ws,
+                                    void* stream);
+
+/* ---- the source pass's ground-truth plan on the device (reference rpn/fcos/loss.py:40-133: FCOS location -> GT
+ *      assignment and centerness targets; :428-463: graph-node sampling of the source branch).  Rows = pyramid rows
+ *      (level-major, image, y, x); strides [n_levels], soi [n_levels][2] = sizes of interest; boxes [N][G][4] xyxy padded
+ *      to G per image, glabels [N][G], ng [N] = boxes of each image.
+ *      scan_fcos_assign: labels [M] (+ an int32 copy), reg [M][4] = (l, t, r, b) of the assigned box, level_pos
+ *      [SCAN_MAX_LEVELS] = positives per level (device counters; the host reads them once to size the rest).
+ *      scan_fcos_compact: pos_list / neg_list [M]: per level, at its row offset, the rows with label > 0 / == 0 in row
+ *      order.  scan_fcos_nodes (level_pos: HOST copy of the counters): node_index / node_labels [scan_fcos_nodes_count]
+ *      in the reference's order [all negatives picked, all positives], pos_inds [n_pos], reg_pos [n_pos][4], ctr_pos
+ *      [n_pos]. ---- */
+int scan_fcos_assign(const scan_pyramid_t* d, const int32_t* strides, const float* soi, const float* boxes,
+                     const int64_t* glabels, const int32_t* ng, int32_t G, int64_t* labels, int32_t* labels_i32,
+                     float* reg, int32_t* level_pos, void* stream);
+int scan_fcos_compact(const scan_pyramid_t* d, const int64_t* labels, int32_t* pos_list, int32_t* neg_list, void* stream);
+int64_t scan_fcos_nodes_count(const scan_pyramid_t* d, const int32_t* level_pos);
+int scan_fcos_nodes(const scan_pyramid_t* d, const int32_t* level_pos, const int64_t* labels, const float* reg,
+                    const int32_t* pos_list, const int32_t* neg_list, int64_t* node_index, int64_t* node_labels,
+                    int64_t* pos_inds, float* reg_pos, float* ctr_pos, void* stream);
 
 /* ---- 2x2 / stride-2 max pooling on NHWC rows (replaces nn.MaxPool2d(2, 2) of the VGG body,
  *      backbone/mmdetection/vgg.py:33).  x [N,H,W,C], y [N,H/2,W/2,C]; H, W even, C % 4 == 0.

@@ -85,6 +85,15 @@ SIGNATURES = {
     "scan_groupnorm_relu_forward": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "scan_groupnorm_relu_forward_from_sums": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "scan_groupnorm_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
+    "scan_fcos_assign": (ctypes.c_int, [_PD, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "scan_fcos_compact": (ctypes.c_int, [_PD, c_vp, c_vp, c_vp, c_vp]),
+    "scan_fcos_nodes_count": (c_i64, [_PD, c_vp]),
+    "scan_fcos_nodes": (ctypes.c_int, [_PD, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "scan_groupnorm_relu_forward_ld": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    "scan_groupnorm_relu_forward_from_sums_ld": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_vp, c_f32, c_vp, c_vp, c_i32, c_vp,
+                                                                c_i32, c_vp, c_vp]),
+    "scan_groupnorm_relu_backward_ld": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, _PD, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp,
+                                                       c_vp, c_vp, c_i32, c_vp, c_vp]),
     "scan_groupnorm_relu_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, _PD, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "scan_maxpool2x2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_maxpool2x2_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),

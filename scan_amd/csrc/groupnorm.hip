@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, int relu,
                                                        float* __restrict__ y, const double* __restrict__ sums,
-                                                       float eps, float* __restrict__ stats_out) {
+                                                       float eps, float* __restrict__ stats_out, int ldy) {
   const GnBlock b = gn_block(d, tab);
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int g = lane >> 1;
@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
           o.z = fmaxf(o.z, 0.f);
           o.w = fmaxf(o.w, 0.f);
         }
-        *reinterpret_cast<float4*>(y + base + (int64_t)(r + 4 * u) * GN_C) = o;
+        *reinterpret_cast<float4*>(y + (b.row0 + r + 4 * u) * (int64_t)ldy + 4 * lane) = o;
       }
     }
   }
@@ -173,7 +173,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
                                                             const float* __restrict__ dy, scan_pyramid_t d, GnTab tab,
                                                             int G, const float* __restrict__ stats,
                                                             const float* __restrict__ gamma, int relu,
-                                                            double* __restrict__ ws_g, double* __restrict__ ws_c) {
+                                                            double* __restrict__ ws_g, double* __restrict__ ws_c,
+                                                            int lddy) {
   __shared__ double redg[4][32][2];
   __shared__ float redc[4][GN_C][2];
   const GnBlock b = gn_block(d, tab);
@@ -192,7 +193,8 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const float* __restr
       const bool ok = r + 4 * u < b.rows;
       const int64_t off = base + (int64_t)(r + 4 * u) * GN_C;
       xv[u] = ok ? *reinterpret_cast<const float4*>(x + off) : make_float4(0.f, 0.f, 0.f, 0.f);
-      gv[u] = ok ? *reinterpret_cast<const float4*>(dy + off) : make_float4(0.f, 0.f, 0.f, 0.f);
+      gv[u] = ok ? *reinterpret_cast<const float4*>(dy + (b.row0 + r + 4 * u) * (int64_t)lddy + 4 * lane)
+                 : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ gamma, int relu,
                                                            const double* __restrict__ ws_g, float* __restrict__ dx,
                                                            const double* __restrict__ ws_c, float* __restrict__ dgamma,
-                                                           float* __restrict__ dbeta, int accumulate) {
+                                                           float* __restrict__ dbeta, int accumulate, int lddy) {
   if (blockIdx.x == 0) {
     // the channel sums are final (the reduce kernel ran before this launch): fold the GN_REP replicas into dgamma /
     // dbeta here instead of in a one-block launch of its own (256 threads == 256 channels)
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
       if (r + 4 * u < b.rows) {
         const int64_t off = base + (int64_t)(r + 4 * u) * GN_C;
         xv[u] = *reinterpret_cast<const float4*>(x + off);
-        gv[u] = *reinterpret_cast<const float4*>(dy + off);
+        gv[u] = *reinterpret_cast<const float4*>(dy + (b.row0 + r + 4 * u) * (int64_t)lddy + 4 * lane);
       }
     }
 #pragma unroll
@@ -346,40 +348,63 @@ extern "C" int scan_groupnorm_stats_from_sums(const float* ws, const scan_pyrami
   return 0;
 }
 
-extern "C" int scan_groupnorm_relu_forward(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
-                                           const float* stats, const float* gamma, const float* beta, int32_t relu,
-                                           float* y, void* stream) {
-  if (gn_check(d, C, G, "groupnorm_relu_forward")) return -1;
+// ld variants: y (forward) / dy (backward) may be a column slice of a wider row-major matrix -- ldy / lddy = its row
+// stride in floats (a multiple of 4, >= C; the slice starts at the pointer).  The CKA discriminators normalise straight
+// into the first 256 columns of the [M, 256 + Cf] class-branch input and take the gradient back from the same columns
+// of its data gradient: no concatenation copy forward, no contiguous() copy backward.
+static int gn_ld_check(int ld, int C, const char* who) {
+  SCAN_CHECK_ARG(ld >= C && ld % 4 == 0, "%s: row stride %d must be a multiple of 4 and >= C", who, ld);
+  return 0;
+}
+
+extern "C" int scan_groupnorm_relu_forward_ld(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
+                                              const float* stats, const float* gamma, const float* beta, int32_t relu,
+                                              float* y, int32_t ldy, void* stream) {
+  if (gn_check(d, C, G, "groupnorm_relu_forward") || gn_ld_check(ldy, C, "groupnorm_relu_forward")) return -1;
   SCAN_CHECK_ARG(x && stats && gamma && beta && y, "groupnorm_relu_forward: null pointer");
   GnTab tab;
   const int nblk = gn_tab(d, &tab);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), x, *d, tab, G, stats, gamma, beta, relu, y,
-                     (const double*)nullptr, 0.f, (float*)nullptr);
+                     (const double*)nullptr, 0.f, (float*)nullptr, ldy);
   SCAN_LAUNCH_CHECK("gn_apply");
   return 0;
 }
 
+extern "C" int scan_groupnorm_relu_forward(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
+                                           const float* stats, const float* gamma, const float* beta, int32_t relu,
+                                           float* y, void* stream) {
+  return scan_groupnorm_relu_forward_ld(x, d, C, G, stats, gamma, beta, relu, y, C, stream);
+}
+
 // scan_groupnorm_stats_from_sums + scan_groupnorm_relu_forward in one launch: sums = fp64 [n_levels*N*G][2] from
 // scan_conv3x3_gn_bf16x3's epilogue; stats [n_levels*N*G][2] is written for the backward pass.
-extern "C" int scan_groupnorm_relu_forward_from_sums(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
-                                                     const float* sums, float eps, const float* gamma,
-                                                     const float* beta, int32_t relu, float* y, float* stats,
-                                                     void* stream) {
-  if (gn_check(d, C, G, "groupnorm_relu_forward_from_sums")) return -1;
+extern "C" int scan_groupnorm_relu_forward_from_sums_ld(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
+                                                        const float* sums, float eps, const float* gamma,
+                                                        const float* beta, int32_t relu, float* y, int32_t ldy,
+                                                        float* stats, void* stream) {
+  if (gn_check(d, C, G, "groupnorm_relu_forward_from_sums") || gn_ld_check(ldy, C, "groupnorm_relu_forward_from_sums"))
+    return -1;
   SCAN_CHECK_ARG(x && sums && stats && gamma && beta && y, "groupnorm_relu_forward_from_sums: null pointer");
   GnTab tab;
   const int nblk = gn_tab(d, &tab);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(nblk), dim3(256), 0, as_stream(stream), x, *d, tab, G, (const float*)nullptr,
-                     gamma, beta, relu, y, reinterpret_cast<const double*>(sums), eps, stats);
+                     gamma, beta, relu, y, reinterpret_cast<const double*>(sums), eps, stats, ldy);
   SCAN_LAUNCH_CHECK("gn_apply_from_sums");
   return 0;
 }
 
-extern "C" int scan_groupnorm_relu_backward(const float* x, const float* beta, const float* dy, const scan_pyramid_t* d,
-                                            int32_t C, int32_t G, const float* stats, const float* gamma, int32_t relu,
-                                            float* dx, float* dgamma, float* dbeta, int32_t accumulate, float* ws,
-                                            void* stream) {
-  if (gn_check(d, C, G, "groupnorm_relu_backward")) return -1;
+extern "C" int scan_groupnorm_relu_forward_from_sums(const float* x, const scan_pyramid_t* d, int32_t C, int32_t G,
+                                                     const float* sums, float eps, const float* gamma,
+                                                     const float* beta, int32_t relu, float* y, float* stats,
+                                                     void* stream) {
+  return scan_groupnorm_relu_forward_from_sums_ld(x, d, C, G, sums, eps, gamma, beta, relu, y, C, stats, stream);
+}
+
+extern "C" int scan_groupnorm_relu_backward_ld(const float* x, const float* beta, const float* dy, int32_t lddy,
+                                               const scan_pyramid_t* d, int32_t C, int32_t G, const float* stats,
+                                               const float* gamma, int32_t relu, float* dx, float* dgamma, float* dbeta,
+                                               int32_t accumulate, float* ws, void* stream) {
+  if (gn_check(d, C, G, "groupnorm_relu_backward") || gn_ld_check(lddy, C, "groupnorm_relu_backward")) return -1;
   SCAN_CHECK_ARG(x && dy && stats && gamma && dx && dgamma && dbeta && ws && (beta || !relu),
                  "groupnorm_relu_backward: null pointer");
   hipStream_t st = as_stream(stream);
@@ -392,10 +417,19 @@ extern "C" int scan_groupnorm_relu_backward(const float* x, const float* beta, c
   }
   GnTab tab;
   const int nblk = gn_tab(d, &tab);
-  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, x, beta, dy, *d, tab, G, stats, gamma, relu, ws_g, ws_c);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(nblk), dim3(256), 0, st, x, beta, dy, *d, tab, G, stats, gamma, relu, ws_g, ws_c,
+                     lddy);
   SCAN_LAUNCH_CHECK("gn_bwd_reduce");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, x, beta, dy, *d, tab, G, stats, gamma, relu, ws_g, dx,
-                     ws_c, dgamma, dbeta, accumulate);
+                     ws_c, dgamma, dbeta, accumulate, lddy);
   SCAN_LAUNCH_CHECK("gn_bwd_apply");
   return 0;
+}
+
+extern "C" int scan_groupnorm_relu_backward(const float* x, const float* beta, const float* dy, const scan_pyramid_t* d,
+                                            int32_t C, int32_t G, const float* stats, const float* gamma, int32_t relu,
+                                            float* dx, float* dgamma, float* dbeta, int32_t accumulate, float* ws,
+                                            void* stream) {
+  return scan_groupnorm_relu_backward_ld(x, beta, dy, C, d, C, G, stats, gamma, relu, dx, dgamma, dbeta, accumulate, ws,
+                                         stream);
 }

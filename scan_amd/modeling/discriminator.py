@@ -61,11 +61,19 @@ class FCOSDiscriminator_con(nn.Module):
         Cf = self.num_classes
         feature = self.grad_reverse(feature)
         act_maps = self.grad_reverse(act_maps)
-        x = run_tower(self.dis_tower, feature, shape, self.num_convs)
-        xcat = torch.cat([x, act_maps[:, 1:]], 1)  # [M, 256 + Cf]; 264 is a multiple of 4
-        pad = ops.pad4(xcat.shape[1]) - xcat.shape[1]
-        if pad:
-            xcat = torch.nn.functional.pad(xcat, (0, pad))
+        # cat([x, act[1:]], 1) (reference :104-118) without copying x: the tower's last GroupNorm writes into the first
+        # 256 columns of the [M, pad4(256 + Cf)] class-branch input, only the Cf act columns are copied behind them, and
+        # the backward hands the GroupNorm its column slice of the conv's data gradient in place
+        cs1 = ops.pad4(self.in_channels + Cf)
+        if ops.CAT_IN_PLACE and self.num_convs > 0:
+            buf = feature.new_empty((feature.shape[0], cs1))
+            x = run_tower(self.dis_tower, feature, shape, self.num_convs, out_buf=buf)
+            xcat = ops.cat_into(x, act_maps[:, 1:], buf)
+        else:
+            x = run_tower(self.dis_tower, feature, shape, self.num_convs)
+            xcat = torch.cat([x, act_maps[:, 1:]], 1)  # [M, 256 + Cf]; 264 is a multiple of 4
+            if cs1 != xcat.shape[1]:
+                xcat = torch.nn.functional.pad(xcat, (0, cs1 - xcat.shape[1]))
         blocks = [getattr(self, "classifier_cls_%d" % c) for c in range(Cf)]
         if ops.BATCHED:
             w1, b1, w2, b2 = ops.cka_stacked_weights([(b[0], b[2]) for b in blocks], self.in_channels, 128,

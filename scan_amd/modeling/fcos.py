@@ -7,6 +7,7 @@ Because a pyramid's rows are already in the reference's flatten order (level-maj
 image, y, x; rpn/fcos/loss.py:191-202) the losses consume the conv outputs with no
 permute/reshape/cat copies.
 """
+import ctypes
 import math
 
 import torch
@@ -28,13 +29,15 @@ def make_tower(n, c=256):
     return nn.Sequential(*layers)
 
 
-def run_tower(tower, rows, shape, n):
+def run_tower(tower, rows, shape, n, out_buf=None):
     """n x [conv3x3 (MFMA), GroupNorm(32)+ReLU (fused HIP)] sharing weights across the levels:
-    one launch per layer covers the whole pyramid."""
+    one launch per layer covers the whole pyramid.  out_buf: a wider [M, C + e] matrix whose first C columns receive
+    the tower's output (ops.groupnorm_relu(out_buf=...)); the returned rows are that column slice."""
     for i in range(n):
         conv, gn = tower[3 * i], tower[3 * i + 1]
         rows = ops.conv2d(rows, conv.weight, conv.bias, shape, 3, 1, gn_sums=True)  # GN sums from the conv epilogue
-        rows = ops.groupnorm_relu(rows, gn.weight, gn.bias, shape, relu=True, eps=gn.eps)
+        rows = ops.groupnorm_relu(rows, gn.weight, gn.bias, shape, relu=True, eps=gn.eps,
+                                  out_buf=out_buf if i == n - 1 else None)
     return rows
 
 
@@ -115,7 +118,55 @@ def target_plan(shape, targets, device, side_stream=None, after=None):
     return p
 
 
+DEVICE_PLAN = True  # False: the torch spelling below also on the GPU (A/B, cross-checks)
+
+
+def _build_plan_device(shape, targets, device):
+    """The plan in three launches of csrc/targets.hip and ONE host read (the five per-level positive counts) instead of
+    ~115 torch launches with a dozen host round trips; bit-identical to the torch spelling below."""
+    p = TargetPlan()
+    p.ready = None
+    N, L, M = shape.n_images, shape.n_levels, shape.rows
+    G = max(1, max(int(b.shape[0]) for b, _ in targets))
+    boxes = torch.zeros((N, G, 4), dtype=torch.float32, device=device)
+    glab = torch.zeros((N, G), dtype=torch.int64, device=device)
+    for i, (b, l) in enumerate(targets):
+        g = int(b.shape[0])
+        if g:
+            boxes[i, :g] = b.to(device=device, dtype=torch.float32)
+            glab[i, :g] = l.to(device=device, dtype=torch.int64)
+    ng = torch.tensor([int(b.shape[0]) for b, _ in targets], dtype=torch.int32).to(device)
+    st = ops._stream()
+    p.labels = torch.empty((M,), dtype=torch.int64, device=device)
+    p.labels_i32 = torch.empty((M,), dtype=torch.int32, device=device)
+    p.reg_targets = torch.empty((M, 4), dtype=torch.float32, device=device)
+    level_pos = torch.empty((8,), dtype=torch.int32, device=device)
+    pos_list = torch.empty((M,), dtype=torch.int32, device=device)
+    neg_list = torch.empty((M,), dtype=torch.int32, device=device)
+    strides_h = (ctypes.c_int32 * L)(*FPN_STRIDES[:L])
+    soi_h = (ctypes.c_float * (2 * L))(*[float(v) for l in range(L) for v in SIZES_OF_INTEREST[l]])
+    ops.call("scan_fcos_assign", shape.ref(), strides_h, soi_h, ops._ptr(boxes), ops._ptr(glab), ops._ptr(ng), G,
+             ops._ptr(p.labels), ops._ptr(p.labels_i32), ops._ptr(p.reg_targets), ops._ptr(level_pos), st)
+    ops.call("scan_fcos_compact", shape.ref(), ops._ptr(p.labels), ops._ptr(pos_list), ops._ptr(neg_list), st)
+    counts = level_pos[:L].tolist()  # the one host round trip of the plan
+    cnt_h = (ctypes.c_int32 * L)(*counts)
+    n_nodes = ops.query("scan_fcos_nodes_count", shape.ref(), cnt_h)
+    p.n_pos = int(sum(counts))
+    p.node_index = torch.empty((n_nodes,), dtype=torch.int64, device=device)
+    p.node_labels = torch.empty((n_nodes,), dtype=torch.int64, device=device)
+    p.pos_inds = torch.empty((p.n_pos,), dtype=torch.int64, device=device)
+    p.reg_pos = torch.empty((p.n_pos, 4), dtype=torch.float32, device=device)
+    ctr = torch.empty((p.n_pos,), dtype=torch.float32, device=device)
+    ops.call("scan_fcos_nodes", shape.ref(), cnt_h, ops._ptr(p.labels), ops._ptr(p.reg_targets), ops._ptr(pos_list),
+             ops._ptr(neg_list), ops._ptr(p.node_index), ops._ptr(p.node_labels), ops._ptr(p.pos_inds),
+             ops._ptr(p.reg_pos), ops._ptr(ctr), st)
+    p.ctr_pos = ctr if p.n_pos > 0 else None
+    return p
+
+
 def _build_plan(shape, targets, device):
+    if DEVICE_PLAN and device.type == "cuda" and targets and all(int(b.shape[0]) > 0 for b, _ in targets):
+        return _build_plan_device(shape, targets, device)
     p = TargetPlan()
     p.ready = None
     p.labels, p.reg_targets = assign_targets(compute_locations(shape, device), targets)

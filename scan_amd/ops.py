@@ -181,6 +181,9 @@ def _round8(c):
 # separate GroupNorm statistics finalisation -- for same-box A/B measurements (profiles/r02_batched_ab.txt).  Same
 # results either way.
 BATCHED = os.environ.get("SCAN_BATCHED", "1") != "0"
+# SCAN_CAT_IN_PLACE=0: the CKA discriminators build their class-branch input with torch.cat (+ the contiguous() copy of
+# its gradient slice in the GroupNorm backward) instead of normalising into place, for A/B.  Same values.
+CAT_IN_PLACE = os.environ.get("SCAN_CAT_IN_PLACE", "1") != "0"
 SPLIT_EPOCH = None
 _split_cache = {}
 _epoch_counter = [0]
@@ -629,29 +632,45 @@ def add_relu(a, b):
 
 
 # ----------------------------------------------------------------------------- GroupNorm + ReLU
+def _col_slice_ld(t, C):
+    """row stride (floats) of t when it is a [M, C] column slice of a wider row-major fp32 matrix that the kernels can
+    address in place (unit column stride, 16-byte aligned rows), else None"""
+    if t.dim() == 2 and t.shape[1] == C and t.stride(1) == 1 and t.stride(0) >= C and t.stride(0) % 4 == 0 \
+            and t.data_ptr() % 16 == 0:
+        return t.stride(0)
+    return None
+
+
 class _GroupNormReLU(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, shape, relu, eps):
+    def forward(ctx, x, gamma, beta, shape, relu, eps, out_buf=None):
         _chk(x, gamma, beta)
         C = x.shape[1]
         st = _stream()
         stats = x.new_empty((shape.n_levels * shape.n_images * 32 * 2,))
         sums = _gn_sums.pop(x.data_ptr(), None)
-        y = torch.empty_like(x)
+        if out_buf is None:
+            y, ldy = torch.empty_like(x), C
+        else:  # normalise straight into the first C columns of a wider matrix (cat_into completes it)
+            if not (out_buf.is_cuda and out_buf.dtype == torch.float32 and out_buf.is_contiguous()
+                    and out_buf.shape[0] == x.shape[0] and out_buf.shape[1] >= C and out_buf.shape[1] % 4 == 0):
+                raise RuntimeError("groupnorm_relu: out_buf must be a contiguous fp32 [M, >= C] GPU matrix with a row "
+                                   "length that is a multiple of 4")
+            y, ldy = out_buf[:, :C], out_buf.shape[1]
         if sums is not None and not BATCHED:
             call("scan_groupnorm_stats_from_sums", _ptr(sums), shape.ref(), C, 32, eps, _ptr(stats), st)
-            call("scan_groupnorm_relu_forward", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta),
-                 int(relu), _ptr(y), st)
+            call("scan_groupnorm_relu_forward_ld", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta),
+                 int(relu), _ptr(y), ldy, st)
         elif sums is not None:  # accumulated by the epilogue of the conv that produced x: one launch normalises and
             # leaves (mean, rstd) behind for the backward
-            call("scan_groupnorm_relu_forward_from_sums", _ptr(x), shape.ref(), C, 32, _ptr(sums), eps, _ptr(gamma),
-                 _ptr(beta), int(relu), _ptr(y), _ptr(stats), st)
+            call("scan_groupnorm_relu_forward_from_sums_ld", _ptr(x), shape.ref(), C, 32, _ptr(sums), eps, _ptr(gamma),
+                 _ptr(beta), int(relu), _ptr(y), ldy, _ptr(stats), st)
         else:
             nws = query("scan_groupnorm_ws_floats", shape.ref(), C, 32)
             ws = torch.empty((nws // 2 + 1,), dtype=torch.float64, device=x.device)
             call("scan_groupnorm_stats", _ptr(x), shape.ref(), C, 32, eps, _ptr(stats), _ptr(ws), st)
-            call("scan_groupnorm_relu_forward", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta),
-                 int(relu), _ptr(y), st)
+            call("scan_groupnorm_relu_forward_ld", _ptr(x), shape.ref(), C, 32, _ptr(stats), _ptr(gamma), _ptr(beta),
+                 int(relu), _ptr(y), ldy, st)
         ctx.save_for_backward(x, beta, gamma, stats)  # the backward recomputes the ReLU mask from x: y is not kept
         ctx.cfg = (shape, relu)
         ctx.gbuf = ctx.bbuf = None
@@ -665,22 +684,54 @@ class _GroupNormReLU(torch.autograd.Function):
         x, beta, gamma, stats = ctx.saved_tensors
         shape, relu = ctx.cfg
         C = x.shape[1]
-        dy = dy.contiguous()
+        lddy = _col_slice_ld(dy, C)  # e.g. the first C columns of the class-branch conv's data gradient: read in place
+        if lddy is None:
+            dy, lddy = dy.contiguous(), C
         nws = query("scan_groupnorm_ws_floats", shape.ref(), C, 32)
         ws = torch.empty((nws // 2 + 1,), dtype=torch.float64, device=x.device)
         dx = torch.empty_like(x)
         direct = ctx.gbuf is not None
         dg = ctx.gbuf if direct else x.new_empty((C,))
         db = ctx.bbuf if direct else x.new_empty((C,))
-        call("scan_groupnorm_relu_backward", _ptr(x), _ptr(beta), _ptr(dy), shape.ref(), C, 32, _ptr(stats), _ptr(gamma),
-             int(relu), _ptr(dx), _ptr(dg), _ptr(db), int(direct), _ptr(ws), _stream())
+        call("scan_groupnorm_relu_backward_ld", _ptr(x), _ptr(beta), _ptr(dy), lddy, shape.ref(), C, 32, _ptr(stats),
+             _ptr(gamma), int(relu), _ptr(dx), _ptr(dg), _ptr(db), int(direct), _ptr(ws), _stream())
         if direct:
-            return dx, None, None, None, None, None
-        return dx, dg, db, None, None, None
+            return dx, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None
 
 
-def groupnorm_relu(x, gamma, beta, shape, relu=True, eps=1e-5):
-    return _GroupNormReLU.apply(x, gamma, beta, shape, relu, eps)
+def groupnorm_relu(x, gamma, beta, shape, relu=True, eps=1e-5, out_buf=None):
+    """out_buf: a contiguous [M, C + e] matrix -- the result is written into (and returned as) its first C columns;
+    cat_into() then adds the remaining columns without copying these."""
+    return _GroupNormReLU.apply(x, gamma, beta, shape, relu, eps, out_buf)
+
+
+class _CatInto(torch.autograd.Function):
+    """cat([y, extra, zeros], 1) where y already IS the first C columns of ``buf`` (groupnorm_relu(out_buf=buf)): only
+    the few extra columns are copied.  Backward: the two column slices of the gradient, as views -- the GroupNorm
+    backward reads its slice in place (scan_groupnorm_relu_backward_ld)."""
+
+    @staticmethod
+    def forward(ctx, y, extra, buf):
+        C, e = y.shape[1], extra.shape[1]
+        if y.data_ptr() != buf.data_ptr() or y.stride(0) != buf.shape[1] or C + e > buf.shape[1]:
+            raise RuntimeError("cat_into: y must be the leading columns of buf")
+        buf[:, C:C + e] = extra
+        if C + e < buf.shape[1]:
+            buf[:, C + e:] = 0
+        ctx.cols = (C, e)
+        # a fresh tensor object over buf's storage: to autograd the result is not a view of an input
+        return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(buf.untyped_storage(), buf.storage_offset(),
+                                                                      buf.shape, buf.stride())
+
+    @staticmethod
+    def backward(ctx, g):
+        C, e = ctx.cols
+        return g[:, :C], g[:, C:C + e], None
+
+
+def cat_into(y, extra, buf):
+    return _CatInto.apply(y, extra, buf)
 
 
 # ----------------------------------------------------------------------------- dynamic conv + softmax

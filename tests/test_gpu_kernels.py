@@ -1040,3 +1040,56 @@ def test_new_entry_points_reject_bad_arguments(device):
     with pytest.raises(RuntimeError, match="from_sums"):
         _lib.call("scan_groupnorm_relu_forward_from_sums", P(x), shape.ref(), 256, 32, None, 1e-5, P(x), P(x), 1, P(x), P(x), st)
     assert _lib.query("scan_tune", b"no_such_knob", 1) == -1
+
+
+# ----------------------------------------------------------------------------- ground-truth plan (csrc/targets.hip)
+@pytest.mark.parametrize("case", ["bench_like", "crowded_small_level", "one_box", "ragged_counts"])
+def test_target_plan_kernels_equal_torch_plan(device, case):
+    """scan_fcos_assign / _compact / _nodes against the torch spelling of the plan (modeling/fcos.py: assign_targets,
+    source_node_index, centerness_targets -- the functions the CPU tests pin against the reference's label maps and node
+    lists): labels, node index and node labels, positive rows bit-identical; regression and centerness targets of the
+    positives bit-identical.  Cases: the bench geometry; boxes covering most of a small level (n_pos > n_neg on it, every
+    background row taken); a single box; images with different box counts (padded slots must not be read)."""
+    from scan_amd import synth
+    from scan_amd.modeling import fcos
+    g = torch.Generator().manual_seed(5)
+    if case == "bench_like":
+        H, W, N = 512, 1024, 2
+        targets = synth.synth_targets(N, H, W, 8, 12, 4321)
+    elif case == "crowded_small_level":
+        H, W, N = 128, 256, 2
+        big = torch.tensor([[2.0, 2.0, W - 3.0, H - 3.0], [10.0, 8.0, W - 20.0, H - 9.0]])
+        targets = [(big.clone(), torch.tensor([3, 5])), (big[:1].clone(), torch.tensor([1]))]
+    elif case == "one_box":
+        H, W, N = 96, 160, 1
+        targets = [(torch.tensor([[20.0, 16.0, 90.0, 70.0]]), torch.tensor([2]))]
+    else:
+        H, W, N = 256, 256, 3
+        targets = []
+        for n, k in enumerate((1, 7, 3)):
+            xy = torch.rand(k, 2, generator=g) * 150
+            wh = torch.rand(k, 2, generator=g) * 100 + 8
+            targets.append((torch.cat([xy, xy + wh], 1), torch.randint(1, 9, (k,), generator=g)))
+    targets = [(b.to(device), l.to(device)) for b, l in targets]
+    shape = __import__("scan_amd.ops", fromlist=["PyramidShape"]).PyramidShape(
+        N, [((H + s - 1) // s, (W + s - 1) // s) for s in fcos.FPN_STRIDES])
+    dev_plan = fcos._build_plan_device(shape, targets, device)
+    fcos.DEVICE_PLAN = False
+    try:
+        ref = fcos._build_plan(shape, targets, device)
+    finally:
+        fcos.DEVICE_PLAN = True
+    torch.cuda.synchronize()
+    assert torch.equal(dev_plan.labels, ref.labels) and torch.equal(dev_plan.labels_i32, ref.labels_i32)
+    assert dev_plan.n_pos == ref.n_pos and dev_plan.n_pos > 0
+    assert torch.equal(dev_plan.pos_inds, ref.pos_inds)
+    assert torch.equal(dev_plan.node_index, ref.node_index), (dev_plan.node_index.shape, ref.node_index.shape)
+    assert torch.equal(dev_plan.node_labels, ref.node_labels)
+    assert torch.equal(dev_plan.reg_pos, ref.reg_pos)
+    assert torch.equal(dev_plan.reg_targets[ref.pos_inds], ref.reg_targets[ref.pos_inds])
+    assert torch.equal(dev_plan.ctr_pos.view(torch.int32), ref.ctr_pos.view(torch.int32))
+    if case == "crowded_small_level":  # the branch "more positives than background rows" was really taken
+        lab = ref.labels
+        per_level = [(int((lab[shape.row_off[l]:shape.row_off[l + 1]] > 0).sum()), shape.row_off[l + 1] - shape.row_off[l])
+                     for l in range(shape.n_levels)]
+        assert any(p > r - p for p, r in per_level), per_level

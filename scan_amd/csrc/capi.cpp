@@ -33,6 +33,8 @@ extern int g_scan_wgrad_exp;
 extern int g_scan_wgrad_v4;
 extern int g_scan_wgrad_v5;
 extern int g_scan_wgrad_il;
+extern int g_scan_wgrad_v6;
+extern int g_scan_wgrad_prio;
 
 static int* tune_slot(const char* key) {
   int* slot = nullptr;
@@ -51,6 +53,8 @@ static int* tune_slot(const char* key) {
   if (strcmp(key, "wgrad_v4") == 0) slot = &g_scan_wgrad_v4;
   if (strcmp(key, "wgrad_v5") == 0) slot = &g_scan_wgrad_v5;
   if (strcmp(key, "wgrad_il") == 0) slot = &g_scan_wgrad_il;
+  if (strcmp(key, "wgrad_v6") == 0) slot = &g_scan_wgrad_v6;
+  if (strcmp(key, "wgrad_prio") == 0) slot = &g_scan_wgrad_prio;
   return slot;
 }
 

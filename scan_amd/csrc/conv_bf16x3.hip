@@ -26,6 +26,7 @@
 // dgrad reuses the same kernel: dX = conv3x3(dY, W') with W'[c][t][o] = W[o][8-t][c]
 // (scan_weight_split mode 1 writes the flipped + transposed copy).
 #include "common.h"
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4v __attribute__((ext_vector_type(4)));
@@ -1897,6 +1898,320 @@ __global__ __launch_bounds__(NT, 2) void conv_wgrad_bf16x3_v5_kernel(
 }
 
 
+// ------------------------------------------------------------------------------------------------
+// Sixth generation: producer / consumer wave specialisation.  What is left of a K chunk in the fourth generation beside
+// its MFMAs (3.8 us per chunk against 2.9 us for the MFMA phase with its barriers alone, profiles/r03_wgrad_exp.txt) is
+// the fp32 -> bf16 hi / lo split and the LDS writes, which all eight waves execute together between two barriers while
+// the matrix pipe idles.  Here a workgroup has 12 waves: waves 0..7 ONLY read fragments and issue MFMAs (the 2 x 4 wave
+// grid of the earlier generations, two per SIMD), waves 8..11 -- one per SIMD -- ONLY stage: they walk the chunks (scalar
+// state, range-checked buffer loads, as in the fourth generation), split and write the NEXT chunk into the other of two
+// LDS stages (288-byte rows, see wsw6: 2 x 73 KB) while the consumers multiply the current
+// one, and fetch the chunk after that.  One barrier per chunk; the vector ALU work of the split runs beside the matrix
+// pipe on every SIMD instead of in front of it.  168 registers per lane (three waves per SIMD): the accumulators live
+// in the consumer branch only, the staging registers in the producer branch only.  Same K order: bit-identical slabs.
+// ------------------------------------------------------------------------------------------------
+// LDS image of the sixth generation: two stages must fit, and the transposed-read addresses must stay "base + immediate"
+// (the unpadded image of the third generation XORs four row bits into the column: one address register per (tile, tap,
+// row group), which does not fit beside 96 accumulators at three waves per SIMD).  Rows are 288 bytes (256 + 32 pad):
+// consecutive rows start 8 banks apart, so the four pixel rows a 16-lane group of ds_read_b64_tr_b16 touches (32 bytes
+// each) cover 32 banks; the other lane group of the same half wave reads rows 8 further (64 banks = 0 further) and is
+// moved to the other 32 banks by swapping the two 128-byte halves of a row when bit 3 of the row index is set.
+#define W6ROW 144  // bf16 elements per LDS row
+#define W6STAGE(KX) ((2 * WK + 2 * (WK + (KX) - 1)) * W6ROW)  // bf16 elements per stage: 74,880 B for the 3x3
+__device__ __forceinline__ int wsw6(int row, int col) { return row * W6ROW + (col ^ (((row >> 3) & 1) << 6)); }
+
+// Fragment addresses as "lane base + compile-time offset": the half-row swap of wsw6 is applied to the lane's base column
+// only (adding 16 t or 16 tc afterwards never carries into bit 6: the base columns are 64 wm + col4 and 32 wn + col4,
+// col4 < 16), and a row offset is an immediate wherever it cannot change bit 3 of the row -- true for the rows
+// 8 kg + q (+ kx) and 8 kg + q + 4, q = (lane & 15) >> 2; only rows 8 kg + q + 4 + kx, kx = 1, 2 may cross into the next
+// group of eight and get bases of their own.  Four address registers instead of one per (tile, tap, row group).
+struct W6Lane {
+  int a;        // (row 8 kg + q, column a_col + col4): A operand, rows + 4 and tiles + 16 t by immediate
+  int b;        // (row 8 kg + q, column b_col + col4): B operand, rows + kx, + 4 (kx = 0) and tiles + 16 tc by immediate
+  int b1[2];    // (row 8 kg + q + 4 + kx, same column), kx = 1, 2
+};
+__device__ __forceinline__ W6Lane w6_lane(int row_lane, int col4, int a_col, int b_col) {
+  W6Lane w;
+  w.a = wsw6(row_lane, a_col + col4);
+  w.b = wsw6(row_lane, b_col + col4);
+  w.b1[0] = wsw6(row_lane + 5, b_col + col4);
+  w.b1[1] = wsw6(row_lane + 6, b_col + col4);
+  return w;
+}
+
+template <int TO, int KX, int TOMAX>
+__device__ __forceinline__ void wgrad_mma_v6(const __bf16* Ah, const __bf16* Al, const __bf16* Bh, const __bf16* Bl,
+                                             const W6Lane& w, f32x4v (&acc)[KX][TOMAX][2]) {
+#pragma unroll
+  for (int s = 0; s < WK / 32; ++s) {
+    bf16x8 ah[TO], al[TO];
+#pragma unroll
+    for (int t = 0; t < TO; ++t) {
+      const int o0 = w.a + 32 * s * W6ROW + 16 * t, o1 = o0 + 4 * W6ROW;
+      ah[t] = tr_read8_v2(Ah + o0, Ah + o1);
+      al[t] = tr_read8_v2(Al + o0, Al + o1);
+    }
+#pragma unroll
+    for (int kx = 0; kx < KX; ++kx) {
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        // X row j <-> pixel x0 - HALO + j: tap kx is a row shift
+        const int o0 = w.b + (32 * s + kx) * W6ROW + 16 * tc;
+        const int o1 = (kx == 0 ? w.b + 4 * W6ROW : w.b1[kx - 1]) + 32 * s * W6ROW + 16 * tc;
+        const bf16x8 bh = tr_read8_v2(Bh + o0, Bh + o1);
+        const bf16x8 bl = tr_read8_v2(Bl + o0, Bl + o1);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[to], bh, acc[kx][to][tc], 0, 0, 0);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[to], bl, acc[kx][to][tc], 0, 0, 0);
+#pragma unroll
+        for (int to = 0; to < TO; ++to) acc[kx][to][tc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[to], bh, acc[kx][to][tc], 0, 0, 0);
+      }
+    }
+  }
+}
+
+template <int KX>
+__global__ __launch_bounds__(768, 3) void conv_wgrad_bf16x3_v6_kernel(
+    const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
+    float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
+    int chunks_per_split, int splits, int dbg, int prio) {
+  // dbg (scan_tune "wgrad_exp" 5 / 6 / 7, timing only, wrong results): bit 0 = the consumers skip their MFMA phase, bit 1 =
+  // the producers stage the first two chunks only
+  constexpr int HALO = KX / 2, T = KX * KX;
+  constexpr int TOMAX = 4;                            // 16-row o tiles per consumer wave (64 o x 32 c per wave)
+  constexpr int PRG = 8;                              // pixel-row groups of the 256 producer threads
+  constexpr int NA = WK / PRG;                        // dY float4 per producer thread per chunk
+  constexpr int NB = (WK + KX - 1 + PRG - 1) / PRG;   // X float4 per producer thread per chunk
+  constexpr unsigned BAD = 0x80000000u;
+  extern __shared__ __align__(16) unsigned char smem_raw[];
+  __bf16* sm = reinterpret_cast<__bf16*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int L = blockIdx.x;
+  const int xcd = L & 7;
+  const int qq = L >> 3;
+  int tile = __builtin_amdgcn_readfirstlane(qq % n_tiles);
+  const int split = __builtin_amdgcn_readfirstlane(qq / n_tiles) * 8 + xcd;
+  const int c_tile = __builtin_amdgcn_readfirstlane(tile % c_tiles);
+  tile = __builtin_amdgcn_readfirstlane(tile / c_tiles);
+  const int ky = __builtin_amdgcn_readfirstlane(tile % KX);
+  const int o_tile = __builtin_amdgcn_readfirstlane(tile / KX);
+  const int o0 = o_tile * 128, c0 = c_tile * 128;
+  const long long total_chunks = ct.chunk_off[d.n_levels];
+  const long long ch_begin = (long long)split * chunks_per_split;
+  long long ch_end = ch_begin + chunks_per_split;
+  if (ch_end > total_chunks) ch_end = total_chunks;
+  const int nch = ch_end > ch_begin ? (int)(ch_end - ch_begin) : 0;
+  const bool do_bias = (bias_slab != nullptr) && ky == HALO && c_tile == 0;
+
+  if (wid >= 8) {
+    // =============================================================== producers: one wave per SIMD
+    // Per-lane offsets: one register per operand, the pixel-row group i of a load is its scalar offset.
+    // static priority for the staging wave of a SIMD (scan_tune "wgrad_prio"): its vector instructions are few beside
+    // its two partners' MFMA streams, but arbitrated by age it loses the issue slot to them and reaches the barrier last
+    if (prio > 0) __builtin_amdgcn_s_setprio(3);
+    const int ptid = tid - 512;
+    const int q4 = ptid & 31, rr = ptid >> 5;
+    const int o = o0 + 4 * q4, c = c0 + 4 * q4;
+    const unsigned offa = (o < Ns) ? (unsigned)((rr * Ns + o) * 4) : BAD;
+    const unsigned offb = (c < Cs) ? (unsigned)((rr * Cs + c) * 4) : BAD;
+    const unsigned offb_last = (rr + PRG * (NB - 1) < WK + KX - 1) ? offb : BAD;  // rows of the last group beyond the halo
+    int lvl = 0;
+#pragma unroll
+    for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+      if (i < d.n_levels && ch_begin >= ct.chunk_off[i]) lvl = i;
+    int segs = lvl_pick(ct.segs, lvl), H = lvl_pick(d.h, lvl), W = lvl_pick(d.w, lvl);
+    long long row0 = lvl_pick64(d.row_off, lvl);
+    int seg, n, y;
+    {
+      const long long r = (nch > 0 ? ch_begin : 0) - ct.chunk_off[lvl];
+      const long long rowl = r / segs;
+      seg = __builtin_amdgcn_readfirstlane((int)(r - rowl * segs));
+      n = __builtin_amdgcn_readfirstlane((int)(rowl / H));
+      y = __builtin_amdgcn_readfirstlane((int)(rowl - (long long)(rowl / H) * H));
+    }
+    float4 ra[NA], rb[NB];
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    __amdgpu_buffer_rsrc_t ra_src, rb_src;
+    bool left_edge = false;
+    auto prepare = [&](bool live) {  // descriptors of the chunk at (lvl, n, y, seg); !live: zero records
+      const int x0 = seg * WK;
+      const long long rowbase = row0 + ((long long)n * H + y) * W;
+      const int kmax = (W - x0 < WK) ? W - x0 : WK;
+      ra_src = uniform_rsrc(dy + (rowbase + x0) * Ns, live ? kmax * Ns * 4 : 0);
+      const int yy = y + ky - HALO;
+      const int jmax = (W - x0 + HALO < WK + KX - 1) ? W - x0 + HALO : WK + KX - 1;
+      const float* bbase = x + (rowbase + (long long)(ky - HALO) * W + x0 - HALO) * Cs;  // never dereferenced outside
+      rb_src = uniform_rsrc(bbase, (live && yy >= 0 && yy < H) ? jmax * Cs * 4 : 0);
+      left_edge = seg == 0;
+    };
+    auto load_a = [&]() {
+#pragma unroll
+      for (int i = 0; i < NA; ++i)
+        ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra_src, (int)offa, PRG * i * Ns * 4, 0));
+    };
+    auto load_b = [&]() {
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        unsigned off = i == NB - 1 ? offb_last : offb;
+        if (KX > 1 && i == 0) off = (left_edge && rr < HALO) ? BAD : off;  // pixel x0 - HALO + j left of the image
+        rb[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb_src, (int)off, PRG * i * Cs * 4, 0));
+      }
+    };
+    auto advance = [&]() {
+      if (++seg == segs) {
+        seg = 0;
+        if (++y == H) {
+          y = 0;
+          if (++n == d.n_images) {
+            n = 0;
+            ++lvl;
+            segs = lvl_pick(ct.segs, lvl);
+            H = lvl_pick(d.h, lvl);
+            W = lvl_pick(d.w, lvl);
+            row0 = lvl_pick64(d.row_off, lvl);
+          }
+        }
+      }
+    };
+    auto store_a = [&](int stage) {
+      __bf16* Ah = sm + stage * W6STAGE(KX);
+      __bf16* Al = Ah + WK * W6ROW;
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int off = wsw6(rr + PRG * i, 4 * q4);
+        split4(ra[i], hi, lo);
+        *reinterpret_cast<bf16x4*>(Ah + off) = hi;
+        *reinterpret_cast<bf16x4*>(Al + off) = lo;
+        if (do_bias) {
+          bsum.x += ra[i].x;
+          bsum.y += ra[i].y;
+          bsum.z += ra[i].z;
+          bsum.w += ra[i].w;
+        }
+      }
+    };
+    auto store_b = [&](int stage) {
+      __bf16* Bh = sm + stage * W6STAGE(KX) + 2 * WK * W6ROW;
+      __bf16* Bl = Bh + (WK + KX - 1) * W6ROW;
+      bf16x4 hi, lo;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int j = rr + PRG * i;
+        if (j < WK + KX - 1) {
+          const int off = wsw6(j, 4 * q4);
+          split4(rb[i], hi, lo);
+          *reinterpret_cast<bf16x4*>(Bh + off) = hi;
+          *reinterpret_cast<bf16x4*>(Bl + off) = lo;
+        }
+      }
+    };
+    // One register set, refilled as soon as a half of it has been converted: the loads of chunk j + 1 are issued right
+    // behind the LDS writes of the same operand of chunk j, i.e. EARLY in an iteration, and have until the same point of
+    // the next iteration to land (issued at the end of the iteration -- behind both operands' conversion -- the producers
+    // waited a full memory latency in front of every barrier: profiles/r03_wgrad_v6_exp.txt).  Behind the last chunk
+    // the loads go through zero-record descriptors: no control flow inside the iteration.
+    prepare(nch > 0);
+    load_a();
+    load_b();
+    store_a(0);
+    if (nch > 1) advance();
+    prepare(nch > 1);
+    load_a();
+    store_b(0);
+    load_b();
+    __syncthreads();  // stage 0 is complete
+    for (int k = 0; k < nch; ++k) {
+      if (!(dbg & 2)) {
+        const int stage = (k + 1) & 1;  // chunk k + 1 is in the registers; chunk k + 2 follows it
+        const bool more = k + 2 < nch;
+        if (more) advance();
+        prepare(more);
+        store_a(stage);
+        load_a();
+        store_b(stage);
+        load_b();
+      }
+      __syncthreads();  // the consumers are done with stage k & 1; stage (k + 1) & 1 is complete
+    }
+    if (do_bias) {  // column sums of this split's dY rows: reduce the 8 pixel-row groups through LDS
+      float* red = reinterpret_cast<float*>(smem_raw);  // [PRG][128]; every stage read is behind the last barrier
+      *reinterpret_cast<float4*>(red + rr * 128 + 4 * q4) = bsum;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    if (do_bias && ptid < 128) {
+      const float* red = reinterpret_cast<const float*>(smem_raw);
+      float sum = 0.f;
+#pragma unroll
+      for (int g = 0; g < PRG; ++g) sum += red[g * 128 + ptid];
+      if (o0 + ptid < Nout) bias_slab[(long long)split * Nout + o0 + ptid] = sum;
+    }
+    return;
+  }
+
+  // ================================================================= consumers: 2 (o) x 4 (c) waves, 64 o x 32 c each
+  const int wm = wid % 2, wn = wid / 2;
+  const int lr = lane & 15, kg = lane >> 4;
+  const int row_lane = 8 * kg + (lr >> 2), col4 = 4 * (lane & 3);
+  const int a_col = wm * (16 * TOMAX), b_col = wn * 32;
+  const bool c_act = c0 + b_col < Cs;
+  const int o_left = Nout - (o0 + a_col);
+
+  f32x4v acc[KX][TOMAX][2];
+#pragma unroll
+  for (int a = 0; a < KX; ++a)
+#pragma unroll
+    for (int b = 0; b < TOMAX; ++b)
+#pragma unroll
+      for (int c = 0; c < 2; ++c) acc[a][b][c] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+  __syncthreads();  // stage 0 is complete
+  // one K loop per live-tile count (wave-uniform; dead tiles: third c tile of Cin = 264 / 268, Cout = 8 / 5 / 1 heads):
+  // inside one loop the compiler would keep the fragment addresses of all three variants in registers across it, which
+  // at 168 registers per lane spills
+  const W6Lane wl = w6_lane(row_lane, col4, a_col, b_col);
+  auto run = [&](auto to_tag) {
+    constexpr int TO = decltype(to_tag)::value;
+    for (int k = 0; k < nch; ++k) {
+      const int stage = k & 1;
+      const __bf16* Ah = sm + stage * W6STAGE(KX);
+      const __bf16* Al = Ah + WK * W6ROW;
+      const __bf16* Bh = Al + WK * W6ROW;
+      const __bf16* Bl = Bh + (WK + KX - 1) * W6ROW;
+      if constexpr (TO > 0)
+        if (!(dbg & 1)) wgrad_mma_v6<TO, KX, TOMAX>(Ah, Al, Bh, Bl, wl, acc);
+      __syncthreads();  // done with this stage; the other one is complete
+    }
+  };
+  if (c_act && o_left > 32)
+    run(std::integral_constant<int, 4>{});
+  else if (c_act && o_left > 16)
+    run(std::integral_constant<int, 2>{});
+  else if (c_act && o_left > 0)
+    run(std::integral_constant<int, 1>{});
+  else
+    run(std::integral_constant<int, 0>{});
+
+  float* out = slab + (long long)split * Nout * T * Cs;
+#pragma unroll
+  for (int kx = 0; kx < KX; ++kx)
+#pragma unroll
+    for (int to = 0; to < TOMAX; ++to)
+#pragma unroll
+      for (int tc = 0; tc < 2; ++tc) {
+        const int c = c0 + b_col + 16 * tc + lr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int o = o0 + a_col + 16 * to + 4 * kg + r;
+          if (o < Nout && c < Cs) out[((long long)o * T + ky * KX + kx) * Cs + c] = acc[kx][to][tc][r];
+        }
+      }
+  __syncthreads();  // pairs with the producers' bias-reduction barrier
+}
+
 // scan_tune "wgrad_v2": 1 = always the 16x16x32 weight-gradient kernel, 0 = always the 32x32x16 one, 2 (default) = by
 // shape.  Same-process A/B per layer (profiles/r02_wgrad_ab.txt): +3...11 % where the input channels fill whole
 // 128-wide tiles (256 -> 256 towers 758 -> 683 us, conv3_x 1785 -> 1706, conv4_x 1716 -> 1667), -1...3 % on the
@@ -1918,6 +2233,10 @@ int g_scan_wgrad_exp = 0;
 int g_scan_wgrad_v4 = 2;
 // scan_tune "wgrad_v5": 1 = the 3x3 launches of the fourth generation take the double-buffered, staggered fifth
 int g_scan_wgrad_v5 = 0;
+// scan_tune "wgrad_v6": 1 = the 3x3 launches of the fourth generation take the producer / consumer sixth
+int g_scan_wgrad_v6 = 1;
+// scan_tune "wgrad_prio": 1 = the producer waves of the sixth generation run at s_setprio 3
+int g_scan_wgrad_prio = 1;
 // scan_tune "wgrad_il": n > 0 = the fourth-generation 3x3 kernel issues the next chunk's loads n at a time between the MFMA
 // blocks of the current chunk instead of together before the barrier (0)
 int g_scan_wgrad_il = 1;
@@ -2039,6 +2358,17 @@ extern "C" int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d
     }
     hipLaunchKernelGGL((conv_wgrad_bf16x3_v3_kernel<3, 1, 512>), dim3(nt * sp), dim3(512), sh3, st, x, *d, Cs, dy, Cout,
                        Cout_s, ws, bias_slab, ct, nt, ctl, cps, sp, *d);
+  } else if (g_scan_wgrad_v6 && g_scan_wgrad_v4 && Cs % 4 == 0 && Cout_s % 4 == 0 &&
+             (g_scan_wgrad_exp == 0 || g_scan_wgrad_exp >= 5) && (g_scan_wgrad_v4 == 2 || wgrad_use_v2(Cs))) {
+    const size_t sh6 = (size_t)2 * W6STAGE(3) * sizeof(__bf16);
+    static bool done7 = false;
+    if (!done7) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_bf16x3_v6_kernel<3>),
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh6);
+      done7 = true;
+    }
+    hipLaunchKernelGGL((conv_wgrad_bf16x3_v6_kernel<3>), dim3(nt * sp), dim3(768), sh6, st, x, *d, Cs, dy, Cout, Cout_s, ws,
+                       bias_slab, ct, nt, ctl, cps, sp, g_scan_wgrad_exp >= 5 ? g_scan_wgrad_exp - 4 : 0, g_scan_wgrad_prio);
   } else if (g_scan_wgrad_v5 && g_scan_wgrad_v4 && Cs % 4 == 0 && Cout_s % 4 == 0 && g_scan_wgrad_exp == 0 &&
              (g_scan_wgrad_v4 == 2 || wgrad_use_v2(Cs))) {
     const size_t sh5 = (size_t)2 * W3STAGE(3) * sizeof(__bf16);

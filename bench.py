@@ -238,6 +238,10 @@ def main():
     ap.add_argument("--forward-target", action="store_true",
                     help="target pass with DBSCAN node sampling + GST losses (reference: once val AP50 > INITIAL_AP50); "
                          "the headline metric uses False like the reference's first phase")
+    ap.add_argument("--ft-positives", type=float, default=None,
+                    help="with --forward-target: keep this fraction of the (pixel, class) act-map entries that pass the 0.05 "
+                         "threshold as clustering candidates (SURVEY.md 8d second series: 0.01).  A random-init model passes "
+                         "ALL entries -- the worst case -- a trained one a small fraction; measurement switch only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true",
                     help="skip the companion legs of the line (strict fp32-MFMA steps, the three-phase schedule, inference)")
@@ -285,6 +289,11 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from scan_amd import comm, engine, ops, synth
+    if a.ft_positives is not None:
+        if not a.forward_target:
+            raise SystemExit("--ft-positives needs --forward-target")
+        from scan_amd.modeling import condgraph
+        condgraph.FT_CANDIDATE_FRACTION = float(a.ft_positives)
     mcfg = engine.CONFIGS[a.model]
     body = mcfg["conv_body"]
     model = engine.build_model(device=dev, settings=mcfg)
@@ -490,7 +499,9 @@ def main():
                      "product = 16 significand bits per operand; strict fp32-MFMA figure: strict_fp32)",
             "data": "synthetic",
             "config": {"workload": "SCAN %s %s DA iteration, %d src + %d tgt frames/GPU at %dx%d, "
-                                   "forward_target=%s, procedural weights" % (a.model.upper(), body, B, B, H, W, a.forward_target),
+                                   "forward_target=%s%s, procedural weights" % (
+                           a.model.upper(), body, B, B, H, W, a.forward_target,
+                           "" if a.ft_positives is None else " (%.3g of the act-map entries kept as clustering candidates)" % a.ft_positives),
                        "arithmetic": "fp32 storage and accumulation; 3x3 convs split each fp32 operand hi+lo into "
                                      "2 x bf16 and issue 3 bf16 MFMAs per product (1.7e-6 rel on the losses vs fp32)",
                        "global_batch_pairs": B * world, "frames_per_s": round(2 * value, 4), "parallelism": "dp%d" % world,

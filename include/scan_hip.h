@@ -128,6 +128,13 @@ int scan_cka_bce_forward(const float* logits, const float* act, int64_t M, int32
 /* d_logits[m][c] = g_dev[c] * act[m][c+1] * (sigmoid(x) - t),  g_dev[c] = upstream / (Cf * sum_w[c]) */
 int scan_cka_bce_backward(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
                           const float* g_dev, float* d_logits, void* stream);
+/* The same pair with the layer's scalar arithmetic folded in: out = 2 * Cf + 2 floats zeroed by the caller (sums, a ticket
+ * word, the loss  sum_c (num_c / den_c) / Cf  written by the block that finishes last); the backward takes the gradient
+ * of that scalar (g_loss [1], device) and the forward's out and forms the per-class coefficients itself. */
+int scan_cka_bce_forward_loss(const float* logits, const float* act, int64_t M, int32_t Cf, float target, float* out,
+                              void* stream);
+int scan_cka_bce_backward_loss(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
+                               const float* g_loss, const float* sums, float* d_logits, void* stream);
 
 /* ---- y = alpha * x  (GradientReversalFunction: forward alpha = 1 copy, backward alpha = -lambda;
  *      discriminator/layer.py:6-24) ---- */

@@ -358,8 +358,29 @@ extern "C" int scan_bce_logits_backward(const float* logits, const float* target
 
 // ------------------------------------------------------------------ CKA class-conditional BCE
 #define CKA_MAXC 16
+// fin != nullptr: the block that finishes last (ticket fin[0], zeroed by the caller) turns the completed sums into the
+// loss  fin[1] = sum_c (num_c / den_c) / Cf  -- the reference's per-class weighted means averaged over the classes
+// (discriminator/fcos_head_discriminator_con.py:119-121) -- so the layer needs no select / div / sum / div kernels of
+// its own behind this launch.  The sums were added with float atomics (executed at the memory side): they are read
+// back the same way.
+__device__ __forceinline__ void cka_finish(float* __restrict__ out, int Cf, float* __restrict__ fin) {
+  __shared__ unsigned last_flag;
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(fin), 1u);
+    last_flag = (t == gridDim.x - 1) ? 1u : 0u;
+  }
+  __syncthreads();
+  if (last_flag && threadIdx.x == 0) {
+    float s = 0.f;
+    for (int c = 0; c < Cf; ++c) s += atomicAdd(out + 2 * c, 0.f) / atomicAdd(out + 2 * c + 1, 0.f);
+    fin[1] = s / (float)Cf;
+  }
+}
 __global__ __launch_bounds__(256) void cka_fwd_kernel(const float* __restrict__ logits, const float* __restrict__ act,
-                                                      int64_t M, int Cf, float t, float* __restrict__ out) {
+                                                      int64_t M, int Cf, float t, float* __restrict__ out,
+                                                      float* __restrict__ fin) {
   __shared__ float red[4];
   float num[CKA_MAXC], den[CKA_MAXC];
 #pragma unroll
@@ -387,13 +408,15 @@ __global__ __launch_bounds__(256) void cka_fwd_kernel(const float* __restrict__ 
       }
     }
   }
+  if (fin != nullptr) cka_finish(out, Cf, fin);
 }
 
 // Cf == 8 (Cityscapes): a thread owns one float4 of logits = half a row, i.e. ALWAYS the same four classes (the grid
 // stride is even), so its eight partial sums stay in registers; the act-map row (9 floats, unaligned) is read by the two
 // lanes of a row as 4 + 4 scalars of one contiguous wave-wide segment.  Even / odd lanes are reduced separately.
 __global__ __launch_bounds__(256) void cka_fwd8_kernel(const float* __restrict__ logits, const float* __restrict__ act,
-                                                       int64_t M, float t, float* __restrict__ out) {
+                                                       int64_t M, float t, float* __restrict__ out,
+                                                       float* __restrict__ fin) {
   __shared__ float red[4][16];
   float num[4] = {0.f, 0.f, 0.f, 0.f}, den[4] = {0.f, 0.f, 0.f, 0.f};
   const int64_t n4 = M * 2;
@@ -424,35 +447,54 @@ __global__ __launch_bounds__(256) void cka_fwd8_kernel(const float* __restrict__
   }
   __syncthreads();
   if (threadIdx.x < 16) atomicAdd(out + threadIdx.x, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (fin != nullptr) cka_finish(out, 8, fin);
 }
 
+// sums == nullptr: g [Cf] are the per-class coefficients; else g [1] is the gradient of the loss scalar and the
+// coefficient of class c is g / (Cf * den_c), den_c = sums[2 c + 1] (what the layer's backward used to compute with
+// three small kernels)
 __global__ __launch_bounds__(256) void cka_bwd_kernel(const float* __restrict__ logits, const float* __restrict__ act,
                                                       int64_t M, int Cf, float t, const float* __restrict__ g,
-                                                      float* __restrict__ d_logits) {
+                                                      const float* __restrict__ sums, float* __restrict__ d_logits) {
+  __shared__ float coef[CKA_MAXC];
+  if (threadIdx.x < Cf) coef[threadIdx.x] = sums ? g[0] / ((float)Cf * sums[2 * threadIdx.x + 1]) : g[threadIdx.x];
+  __syncthreads();
   const int64_t total = M * Cf;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t m = i / Cf;
     const int c = (int)(i - m * Cf);
     const float x = logits[i];
     const float s = 1.f / (1.f + expf(-x));
-    d_logits[i] = g[c] * act[m * (Cf + 1) + c + 1] * (s - t);
+    d_logits[i] = coef[c] * act[m * (Cf + 1) + c + 1] * (s - t);
   }
 }
 
-extern "C" int scan_cka_bce_forward(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
-                                    float* out, void* stream) {
+static int cka_forward_launch(const float* logits, const float* act, int64_t M, int32_t Cf, float target, float* out,
+                              float* fin, void* stream) {
   SCAN_CHECK_ARG(M >= 0 && Cf > 0 && Cf <= CKA_MAXC && out, "cka_bce_forward: bad arguments (Cf=%d)", Cf);
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && act, "cka_bce_forward: null input");
   if (Cf == 8 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
     int g = grid_reduce(M * 2, 256);
-    hipLaunchKernelGGL(cka_fwd8_kernel, dim3(g), dim3(256), 0, as_stream(stream), logits, act, M, target, out);
+    hipLaunchKernelGGL(cka_fwd8_kernel, dim3(g), dim3(256), 0, as_stream(stream), logits, act, M, target, out, fin);
   } else {
     hipLaunchKernelGGL(cka_fwd_kernel, dim3(grid_reduce(M, 256)), dim3(256), 0, as_stream(stream), logits, act, M, Cf,
-                       target, out);
+                       target, out, fin);
   }
   SCAN_LAUNCH_CHECK("cka_fwd");
   return 0;
+}
+
+extern "C" int scan_cka_bce_forward(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
+                                    float* out, void* stream) {
+  return cka_forward_launch(logits, act, M, Cf, target, out, nullptr, stream);
+}
+
+// out: 2 * Cf + 2 floats, zeroed by the caller: the sums, a ticket word, the loss (written by the last block)
+extern "C" int scan_cka_bce_forward_loss(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
+                                         float* out, void* stream) {
+  SCAN_CHECK_ARG(M > 0, "cka_bce_forward_loss: needs at least one row (the loss is a ratio of sums)");
+  return cka_forward_launch(logits, act, M, Cf, target, out, out ? out + 2 * Cf : nullptr, stream);
 }
 
 extern "C" int scan_cka_bce_backward(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
@@ -461,7 +503,19 @@ extern "C" int scan_cka_bce_backward(const float* logits, const float* act, int6
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && act && g_dev && d_logits, "cka_bce_backward: null pointer");
   hipLaunchKernelGGL(cka_bwd_kernel, dim3(grid_for(M * Cf, 256)), dim3(256), 0, as_stream(stream), logits, act, M, Cf,
-                     target, g_dev, d_logits);
+                     target, g_dev, (const float*)nullptr, d_logits);
+  SCAN_LAUNCH_CHECK("cka_bwd");
+  return 0;
+}
+
+// g_loss [1]: gradient of the loss scalar of scan_cka_bce_forward_loss; sums: that call's out
+extern "C" int scan_cka_bce_backward_loss(const float* logits, const float* act, int64_t M, int32_t Cf, float target,
+                                          const float* g_loss, const float* sums, float* d_logits, void* stream) {
+  SCAN_CHECK_ARG(M >= 0 && Cf > 0 && Cf <= CKA_MAXC, "cka_bce_backward_loss: bad arguments (Cf=%d)", Cf);
+  if (M == 0) return 0;
+  SCAN_CHECK_ARG(logits && act && g_loss && sums && d_logits, "cka_bce_backward_loss: null pointer");
+  hipLaunchKernelGGL(cka_bwd_kernel, dim3(grid_for(M * Cf, 256)), dim3(256), 0, as_stream(stream), logits, act, M, Cf,
+                     target, g_loss, sums, d_logits);
   SCAN_LAUNCH_CHECK("cka_bwd");
   return 0;
 }

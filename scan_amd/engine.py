@@ -628,14 +628,17 @@ class Trainer:
             src_feats, _ = ops.take_images(feats, shape, 0, B)
             _, fl = model["fcos"](il_s.image_sizes, src_feats, shape_src, targets=targets_s)
         losses.update({k + "_gs": v for k, v in fl.items()})
-        f, a = ops.split_levels(feats, shape), ops.split_levels(maps, shape)
+        # the five levels go to their discriminators behind the discriminators' gradient-reversal layers: split + GRL
+        # as one node per tensor whose backward scales each level's gradient straight into its rows
+        lams = [model["dis_%s_CON" % lvl].grad_reverse.lambda_ for lvl in LEVELS]
+        f, a = ops.split_levels_grl(feats, shape, lams), ops.split_levels_grl(maps, shape, lams)
         for lvl in DIS_ORDER:
             i = LEVELS.index(lvl)
             side = self.dis_streams.get(lvl)
             if side is not None:
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):
-                ls, lt = model["dis_%s_CON" % lvl].forward_pair(f[i], a[i], shape.level(i), B)
+                ls, lt = model["dis_%s_CON" % lvl].forward_pair(f[i], a[i], shape.level(i), B, grl_applied=True)
                 losses["loss_adv_%s_CON_ds" % lvl] = lam * ls
                 losses["loss_adv_%s_CON_dt" % lvl] = lam * lt
         for side in self.dis_streams.values():

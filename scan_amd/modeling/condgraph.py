@@ -112,6 +112,13 @@ def sim_matrix(a, b, eps=1e-8):
 
 
 DBSCAN_BACKEND = "device"  # "host": sklearn on the host cores, the reference's own call (kept for cross-checks)
+# MEASUREMENT ONLY (bench.py --ft-positives, SURVEY.md 8d "second series"): a random-init model's act maps are nearly
+# uniform, so EVERY (pixel, class) entry passes the 0.05 threshold and the clustering sees 100 % of the entries -- a
+# trained model passes a small fraction.  A value p in (0, 1] keeps a fixed pseudo-random fraction p of the entries that
+# pass the threshold as clustering candidates (seeded per level: the same entries every iteration).  None = the
+# reference's rule, always used outside that bench series.
+FT_CANDIDATE_FRACTION = None
+_ft_masks = {}
 
 
 def dbscan_positive_rows(feat_l, act_l, n_images, eps, thr):
@@ -124,6 +131,13 @@ def dbscan_positive_rows(feat_l, act_l, n_images, eps, thr):
     hw = feat_l.shape[0] // n_images
     act = act_l.detach().view(n_images, hw, K)[:, :, 1:].permute(0, 2, 1).contiguous()  # [N, CLS, HW]
     mask = act > thr
+    if FT_CANDIDATE_FRACTION is not None:
+        key = (tuple(act.shape), str(act.device), float(FT_CANDIDATE_FRACTION))
+        keep = _ft_masks.get(key)
+        if keep is None:
+            g = torch.Generator(device=act.device).manual_seed(977 + act.shape[2])
+            keep = _ft_masks[key] = torch.rand(act.shape, generator=g, device=act.device) < FT_CANDIDATE_FRACTION
+        mask = mask & keep
     idx = mask.nonzero()  # (n, cls, hw) lexicographic = the reference's (n, cls, h, w) order
     sel = torch.zeros_like(act)
     if idx.shape[0] > 0:

@@ -57,10 +57,11 @@ class FCOSDiscriminator_con(nn.Module):
         b2 = torch.cat([b[2].bias for b in blocks], 0)
         return w1, b1, w2, b2
 
-    def _logits(self, feature, act_maps, shape):
+    def _logits(self, feature, act_maps, shape, grl_applied=False):
         Cf = self.num_classes
-        feature = self.grad_reverse(feature)
-        act_maps = self.grad_reverse(act_maps)
+        if not grl_applied:  # the caller already put both inputs behind this module's GRL (ops.split_levels_grl)
+            feature = self.grad_reverse(feature)
+            act_maps = self.grad_reverse(act_maps)
         # cat([x, act[1:]], 1) (reference :104-118) without copying x: the tower's last GroupNorm writes into the first
         # 256 columns of the [M, pad4(256 + Cf)] class-branch input, only the Cf act columns are copied behind them, and
         # the backward hands the GroupNorm its column slice of the conv's data gradient in place
@@ -101,12 +102,12 @@ class FCOSDiscriminator_con(nn.Module):
         logits, act_maps = self._logits(feature, act_maps, shape)
         return self._loss(logits, act_maps, target)
 
-    def forward_pair(self, feature, act_maps, shape, n_src):
+    def forward_pair(self, feature, act_maps, shape, n_src, grl_applied=False):
         """source frames [0, n_src) and target frames [n_src, N) of one level in ONE pass through the tower and the
         class branches; the two domain losses (labels 1.0 / 0.0, each with its own act-map normaliser) are taken on
         the two halves of the rows.  Same values and gradients as forward(.., 1.0, 'source') + forward(.., 0.0,
         'target') (reference trainer.py:314-333, 373-376)."""
-        logits, act_maps = self._logits(feature, act_maps, shape)
+        logits, act_maps = self._logits(feature, act_maps, shape, grl_applied)
         (h, w) = shape.sizes[0]
         m = n_src * h * w
         return self._loss(logits[:m], act_maps[:m], 1.0), self._loss(logits[m:], act_maps[m:], 0.0)

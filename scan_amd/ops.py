@@ -533,6 +533,38 @@ def split_levels(rows, shape):
     return _SplitLevels.apply(rows, shape)
 
 
+class _SplitLevelsGRL(torch.autograd.Function):
+    """rows [M, C] -> one view per level, each behind a gradient-reversal layer of its own strength (reference
+    discriminator/layer.py:6-33: forward identity, backward -lambda_l * g).  The backward scales every level's gradient
+    STRAIGHT INTO its row range of one [M, C] matrix: no per-level scaled copy followed by a concatenation."""
+
+    @staticmethod
+    def forward(ctx, rows, shape, lams):
+        _chk(rows)
+        ctx.cfg = (shape, tuple(float(v) for v in lams), rows.shape[1])
+        return tuple(rows[shape.row_off[l]:shape.row_off[l + 1]] for l in range(shape.n_levels))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        shape, lams, cols = ctx.cfg
+        ref = next(g for g in grads if g is not None)
+        out = ref.new_empty((shape.rows, cols))
+        st = _stream()
+        for l, g in enumerate(grads):
+            part = out[shape.row_off[l]:shape.row_off[l + 1]]
+            if g is None:
+                part.zero_()
+            else:
+                g = g.contiguous()
+                call("scan_scale", _ptr(g), -lams[l], _ptr(part), g.numel(), st)
+        return out, None, None
+
+
+def split_levels_grl(rows, shape, lams):
+    """split_levels with grad_reverse(., lams[l]) applied to level l (the discriminators' own GRL is then skipped)."""
+    return _SplitLevelsGRL.apply(rows, shape, lams)
+
+
 class _TakeImages(torch.autograd.Function):
     """rows of images [i0, i1) of every level, as the pyramid of those images (level-major order is kept)."""
 
@@ -879,27 +911,30 @@ def bce_with_logits_mean(logits, targets):
 
 
 class _CkaBce(torch.autograd.Function):
-    """sum_c [ sum_m act[m,c+1] bce(logit[m,c], t) / sum_m act[m,c+1] ] / Cf"""
+    """sum_c [ sum_m act[m,c+1] bce(logit[m,c], t) / sum_m act[m,c+1] ] / Cf -- one launch forward (the last block to
+    finish forms the scalar), one launch backward (the kernel forms the per-class coefficients from the gradient of the
+    scalar and the forward's sums)."""
 
     @staticmethod
     def forward(ctx, logits, act, target, cf):
         _chk(logits, act)
         M = logits.shape[0]
         assert logits.shape[1] == cf and act.shape[1] == cf + 1
-        out = logits.new_zeros((2 * cf,))
-        call("scan_cka_bce_forward", _ptr(logits), _ptr(act), M, cf, target, _ptr(out), _stream())
-        o = out.view(cf, 2)
-        ctx.save_for_backward(logits, act, o)
+        out = logits.new_zeros((2 * cf + 2,))
+        if M > 0:
+            call("scan_cka_bce_forward_loss", _ptr(logits), _ptr(act), M, cf, target, _ptr(out), _stream())
+        ctx.save_for_backward(logits, act, out)
         ctx.cfg = (target, cf)
-        return (o[:, 0] / o[:, 1]).sum() / cf
+        return out[2 * cf + 1] if M > 0 else out[2 * cf + 1] / 0.0  # no rows: the reference's 0 / 0
 
     @staticmethod
     def backward(ctx, g):
-        logits, act, o = ctx.saved_tensors
+        logits, act, out = ctx.saved_tensors
         target, cf = ctx.cfg
-        gd = (g / (cf * o[:, 1])).contiguous()
         d = torch.empty_like(logits)
-        call("scan_cka_bce_backward", _ptr(logits), _ptr(act), logits.shape[0], cf, target, _ptr(gd), _ptr(d), _stream())
+        if logits.shape[0] > 0:
+            call("scan_cka_bce_backward_loss", _ptr(logits), _ptr(act), logits.shape[0], cf, target,
+                 _ptr(g.reshape(1).contiguous()), _ptr(out), _ptr(d), _stream())
         return d, None, None, None
 
 

@@ -312,6 +312,14 @@ int scan_fcos_nodes(const scan_pyramid_t* d, const int32_t* level_pos, const int
                     const int32_t* pos_list, const int32_t* neg_list, int64_t* node_index, int64_t* node_labels,
                     int64_t* pos_inds, float* reg_pos, float* ctr_pos, void* stream);
 
+/* ---- FPN top-down join on NHWC rows (reference backbone/fpn.py:62-75: inner = lateral + F.interpolate(top,
+ *      scale_factor=2, mode="nearest")).  lat / y [N, 2h, 2w, C], coarse [N, h, w, C], C % 4 == 0.  Backward:
+ *      d_lateral is the incoming gradient itself, d_coarse its 2x2 window sums (scan_downsample2x_sum: g [N, 2h, 2w, C]
+ *      -> d [N, h, w, C]). ---- */
+int scan_upsample2x_add(const float* lat, const float* coarse, int32_t N, int32_t h, int32_t w, int32_t C, float* y,
+                        void* stream);
+int scan_downsample2x_sum(const float* g, int32_t N, int32_t h, int32_t w, int32_t C, float* d, void* stream);
+
 /* ---- 2x2 / stride-2 max pooling on NHWC rows (replaces nn.MaxPool2d(2, 2) of the VGG body,
  *      backbone/mmdetection/vgg.py:33).  x [N,H,W,C], y [N,H/2,W/2,C]; H, W even, C % 4 == 0.
  *      backward routes the gradient to the first maximum of each window (F.max_pool2d's rule);

@@ -109,6 +109,8 @@ SIGNATURES = {
     "scan_conv_smallcin_bf16x3": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                                  c_i32, c_vp]),
     "scan_maxpool3x3s2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "scan_upsample2x_add": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "scan_downsample2x_sum": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_add_relu": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp]),
     "scan_dbscan_prepare": (ctypes.c_int, [c_vp, c_i64, c_i32, c_f32, c_i32, c_vp, c_vp, c_vp]),
     "scan_dbscan_bfs_step": (ctypes.c_int, [c_i64, c_vp, c_i32, c_vp, c_vp]),

@@ -837,3 +837,62 @@ extern "C" int scan_add_relu(const float* a, const float* b, float* y, int64_t n
   SCAN_LAUNCH_CHECK("add_relu");
   return 0;
 }
+
+// ------------------------------------------------------------------ FPN top-down join (reference backbone/fpn.py:62-75)
+// y = lateral + F.interpolate(coarse, scale_factor=2, mode="nearest") on NHWC rows: lateral [N, 2h, 2w, C], coarse
+// [N, h, w, C].  One pass (read 1.25 C floats per output pixel, write C) instead of the expand / reshape copy of the
+// up-sampled map followed by an add.  Backward: d_lateral = g itself; d_coarse = the 2x2 window sums of g.
+__global__ __launch_bounds__(256) void upsample2x_add_kernel(const float* __restrict__ lat, const float* __restrict__ coarse,
+                                                             int N, int h, int w, int C4, float* __restrict__ y) {
+  const int64_t total = (int64_t)N * 4 * h * w * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t p = i / C4;
+    const int x = (int)(p % (2 * w));
+    p /= 2 * w;
+    const int yy = (int)(p % (2 * h));
+    const int n = (int)(p / (2 * h));
+    const float4 a = reinterpret_cast<const float4*>(lat)[i];
+    const float4 b = reinterpret_cast<const float4*>(coarse)[(((int64_t)n * h + (yy >> 1)) * w + (x >> 1)) * C4 + c];
+    reinterpret_cast<float4*>(y)[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+__global__ __launch_bounds__(256) void downsample2x_sum_kernel(const float* __restrict__ g, int N, int h, int w, int C4,
+                                                               float* __restrict__ d) {
+  const int64_t total = (int64_t)N * h * w * C4;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4);
+    int64_t p = i / C4;
+    const int x = (int)(p % w);
+    p /= w;
+    const int yy = (int)(p % h);
+    const int n = (int)(p / h);
+    const float4* r0 = reinterpret_cast<const float4*>(g) + (((int64_t)n * 2 * h + 2 * yy) * 2 * w + 2 * x) * C4 + c;
+    const float4* r1 = r0 + (int64_t)2 * w * C4;
+    const float4 a = r0[0], b = r0[C4], e = r1[0], f = r1[C4];
+    // the order of torch's sum over the (2, 2) window axes of the expanded view: rows first, then columns
+    reinterpret_cast<float4*>(d)[i] = make_float4((a.x + b.x) + (e.x + f.x), (a.y + b.y) + (e.y + f.y),
+                                                  (a.z + b.z) + (e.z + f.z), (a.w + b.w) + (e.w + f.w));
+  }
+}
+
+extern "C" int scan_upsample2x_add(const float* lat, const float* coarse, int32_t N, int32_t h, int32_t w, int32_t C,
+                                   float* y, void* stream) {
+  SCAN_CHECK_ARG(lat && coarse && y && N >= 1 && h >= 1 && w >= 1 && C >= 4 && C % 4 == 0,
+                 "upsample2x_add: bad arguments (C=%d must be a multiple of 4)", C);
+  const int64_t n4 = (int64_t)N * 4 * h * w * (C / 4);
+  hipLaunchKernelGGL(upsample2x_add_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, as_stream(stream), lat, coarse, N, h, w,
+                     C / 4, y);
+  SCAN_LAUNCH_CHECK("upsample2x_add");
+  return 0;
+}
+
+extern "C" int scan_downsample2x_sum(const float* g, int32_t N, int32_t h, int32_t w, int32_t C, float* d, void* stream) {
+  SCAN_CHECK_ARG(g && d && N >= 1 && h >= 1 && w >= 1 && C >= 4 && C % 4 == 0,
+                 "downsample2x_sum: bad arguments (C=%d must be a multiple of 4)", C);
+  const int64_t n4 = (int64_t)N * h * w * (C / 4);
+  hipLaunchKernelGGL(downsample2x_sum_kernel, dim3(grid_for(n4, 256)), dim3(256), 0, as_stream(stream), g, N, h, w, C / 4, d);
+  SCAN_LAUNCH_CHECK("downsample2x_sum");
+  return 0;
+}

@@ -75,6 +75,44 @@ class VGGBody(nn.Module):
         return outs
 
 
+def fpn_top_down(inner, layer, top_blocks, c3, c4, c5):
+    """FPN on C3..C5 + LastLevelP6P7 on P5 (reference backbone/fpn.py:44-130); inner / layer: the 1x1 lateral and 3x3
+    output conv holders of the three levels, finest first.  -> (rows [M, 256], PyramidShape of P3..P7)."""
+    # The five output convs write straight into their row ranges of ONE [M, 256] pyramid matrix (no concatenation
+    # afterwards), and a top-down join (lateral + nearest-2x up-sampled coarser map) is one pass.
+    s3, s4, s5 = c3[1], c4[1], c5[1]
+    s6 = s5.conv_out(3, 2)
+    s7 = s6.conv_out(3, 2)
+    shape = PyramidShape(s3.n_images, [s.sizes[0] for s in (s3, s4, s5, s6, s7)])
+    direct = c3[0].is_cuda
+    buf = c3[0].new_empty((shape.rows, 256)) if direct else None
+
+    def conv(m, rs, k, stride=1, lvl=None):
+        out = buf[shape.row_off[lvl]:shape.row_off[lvl + 1]] if (direct and lvl is not None) else None
+        return ops.conv2d(rs[0], m.weight, m.bias, rs[1], k, stride, out=out), rs[1].conv_out(k, stride)
+
+    def join(lat, coarse):
+        (hl, wl), (hc, wc) = lat[1].sizes[0], coarse[1].sizes[0]
+        if direct and (hl, wl) == (2 * hc, 2 * wc):
+            return ops.upsample2x_add(lat[0], coarse[0], coarse[1]), lat[1]
+        return lat[0] + upsample2x(*coarse), lat[1]
+
+    inner5 = conv(inner[2], c5, 1)
+    p5 = conv(layer[2], inner5, 3, lvl=2)
+    inner4 = join(conv(inner[1], c4, 1), inner5)
+    p4 = conv(layer[1], inner4, 3, lvl=1)
+    inner3 = join(conv(inner[0], c3, 1), inner4)
+    p3 = conv(layer[0], inner3, 3, lvl=0)
+    p6 = conv(top_blocks.p6, p5, 3, 2, lvl=3)
+    p7 = conv(top_blocks.p7, (F.relu(p6[0]), p6[1]), 3, 2, lvl=4)
+    levels = [p3, p4, p5, p6, p7]
+    if direct:
+        rows = ops.assemble_rows(buf, [l[0] for l in levels])
+    else:
+        rows = torch.cat([l[0] for l in levels], 0)
+    return rows, shape
+
+
 class LastLevelP6P7(nn.Module):
     def __init__(self, cin, cout):
         super().__init__()
@@ -91,23 +129,8 @@ class FPN(nn.Module):
         self.top_blocks = LastLevelP6P7(256, 256)
 
     def forward(self, c3, c4, c5):
-        def conv(m, rs, k, stride=1):
-            return ops.conv2d(rs[0], m.weight, m.bias, rs[1], k, stride), rs[1].conv_out(k, stride)
-
-        inner5 = conv(self.fpn_inner5, c5, 1)
-        p5 = conv(self.fpn_layer5, inner5, 3)
-        lat4 = conv(self.fpn_inner4, c4, 1)
-        inner4 = (lat4[0] + upsample2x(*inner5), lat4[1])
-        p4 = conv(self.fpn_layer4, inner4, 3)
-        lat3 = conv(self.fpn_inner3, c3, 1)
-        inner3 = (lat3[0] + upsample2x(*inner4), lat3[1])
-        p3 = conv(self.fpn_layer3, inner3, 3)
-        p6 = conv(self.top_blocks.p6, p5, 3, 2)
-        p7 = conv(self.top_blocks.p7, (F.relu(p6[0]), p6[1]), 3, 2)
-        levels = [p3, p4, p5, p6, p7]
-        rows = torch.cat([l[0] for l in levels], 0)
-        shape = PyramidShape(p3[1].n_images, [l[1].sizes[0] for l in levels])
-        return rows, shape
+        return fpn_top_down([getattr(self, "fpn_inner%d" % l) for l in (3, 4, 5)],
+                            [getattr(self, "fpn_layer%d" % l) for l in (3, 4, 5)], self.top_blocks, c3, c4, c5)
 
 
 class VGG16FPN(nn.Module):

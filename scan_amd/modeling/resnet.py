@@ -20,7 +20,7 @@ from torch import nn
 
 from .. import ops
 from ..ops import PyramidShape
-from .backbone import LastLevelP6P7, conv_holder, upsample2x
+from .backbone import LastLevelP6P7, conv_holder, fpn_top_down
 
 STAGE_BLOCKS = {"R-50": (3, 4, 6, 3), "R-101": (3, 4, 23, 3)}
 
@@ -128,22 +128,8 @@ class ResNetFPN(nn.Module):
         self.top_blocks = LastLevelP6P7(256, 256)
 
     def forward(self, c3, c4, c5):
-        def conv(m, rs, k, stride=1):
-            return ops.conv2d(rs[0], m.weight, m.bias, rs[1], k, stride), rs[1].conv_out(k, stride)
-
-        inner5 = conv(self.fpn_inner4, c5, 1)
-        p5 = conv(self.fpn_layer4, inner5, 3)
-        lat4 = conv(self.fpn_inner3, c4, 1)
-        inner4 = (lat4[0] + upsample2x(*inner5), lat4[1])
-        p4 = conv(self.fpn_layer3, inner4, 3)
-        lat3 = conv(self.fpn_inner2, c3, 1)
-        inner3 = (lat3[0] + upsample2x(*inner4), lat3[1])
-        p3 = conv(self.fpn_layer2, inner3, 3)
-        p6 = conv(self.top_blocks.p6, p5, 3, 2)
-        p7 = conv(self.top_blocks.p7, (torch.relu(p6[0]), p6[1]), 3, 2)
-        levels = [p3, p4, p5, p6, p7]
-        rows = torch.cat([l[0] for l in levels], 0)
-        return rows, PyramidShape(p3[1].n_images, [l[1].sizes[0] for l in levels])
+        return fpn_top_down([getattr(self, "fpn_inner%d" % l) for l in (2, 3, 4)],
+                            [getattr(self, "fpn_layer%d" % l) for l in (2, 3, 4)], self.top_blocks, c3, c4, c5)
 
 
 class ResNetFPNBackbone(nn.Module):

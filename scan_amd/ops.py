@@ -264,7 +264,7 @@ _gn_sums = {}
 
 
 def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None,
-                    mask=None, dst_shape=None, cmap=0, pool=False, gn_sums=False, param=None):
+                    mask=None, dst_shape=None, cmap=0, pool=False, gn_sums=False, param=None, out=None):
     """wp: packed fp32 weights [O][T][Cs_w], T = 9 (3x3 / stride 1) or 1 (1x1; dst_shape = output pyramid, cmap =
     scan_conv1x1_bf16x3's map).  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
     st = _stream()
@@ -296,7 +296,7 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
             _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
             if _active_plan is not None and param is not None and wp.data_ptr() == cache_key == param.data_ptr():
                 _active_plan.add((cache_key, mode, csw), param, O, T, cs_w, mode, rows, csw, wh, wl)
-    y = (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
+    y = out if out is not None else (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
     if kernel_timer.enabled:  # label the record with the template instance the launch takes (64 / 128 / 256 channels)
         inst = query("scan_conv3x3_bf16x3_instance", (dst_shape or shape).ref(), nout) if T == 9 else (128 if nout > 64 else 64)
         ev = kernel_timer.begin("%s_bn%d" % (name, inst), flops)
@@ -346,7 +346,8 @@ class _Conv2d(torch.autograd.Function):
     which those kernels do for free in their epilogue; it removes the separate relu-backward pass over dy."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx=False, pool=False, gn_sums=False):
+    def forward(ctx, x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx=False, pool=False, gn_sums=False,
+                out=None):
         _chk(x, bias)
         if not weight.is_cuda:
             raise RuntimeError("scan_amd ops run only on the GPU (HIP); no CPU fallback")
@@ -356,6 +357,11 @@ class _Conv2d(torch.autograd.Function):
         cout_s = cout_s or pad4(cout)
         wp = pack_weight(weight, cs)
         oshape = shape.conv_out(ksize, stride)
+        if out is not None:  # write into a caller-provided row block (a slice of a pyramid buffer, see assemble_rows)
+            if pool or not (out.is_cuda and out.dtype == torch.float32 and out.is_contiguous()
+                            and tuple(out.shape) == (oshape.rows, cout_s) and cout_s == cout):
+                raise RuntimeError("conv2d(out=...): needs a contiguous fp32 [%d, %d] GPU block with Cout == Cout_s"
+                                   % (oshape.rows, cout_s))
         fast = CONV_MODE == "bf16x3" and ((ksize == 3 and stride == 1) or ksize == 1)
         flops = 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1]
         ckey = weight.data_ptr() if getattr(weight, "_scan_flat", False) else None
@@ -364,7 +370,7 @@ class _Conv2d(torch.autograd.Function):
             and shape.n_levels == 1
         if first:
             (h, w_), n = shape.sizes[0], shape.n_images
-            y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
+            y = out if out is not None else (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
             ev = kernel_timer.begin("conv_smallcin_bf16x3", flops)
             call("scan_conv_smallcin_bf16x3", _ptr(x), n, h, w_, _ptr(wp), _ptr(bias), _ptr(y), cout, cout_s, ksize,
                  stride, int(bool(relu)), _stream())
@@ -380,9 +386,10 @@ class _Conv2d(torch.autograd.Function):
                 y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s,
                                     "conv3x3_bf16x3_fwd" if ksize == 3 else "conv1x1_bf16x3_fwd", flops,
                                     cache_key=ckey, dst_shape=oshape, cmap=stride - 1, param=weight,
-                                    gn_sums=gn_sums and ksize == 3 and cout == 256 and cout_s == 256 and not relu)
+                                    gn_sums=gn_sums and ksize == 3 and cout == 256 and cout_s == 256 and not relu,
+                                    out=out)
         else:
-            y = (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
+            y = out if out is not None else (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
             ev = kernel_timer.begin("conv_igemm_fwd", flops)
             call("scan_conv2d_forward", _ptr(x), shape.ref(), cs, _ptr(wp), _ptr(bias), _ptr(y), oshape.ref(), cout,
                  cout_s, ksize, stride, int(bool(relu)), _stream())
@@ -482,11 +489,11 @@ class _Conv2d(torch.autograd.Function):
             call("scan_colsum", _ptr(dy), M, cout, cout_s, _ptr(db), int(direct_b), _ptr(ws), st)
             if direct_b:
                 db = None
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None, mask_dx=False, pool=False,
-           gn_sums=False):
+           gn_sums=False, out=None):
     """Returns rows [M_out, Cout_s]; the output PyramidShape is shape.conv_out(ksize, stride).
     relu: False | True | "deferred" (see _Conv2d); mask_dx: x is a deferred-ReLU output; pool: fuse the following
     2x2 / stride-2 max-pool (forward-only, bf16x3 mode: frozen VGG stages) -- the rows returned are the pooled ones;
@@ -496,7 +503,7 @@ def conv2d(x, weight, bias, shape, ksize=3, stride=1, relu=False, cout_s=None, m
     if pool and torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad
                                              or (bias is not None and bias.requires_grad)):
         raise RuntimeError("conv2d(pool=True) is forward-only (frozen 3x3 conv on a single-level pyramid)")
-    return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx, pool, gn_sums)
+    return _Conv2d.apply(x, weight, bias, shape, ksize, stride, relu, cout_s, mask_dx, pool, gn_sums, out)
 
 
 def conv_pool_fusable(x, weight, bias, shape):
@@ -637,6 +644,64 @@ def maxpool3x3s2(x, shape):
     y = x.new_empty((n * ho * wo, x.shape[1]))
     call("scan_maxpool3x3s2_forward", _ptr(x), n, h, w, x.shape[1], _ptr(y), _stream())
     return y, PyramidShape(n, [(ho, wo)])
+
+
+class _Upsample2xAdd(torch.autograd.Function):
+    """lateral + nearest-2x-upsampled coarse map (FPN top-down join) in one pass; backward: the gradient itself for the
+    lateral, its 2x2 window sums for the coarse map."""
+
+    @staticmethod
+    def forward(ctx, lat, coarse, shape_c):
+        _chk(lat, coarse)
+        (h, w), n = shape_c.sizes[0], shape_c.n_images
+        C = lat.shape[1]
+        assert coarse.shape == (n * h * w, C) and lat.shape[0] == 4 * n * h * w
+        y = torch.empty_like(lat)
+        call("scan_upsample2x_add", _ptr(lat), _ptr(coarse), n, h, w, C, _ptr(y), _stream())
+        ctx.dims = (n, h, w, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        n, h, w, C = ctx.dims
+        g = g.contiguous()
+        d = g.new_empty((n * h * w, C))
+        call("scan_downsample2x_sum", _ptr(g), n, h, w, C, _ptr(d), _stream())
+        return g, d, None
+
+
+def upsample2x_add(lat, coarse, shape_coarse):
+    """lat rows of a single-level pyramid twice the size of shape_coarse (exactly: FPN levels of /32-padded frames)."""
+    return _Upsample2xAdd.apply(lat, coarse, shape_coarse)
+
+
+class _AssembleRows(torch.autograd.Function):
+    """The row blocks ``parts`` already ARE consecutive row ranges of ``buf`` (convs launched with out=buf[r0:r1]):
+    return buf as one tensor; backward hands each producer its rows of the gradient as a view.  Replaces
+    torch.cat(parts, 0) -- a read + write of the whole pyramid -- by nothing."""
+
+    @staticmethod
+    def forward(ctx, buf, *parts):
+        off, offs = 0, []
+        for p in parts:
+            if p.data_ptr() != buf.data_ptr() + off * buf.shape[1] * buf.element_size() or p.shape[1] != buf.shape[1] \
+                    or not p.is_contiguous():
+                raise RuntimeError("assemble_rows: parts must be consecutive row ranges of buf")
+            offs.append((off, off + p.shape[0]))
+            off += p.shape[0]
+        if off != buf.shape[0]:
+            raise RuntimeError("assemble_rows: parts do not cover buf")
+        ctx.offs = offs
+        return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(buf.untyped_storage(), buf.storage_offset(),
+                                                                      buf.shape, buf.stride())
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) + tuple(g[a:b] for a, b in ctx.offs)
+
+
+def assemble_rows(buf, parts):
+    return _AssembleRows.apply(buf, *parts)
 
 
 class _AddReLU(torch.autograd.Function):

@@ -84,7 +84,7 @@ def fpn_top_down(inner, layer, top_blocks, c3, c4, c5):
     s6 = s5.conv_out(3, 2)
     s7 = s6.conv_out(3, 2)
     shape = PyramidShape(s3.n_images, [s.sizes[0] for s in (s3, s4, s5, s6, s7)])
-    direct = c3[0].is_cuda
+    direct = c3[0].is_cuda and ops.FPN_DIRECT
     buf = c3[0].new_empty((shape.rows, 256)) if direct else None
 
     def conv(m, rs, k, stride=1, lvl=None):

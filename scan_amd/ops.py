@@ -184,6 +184,9 @@ BATCHED = os.environ.get("SCAN_BATCHED", "1") != "0"
 # SCAN_CAT_IN_PLACE=0: the CKA discriminators build their class-branch input with torch.cat (+ the contiguous() copy of
 # its gradient slice in the GroupNorm backward) instead of normalising into place, for A/B.  Same values.
 CAT_IN_PLACE = os.environ.get("SCAN_CAT_IN_PLACE", "1") != "0"
+# SCAN_FPN_DIRECT=0: the FPN output convs write tensors of their own that are concatenated afterwards, and the top-down
+# join is an up-sampling copy + add (torch), for A/B.  Same values.
+FPN_DIRECT = os.environ.get("SCAN_FPN_DIRECT", "1") != "0"
 SPLIT_EPOCH = None
 _split_cache = {}
 _epoch_counter = [0]

@@ -180,6 +180,53 @@ def measure(dev, sizes=(M_CFG5, M_BIG), reps=10, K=9, only=None):
                          P(wsc), st()))
         del xc, dxc, yc, dyc, wsc
         torch.cuda.empty_cache()
+        # ---- 2x2 max-pool (VGG stages 3-5) and the FPN top-down join, on 8 single-level images of 256 channels
+        hp, wp = 2 * (h // 2), 2 * (wd_ // 2)
+        Mp = n_img * hp * wp
+        xp = torch.randn((Mp, 256), device=dev, generator=g)
+        yp = torch.empty((Mp // 4, 256), device=dev)
+        rec("maxpool2x2_fwd", Mp, Mp * 1280, "1280M: x read (1024 B / input pixel), y written (256 B / input pixel)",
+            lambda: call("scan_maxpool2x2_forward", P(xp), n_img, hp, wp, 256, P(yp), st()))
+        dyp = torch.randn((Mp // 4, 256), device=dev, generator=g)
+        dxp = torch.empty_like(xp)
+        rec("maxpool2x2_bwd", Mp, Mp * 2560, "2560M: x, y, dy read; dx written",
+            lambda: call("scan_maxpool2x2_backward", P(xp), P(yp), P(dyp), n_img, hp, wp, 256, P(dxp), 1, st()))
+        rec("upsample2x_add", Mp, Mp * 2304, "2304M: lateral read, coarse read (1/4), sum written",
+            lambda: call("scan_upsample2x_add", P(xp), P(yp), n_img, hp // 2, wp // 2, 256, P(dxp), st()))
+        rec("downsample2x_sum", Mp, Mp * 1280, "1280M: g read, 2x2 sums written",
+            lambda: call("scan_downsample2x_sum", P(xp), n_img, hp // 2, wp // 2, 256, P(yp), st()))
+        del xp, yp, dyp, dxp
+        torch.cuda.empty_cache()
+    # ---- bf16 hi / lo planes of all conv weights of a training iteration in one launch (csrc/batched.hip): the C2F
+    # model's job mix (3x3 weights, both plane orientations for the trainable ones), M = fp32 weight elements split
+    jobs, keep, off, elems = [], [], 0, 0
+    for (O, Cs, modes) in [(64, 64, (0,)), (128, 64, (0,)), (128, 128, (0,))] + [(256, 128, (0, 1))] + \
+            [(256, 256, (0, 1))] * 26 + [(512, 256, (0, 1))] + [(512, 512, (0, 1))] * 5 + [(1024, 264, (0, 1))] * 5:
+        w = torch.randn((O, 9, Cs), device=dev, generator=g)
+        for mode in modes:
+            rows_, csw = (O, ops._round32(Cs)) if mode == 0 else (Cs, ops._round32(O))
+            wh = torch.empty((rows_, 9, csw), dtype=torch.bfloat16, device=dev)
+            wl = torch.empty_like(wh)
+            jobs.append([w.data_ptr(), wh.data_ptr(), wl.data_ptr(), O, 9, Cs, mode, rows_, csw, off])
+            off += query("scan_weight_split_job_blocks", O, 9, Cs, mode, csw)
+            keep.append((w, wh, wl))
+            elems += O * 9 * Cs
+    table = torch.tensor(jobs, dtype=torch.int64).to(dev)
+    rec("weight_split_batched", elems, 8 * elems, "8 B per weight element and orientation: fp32 read, bf16 hi + lo written",
+        lambda: call("scan_weight_split_batched", P(table), len(jobs), off, st()), unit="element")
+    del keep, table
+    # ---- class-aware NMS on one image's candidate set (a18): latency-bound, reported as time (bytes = the 20 B / box read)
+    for n_box in (1000, 4000, 8192):
+        xy = torch.rand((n_box, 2), device=dev, generator=g) * 1000
+        wh_ = torch.rand((n_box, 2), device=dev, generator=g) * 120 + 4
+        boxes = torch.cat([xy, xy + wh_], 1).contiguous()
+        scores = torch.rand((n_box,), device=dev, generator=g)
+        labels = torch.randint(1, 9, (n_box,), device=dev, generator=g).float()
+        wsn = torch.empty((query("scan_nms_ws_bytes", n_box) + 15) // 16 * 2, dtype=torch.float64, device=dev)
+        keepn = torch.empty((n_box,), dtype=torch.int64, device=dev)
+        cnt = torch.zeros((1,), dtype=torch.int32, device=dev)
+        rec("nms_by_label_n%d" % n_box, n_box, 24 * n_box, "24 B / box read (sort + 64x64 IoU bit-mask tiles + scan: latency-bound, see us)",
+            lambda: call("scan_nms", P(boxes), P(scores), P(labels), n_box, 0.6, 1, P(keepn), P(cnt), P(wsn), st()), unit="box")
     return out
 
 
@@ -188,10 +235,13 @@ def main():
     ap.add_argument("--out", default="")
     ap.add_argument("--small", action="store_true", help="only the configs[4] size")
     ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--only", default="", help="comma-separated kernel names (for counter passes over a few kernels)")
+    ap.add_argument("--big-only", action="store_true", help="only the M = 2^24 size")
     a = ap.parse_args()
     import torch
     dev = torch.device("cuda:0")
-    res = measure(dev, (M_CFG5,) if a.small else (M_CFG5, M_BIG), a.reps)
+    sizes = (M_CFG5,) if a.small else ((M_BIG,) if a.big_only else (M_CFG5, M_BIG))
+    res = measure(dev, sizes, a.reps, only=set(a.only.split(",")) if a.only else None)
     for r in res:
         print("%-26s M=%9d %8.1f us %8.1f GB/s  frac %.3f%s" % (r["kernel"], r["M"], r["us"], r["GBps"], r["frac"],
                                                                "  (fits LLC)" if r["fits_llc"] else ""))

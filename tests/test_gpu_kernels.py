@@ -1093,3 +1093,78 @@ def test_target_plan_kernels_equal_torch_plan(device, case):
         per_level = [(int((lab[shape.row_off[l]:shape.row_off[l + 1]] > 0).sum()), shape.row_off[l + 1] - shape.row_off[l])
                      for l in range(shape.n_levels)]
         assert any(p > r - p for p, r in per_level), per_level
+
+
+# ----------------------------------------------------------------------------- in-place assembly / strided GroupNorm / FPN join
+def test_upsample2x_add_and_backward(device):
+    """ops.upsample2x_add = lateral + F.interpolate(coarse, scale_factor=2, 'nearest') (reference backbone/fpn.py:62-75);
+    backward: the gradient itself for the lateral, its 2x2 window sums for the coarse map."""
+    import torch.nn.functional as F
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(31)
+    n, h, w, C = 2, 5, 7, 256
+    lat = torch.randn(n, C, 2 * h, 2 * w, generator=g, requires_grad=True)
+    coarse = torch.randn(n, C, h, w, generator=g, requires_grad=True)
+    ref = lat + F.interpolate(coarse, scale_factor=2, mode="nearest")
+    up = torch.randn(n, C, 2 * h, 2 * w, generator=g)
+    ref.backward(up)
+    lr, ls = ops.nchw_to_rows(lat.detach().to(device))
+    cr, cs = ops.nchw_to_rows(coarse.detach().to(device))
+    lr.requires_grad_(True)
+    cr.requires_grad_(True)
+    y = ops.upsample2x_add(lr, cr, cs)
+    y.backward(ops.nchw_to_rows(up.to(device))[0])
+    assert torch.equal(ops.rows_to_nchw(y.detach(), ls).cpu(), ref.detach())
+    assert torch.equal(ops.rows_to_nchw(lr.grad, ls).cpu(), lat.grad)
+    np.testing.assert_allclose(ops.rows_to_nchw(cr.grad, cs).cpu().numpy(), coarse.grad.numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_groupnorm_into_wider_matrix_and_cat_into(device):
+    """groupnorm_relu(out_buf=...) + cat_into == torch.cat([groupnorm_relu(x), extra, 0-pad], 1), forward bit for bit and
+    every gradient (the GroupNorm backward reads its column slice of the incoming gradient in place)."""
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(32)
+    shape = ops.PyramidShape(2, [(12, 20), (6, 10), (3, 5)])
+    M = shape.rows
+    x = torch.randn(M, 256, generator=g).to(device)
+    gam, bet = (torch.rand(256, generator=g) + 0.5).to(device), torch.randn(256, generator=g).to(device)
+    extra = torch.rand(M, 5, generator=g).to(device)
+    w = torch.randn(M, 264, generator=g).to(device)  # weights of a scalar loss: a distinct gradient for every column
+    res = []
+    for in_place in (False, True):
+        xs = [t.clone().requires_grad_(True) for t in (x, gam, bet, extra)]
+        if in_place:
+            buf = x.new_empty((M, 264))
+            y = ops.groupnorm_relu(xs[0], xs[1], xs[2], shape, out_buf=buf)
+            assert y.data_ptr() == buf.data_ptr() and y.stride() == (264, 1)
+            cat = ops.cat_into(y, xs[3], buf)
+        else:
+            y = ops.groupnorm_relu(xs[0], xs[1], xs[2], shape)
+            cat = torch.cat([y, xs[3], y.new_zeros(M, 3)], 1)
+        (cat * w).sum().backward()
+        res.append((cat.detach().clone(), [t.grad.clone() for t in xs]))
+    assert torch.equal(res[0][0], res[1][0])
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), (a - b).abs().max().item()
+
+
+def test_split_levels_grl_equals_split_then_grl(device):
+    from scan_amd import ops
+    g = torch.Generator().manual_seed(33)
+    shape = ops.PyramidShape(2, [(8, 12), (4, 6), (2, 3)])
+    rows = torch.randn(shape.rows, 12, generator=g).to(device)
+    lams = [0.02, 0.1, 0.5]
+    ups = [torch.randn(shape.row_off[l + 1] - shape.row_off[l], 12, generator=g).to(device) for l in range(3)]
+    grads = []
+    for fused in (False, True):
+        r = rows.clone().requires_grad_(True)
+        if fused:
+            parts = ops.split_levels_grl(r, shape, lams)
+        else:
+            parts = [ops.grad_reverse(p, lam) for p, lam in zip(ops.split_levels(r, shape), lams)]
+        for p, ref in zip(parts, ops.split_levels(rows, shape)):
+            assert torch.equal(p.detach(), ref)
+        sum((p * u).sum() for p, u in zip(parts[:2], ups[:2])).backward()  # level 2 unused: its rows get zeros
+        grads.append(r.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert float(grads[1][shape.row_off[2]:].abs().sum()) == 0.0

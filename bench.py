@@ -92,10 +92,12 @@ def symbol_of(name):
         if bn > 1000:
             bn, nt = bn - 1000, 1024
         return "conv_bf16x3_v2_kernel<%d,%d,%d,%d>" % (bn, th, nt, 3 if m.group(1) == "3x3" else 1)
-    return {"conv1x1_bf16x3_wgrad_g1": "conv3x3_wgrad_bf16x3_kernel<1,S>",
-            "conv1x1_bf16x3_wgrad_g2": "conv_wgrad_bf16x3_v2_kernel<1,S>",
-            "conv3x3_bf16x3_wgrad_g1": "conv3x3_wgrad_bf16x3_kernel<3,1>",
-            "conv3x3_bf16x3_wgrad_g2": "conv_wgrad_bf16x3_v2_kernel<3,1>",
+    # the _g1 / _g2 suffix is the round-2 generation choice by input channel count (scan_conv_wgrad_bf16x3_generation);
+    # since round 3 every bf16x3 weight-gradient launch runs conv_wgrad_bf16x3_v6_kernel (3x3) / _v4_kernel (1x1)
+    return {"conv1x1_bf16x3_wgrad_g1": "conv_wgrad_bf16x3_v4_kernel<1,S>",
+            "conv1x1_bf16x3_wgrad_g2": "conv_wgrad_bf16x3_v4_kernel<1,S>",
+            "conv3x3_bf16x3_wgrad_g1": "conv_wgrad_bf16x3_v6_kernel<3>",
+            "conv3x3_bf16x3_wgrad_g2": "conv_wgrad_bf16x3_v6_kernel<3>",
             "conv_smallcin_bf16x3": "conv_smallcin_kernel",
             "conv_igemm_fwd": "conv_igemm_kernel<0,4>", "conv_igemm_dgrad": "conv_igemm_kernel<1,4>",
             "conv_wgrad": "conv_wgrad_kernel"}.get(name, name)
@@ -317,8 +319,8 @@ def main():
     # frames go through the collator's zero padding to /32 (structures.to_image_list), e.g. 1333x2666 -> 1344x2688
     imgs_s = engine.to_image_list([t.to(dev) for t in synth.synth_image_list([(H, W)] * B, 1234 + 100 * rank)], 32)
     imgs_t = engine.to_image_list([t.to(dev) for t in synth.synth_image_list([(H, W)] * B, 2234 + 100 * rank)], 32)
-    tg = [(b.to(dev), l.to(dev))
-          for b, l in synth.synth_targets(B, H, W, mcfg["num_classes"] - 1, 12, 4321 + 100 * rank)]
+    # ground truth as the collator delivers it: host tensors (the plan kernels upload it on their own stream)
+    tg = synth.synth_targets(B, H, W, mcfg["num_classes"] - 1, 12, 4321 + 100 * rank)
 
     def barrier():
         if dist.is_initialized():

@@ -833,7 +833,7 @@ def do_train(trainer, loader_source, loader_target, max_iter, val_dataset=None, 
             break
         forward_target = gate.forward_target if gate is not None else False
         dev = il_s.tensors.device if il_s.tensors is not None else il_s.rows.device
-        tg_s = [(b.to(dev), l.to(dev)) for b, l in tg_s]
+        # the ground truth stays on the host: the plan kernels upload it on their own stream (fcos._build_plan_device)
         losses = trainer.step(il_s, tg_s, il_t, forward_target=forward_target)
         reduced = comm.reduce_loss_dict(losses)
         if comm.is_main_process():

@@ -29,6 +29,11 @@ GROUPS = [  # (substring of the kernel name, group key); conv keys = the symbols
     ("conv3x3_bf16x3_kernelILi64ELi8ELi256ELi3", "conv3x3_bf16x3_fwd_bn64"),
     ("conv3x3_bf16x3_kernelILi128ELi16ELi512ELi1", "conv1x1_bf16x3_fwd_dgrad_bn128"),
     ("conv3x3_bf16x3_kernelILi64ELi8ELi256ELi1", "conv1x1_bf16x3_fwd_dgrad_bn64"),
+    ("conv_wgrad_bf16x3_v6_kernel", "conv_wgrad_bf16x3_v6_kernel<3>"),
+    ("conv_wgrad_bf16x3_v4_kernelILi3", "conv_wgrad_bf16x3_v4_kernel<3,1>"), ("conv_wgrad_bf16x3_v4_kernel<3", "conv_wgrad_bf16x3_v4_kernel<3,1>"),
+    ("conv_wgrad_bf16x3_v4_kernelILi1", "conv_wgrad_bf16x3_v4_kernel<1,S>"), ("conv_wgrad_bf16x3_v4_kernel<1", "conv_wgrad_bf16x3_v4_kernel<1,S>"),
+    ("fcos_assign_kernel", "fcos_assign"), ("fcos_compact_kernel", "fcos_compact"), ("fcos_nodes_kernel", "fcos_nodes"),
+    ("upsample2x_add_kernel", "upsample2x_add"), ("downsample2x_sum_kernel", "downsample2x_sum"),
     ("conv_wgrad_bf16x3_v2_kernelILi3", "conv_wgrad_bf16x3_v2_kernel<3,1>"), ("conv_wgrad_bf16x3_v2_kernel<3", "conv_wgrad_bf16x3_v2_kernel<3,1>"),
     ("conv_wgrad_bf16x3_v2_kernelILi1", "conv_wgrad_bf16x3_v2_kernel<1,S>"), ("conv_wgrad_bf16x3_v2_kernel<1", "conv_wgrad_bf16x3_v2_kernel<1,S>"),
     ("conv3x3_wgrad_bf16x3_kernelILi3", "conv3x3_wgrad_bf16x3_kernel<3,1>"), ("conv3x3_wgrad_bf16x3_kernel<3", "conv3x3_wgrad_bf16x3_kernel<3,1>"),

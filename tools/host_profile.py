@@ -28,7 +28,7 @@ def main():
     H, W, B = 1024, 2048, 2
     imgs_s = engine.to_image_list([t.to(dev) for t in synth.synth_image_list([(H, W)] * B, 1234)], 32)
     imgs_t = engine.to_image_list([t.to(dev) for t in synth.synth_image_list([(H, W)] * B, 2234)], 32)
-    tg = [(b.to(dev), l.to(dev)) for b, l in synth.synth_targets(B, H, W, mcfg["num_classes"] - 1, 12, 4321)]
+    tg = synth.synth_targets(B, H, W, mcfg["num_classes"] - 1, 12, 4321)  # host tensors, as the collator delivers them
     for _ in range(3):
         trainer.step(imgs_s, tg, imgs_t)
     torch.cuda.synchronize()

@@ -95,7 +95,10 @@ _plan_streams = {}
 def _plan_stream(device):
     s = _plan_streams.get(device)
     if s is None:
-        s = _plan_streams[device] = torch.cuda.Stream(device)
+        # high priority: a hardware queue of its own class.  A process has few hardware queues (HIP maps its streams
+        # onto them); sharing one with the main stream put the three small plan kernels behind a whole iteration of
+        # queued convolutions and the host read of the plan waited ~25 ms for them (tools/host_profile.py)
+        s = _plan_streams[device] = torch.cuda.Stream(device, priority=-1)
     return s
 
 

@@ -95,10 +95,14 @@ _plan_streams = {}
 def _plan_stream(device):
     s = _plan_streams.get(device)
     if s is None:
-        # high priority: a hardware queue of its own class.  A process has few hardware queues (HIP maps its streams
-        # onto them); sharing one with the main stream put the three small plan kernels behind a whole iteration of
-        # queued convolutions and the host read of the plan waited ~25 ms for them (tools/host_profile.py)
-        s = _plan_streams[device] = torch.cuda.Stream(device, priority=-1)
+        # SCAN_PLAN_PRIO=-1 gives the plan a high-priority stream (a hardware queue of its own class): its three small
+        # kernels then run at once and the host read of the plan returns in microseconds instead of ~25 ms (HIP maps
+        # its streams onto few hardware queues; on a shared one the plan sits behind a whole iteration of queued
+        # convolutions).  Measured, it is the WRONG trade on this part: with the extra queue class -- or with
+        # GPU_MAX_HW_QUEUES=8 -- the side streams stop overlapping usefully and the step goes from 61 to 68-76 ms
+        # (profiles/r03_host_runahead.txt).  Default: normal priority.
+        import os
+        s = _plan_streams[device] = torch.cuda.Stream(device, priority=int(os.environ.get("SCAN_PLAN_PRIO", "0")))
     return s
 
 
@@ -358,6 +362,9 @@ class Trainer:
         # (step_paired): same losses and gradients as the three phases, larger launches.  Used when both batches
         # have the same padded size.
         self.paired = True
+        import os
+        self.throttle = os.environ.get("SCAN_THROTTLE", "none")
+        self._throttle_ev = None
 
     def _allreduce_async(self, keys, after_side_streams=False):
         """all-reduce the flat gradient buffers of sub-models whose gradients are final, on the side stream."""
@@ -595,6 +602,7 @@ class Trainer:
         loss (label 0) on the two halves of a level.  The reference's three backward calls (trainer.py:299,343,377)
         accumulate into the same .grad, so ONE backward of the summed losses leaves identical gradients."""
         model, lam = self.model, self.con_dis_lambda
+        self._throttle()
         ops.begin_weight_epoch(self._split_plan)
         fcos_mod.reset_target_plan()
         for m in model.values():
@@ -670,12 +678,32 @@ class Trainer:
             if not getattr(model["backbone"], "grad_marks", None):
                 self._hook_ready(rows, "middle_head")
             self._hook_backbone_marks()
+        self._mark("mid")
         sum(losses.values()).backward()
         self._join_streams()
         losses["zero_gt"] = feats.new_zeros(())
         self._flush_buckets()
         self._optimizer_step()
+        self._mark("end")
         return losses
+
+    # ---- host run-ahead knob (SCAN_THROTTLE, default "none"): the step can wait, at its top, for a point of the PREVIOUS
+    # iteration -- "mid" = its forward pass has been executed, "end" = all of it.  In the default configuration the one
+    # host read of the ground-truth plan already keeps the host within one iteration of the GPU; the knob exists for the
+    # experiments of profiles/r03_host_runahead.txt (no setting beat the default).
+    def _mark(self, which):
+        if self.tgt_stream is None or self.throttle == "none":
+            return
+        if which == self.throttle:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._throttle_ev = ev
+
+    def _throttle(self):
+        ev = getattr(self, "_throttle_ev", None)
+        if ev is not None:
+            ev.synchronize()
+            self._throttle_ev = None
 
     def step(self, images_s, targets_s, images_t, forward_target=False):
         """One DA iteration; returns the loss dict (0-dim GPU tensors, reference key names)."""

@@ -12,6 +12,8 @@ buffer each (weights first, biases after), so the optimizer is two fused-SGD lau
 sub-model and data parallelism is one RCCL all-reduce per flat gradient buffer, issued on a side
 HIP stream as soon as that sub-model's last backward contribution is final.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -101,7 +103,6 @@ def _plan_stream(device):
         # convolutions).  Measured, it is the WRONG trade on this part: with the extra queue class -- or with
         # GPU_MAX_HW_QUEUES=8 -- the side streams stop overlapping usefully and the step goes from 61 to 68-76 ms
         # (profiles/r03_host_runahead.txt).  Default: normal priority.
-        import os
         s = _plan_streams[device] = torch.cuda.Stream(device, priority=int(os.environ.get("SCAN_PLAN_PRIO", "0")))
     return s
 
@@ -354,7 +355,10 @@ class Trainer:
         # fill 256 CUs, so they run on side HIP streams next to P3 (autograd replays each backward on the stream
         # of its forward, so the backward overlaps the same way).
         on_gpu = next(next(iter(model.values())).parameters()).is_cuda
-        self.dis_streams = {lvl: torch.cuda.Stream() for lvl in ("P4", "P5", "P6", "P7")} if on_gpu else {}
+        # SCAN_DIS_STREAMS = number of side streams the four small levels share (default 4: one each)
+        n_side = max(1, min(4, int(os.environ.get("SCAN_DIS_STREAMS", "4"))))
+        pool = [torch.cuda.Stream() for _ in range(n_side)] if on_gpu else []
+        self.dis_streams = {lvl: pool[i % n_side] for i, lvl in enumerate(("P4", "P5", "P6", "P7"))} if on_gpu else {}
         self.tgt_stream = torch.cuda.Stream() if on_gpu else None
         self.overlap_target = True
         self.merge_source_backward = True
@@ -362,7 +366,6 @@ class Trainer:
         # (step_paired): same losses and gradients as the three phases, larger launches.  Used when both batches
         # have the same padded size.
         self.paired = True
-        import os
         self.throttle = os.environ.get("SCAN_THROTTLE", "none")
         self._throttle_ev = None
 

@@ -71,7 +71,11 @@ int scan_abi_version(void);
  *                 2 / 3: two / three per block; 0: together before the barrier.  Same results.
  *   "wgrad_v5"    1: the fourth generation's staging in the double-buffered, staggered structure of "wgrad_v3"
  *                 (default 0: measured slower).
- *   "wgrad_exp"   1..4: timing ablations of the second-generation kernel (WRONG results; profiles/r03_wgrad_exp.txt).
+ *   "wgrad_v6"    1 (default): the 3x3 launches take the producer / consumer sixth generation (12 waves: 8 issue MFMAs, 4
+ *                 stage; bit-identical to "wgrad_v4"); "wgrad_prio" 1 (default): its producer waves run at s_setprio 3.
+ *   "conv_exp"    1..4: timing ablations of the 256-channel forward instance (WRONG results; profiles/r03_conv_exp.txt).
+ *   "wgrad_exp"   1..4: timing ablations of the second-generation kernel, 5..7 of the sixth (WRONG results;
+ *                 profiles/r03_wgrad_exp.txt, r03_wgrad_v6_exp.txt).
  *   "conv_glds"   1 (default): the 16-wave 128- / 256-channel 3x3 instances stage weight tiles by LDS-DMA
  *                 (global_load_lds_dwordx4) on whole tiles; 0: through registers.  Same results bit for bit. */
 int scan_tune(const char* key, int value);

@@ -30,6 +30,7 @@ extern int g_scan_gconv_mfma;
 extern int g_scan_wgrad_wgs;
 extern int g_scan_conv_glds;
 extern int g_scan_wgrad_exp;
+extern int g_scan_conv_exp;
 extern int g_scan_wgrad_v4;
 extern int g_scan_wgrad_v5;
 extern int g_scan_wgrad_il;
@@ -50,6 +51,7 @@ static int* tune_slot(const char* key) {
   if (strcmp(key, "wgrad_wgs") == 0) slot = &g_scan_wgrad_wgs;
   if (strcmp(key, "conv_glds") == 0) slot = &g_scan_conv_glds;
   if (strcmp(key, "wgrad_exp") == 0) slot = &g_scan_wgrad_exp;
+  if (strcmp(key, "conv_exp") == 0) slot = &g_scan_conv_exp;
   if (strcmp(key, "wgrad_v4") == 0) slot = &g_scan_wgrad_v4;
   if (strcmp(key, "wgrad_v5") == 0) slot = &g_scan_wgrad_v5;
   if (strcmp(key, "wgrad_il") == 0) slot = &g_scan_wgrad_il;

@@ -28,6 +28,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define V2_TW 16
+#ifndef SCAN_CONV_WN4
+#define SCAN_CONV_WN4 0  // 1: 4 x 4 wave grid on the 16-wave 256-channel tile (measured 1-3 % slower: profiles/r03_conv_exp.txt)
+#endif
 #define V2_CK 32  // channels per K chunk = one k-step of v_mfma_f32_16x16x32_bf16
 
 struct TileTab2 {
@@ -77,7 +80,11 @@ __device__ __forceinline__ int swz(int idx) { return (idx >> 1) & 2; }
 typedef __attribute__((address_space(3))) void* v2_lds_ptr;
 typedef const __attribute__((address_space(1))) void* v2_glb_ptr;
 
-template <int BN, int TH, int NT, int KS, int TPB = 1, bool GL = false>
+// EXP != 0: TIMING ABLATIONS ONLY (wrong results; scan_tune "conv_exp", instantiated for the 256-channel LDS-DMA instance):
+//   1 no MFMAs (staging, DMA, barriers and fragment reads stay)   2 weight DMA and patch loads / stores for the first
+//   (chunk, tap) only (MFMAs, fragment reads and barriers stay)   3 as 2 without the per-tap barriers
+//   4 as 2 with the fragments of the first tap kept in registers (MFMAs and barriers only)
+template <int BN, int TH, int NT, int KS, int TPB = 1, bool GL = false, int EXP = 0>
 __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ wh,
     const __bf16* __restrict__ wl, int Csw, const float* __restrict__ bias, const float* __restrict__ mask,
@@ -88,7 +95,10 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
   constexpr int PWK = V2_TW + 2 * HALO;
   constexpr int NPATCH = PH * PWK;
   constexpr int WAVES = NT / 64;
-  constexpr int WN_WAVES = BN >= 128 ? 2 : 1;
+  // wave grid (pixel rows x channels).  -DSCAN_CONV_WN4=1 builds the 16-wave 256-channel tile as 4 x 4 waves (a wave owns
+  // 64 pixels x 64 channels, 8 + 8 fragment reads per 48 MFMAs instead of 4 + 16): it spills one patch slot at the
+  // 128-register cap and measured 1-3 % slower than 8 x 2 (profiles/r03_conv_exp.txt)
+  constexpr int WN_WAVES = (BN == 256 && NT == 1024 && SCAN_CONV_WN4) ? 4 : (BN >= 128 ? 2 : 1);
   constexpr int WM_WAVES = WAVES / WN_WAVES;
   constexpr int TM = TH / WM_WAVES;             // 16-pixel tile rows per wave (4, or 2 for the 8-row tile)
   constexpr int TN = BN / (16 * WN_WAVES);      // 16-channel tiles per wave (4, or 8 for BN = 256)
@@ -128,8 +138,11 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
   // (the round-2 version spilled to scratch at the 128-register cap of the 16-wave instances and the compiler put a
   // vmcnt(0) wait right behind the first load of every chunk).
   constexpr unsigned BAD = 0x80000000u;
-  unsigned voff[ASLOTS], voff_last[ASLOTS];
+  unsigned voff[ASLOTS];
   const int c_tail = Cs - (nchunks - 1) * V2_CK;  // channels of the last chunk (1..32)
+  // a lane's float4 column inside a chunk is the same for all its slots (NT is a multiple of 8): one predicate says
+  // whether it lies beyond the channel count in the last chunk
+  const bool tail_bad = 4 * (tid & 7) >= c_tail;
   __amdgpu_buffer_rsrc_t a_src;
   {
     const bool mapped = KS == 1 && map != 0;
@@ -160,17 +173,15 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
         }
       }
       voff[i] = ok ? (unsigned)((pix * Cs + 4 * c4) * 4) : BAD;
-      voff_last[i] = (4 * c4 < c_tail) ? voff[i] : BAD;
     }
   }
   float4 ra[ASLOTS];
   auto load_a = [&](int cc) {
     const int soff = cc * (V2_CK * 4);
-    const bool last = cc == nchunks - 1;
+    const bool kill = tail_bad && cc == nchunks - 1;
 #pragma unroll
     for (int i = 0; i < ASLOTS; ++i)
-      ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_src, (int)(last ? voff_last[i] : voff[i]),
-                                                                                soff, 0));
+      ra[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_src, (int)(kill ? BAD : voff[i]), soff, 0));
   };
   auto store_a = [&]() {
 #pragma unroll
@@ -266,7 +277,38 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
 #pragma unroll
     for (int b = 0; b < TN; ++b) acc[a][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
+  bf16x8 keep_ph[TM], keep_pl[TM], keep_wh[TN], keep_wl[TN];  // EXP 4 only
+  bool keep_valid = false;
   auto taps_mma = [&](int grp, int buf) {
+    if constexpr (EXP == 4) {
+      if (!keep_valid) {
+        const int p_off = ((wm * TM) * PWK + lr) * 32 + ((kg ^ swz(lr)) << 3);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          keep_ph[tm] = *reinterpret_cast<const bf16x8*>(Ah + p_off + tm * PWK * 32);
+          keep_pl[tm] = *reinterpret_cast<const bf16x8*>(Al + p_off + tm * PWK * 32);
+        }
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+          keep_wh[tn] = *reinterpret_cast<const bf16x8*>(Bs + w_off + tn * 16 * 32);
+          keep_wl[tn] = *reinterpret_cast<const bf16x8*>(Bs + BN * 32 + w_off + tn * 16 * 32);
+        }
+        keep_valid = true;
+      }
+#pragma unroll
+      for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(keep_wh[tn], keep_pl[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(keep_wl[tn], keep_ph[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm)
+          acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(keep_wh[tn], keep_ph[tm], acc[tm][tn], 0, 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int tt = 0; tt < TPB; ++tt) {
       const int tap = grp * TPB + tt;
@@ -298,6 +340,12 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
         const bf16x8 whv = *reinterpret_cast<const bf16x8*>(bh + tn * 16 * 32);
         const bf16x8 wlv = *reinterpret_cast<const bf16x8*>(bl + tn * 16 * 32);
 #endif
+        if constexpr (EXP == 1) {  // keep the fragment reads alive, issue no MFMA
+          asm volatile("" ::"v"(whv), "v"(wlv));
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm) asm volatile("" ::"v"(ph[tm]), "v"(pl[tm]));
+          continue;
+        }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm)
           acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, pl[tm], acc[tm][tn], 0, 0, 0);
@@ -314,26 +362,29 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
   load_a(0);
   if constexpr (GL) {
     issue_b(0, 0, 0);
+    constexpr bool FROZEN = EXP >= 2;  // ablations 2..4: memory side and staging for the first (chunk, tap) only
     for (int cc = 0; cc < nchunks; ++cc) {
-      __syncthreads();  // every wave is done reading the previous chunk's patch
-      store_a();
-      if (NGRP == 1 && cc + 1 < nchunks) load_a(cc + 1);
+      if (!(EXP == 3 && cc > 0)) __syncthreads();  // every wave is done reading the previous chunk's patch
+      if (!FROZEN || cc == 0) store_a();
+      if (!FROZEN && NGRP == 1 && cc + 1 < nchunks) load_a(cc + 1);
 #pragma unroll 1
       for (int grp = 0; grp < NGRP; ++grp) {
-        const int buf = (cc * NGRP + grp) & 1;
+        const int buf = FROZEN ? 0 : (cc * NGRP + grp) & 1;
         // an LDS-DMA counts on vmcnt and the compiler does not wait for it on its own: this wave's pieces of the tile
         // (issued one tap ago) must have landed before the barrier publishes the tile
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();  // this tap's weight tile is complete for everyone; the patch is visible
-        // the other buffer was last read one tap ago: the next tap's tile goes there while this one is multiplied
-        if (grp < NGRP - 1)
-          issue_b(cc, grp + 1, buf ^ 1);
-        else if (cc + 1 < nchunks)
-          issue_b(cc + 1, 0, buf ^ 1);
-        // the next chunk's patch: fetched one tap before it is needed (the barrier above drains every outstanding
-        // load, so an earlier prefetch would only stall an earlier tap)
-        if (NGRP > 1 && grp == NGRP - 2 && cc + 1 < nchunks) load_a(cc + 1);
-        taps_mma(grp, buf);
+        if (!(EXP == 3 && (cc > 0 || grp > 0))) __syncthreads();  // this tap's weight tile is complete; the patch is visible
+        if (!FROZEN) {
+          // the other buffer was last read one tap ago: the next tap's tile goes there while this one is multiplied
+          if (grp < NGRP - 1)
+            issue_b(cc, grp + 1, buf ^ 1);
+          else if (cc + 1 < nchunks)
+            issue_b(cc + 1, 0, buf ^ 1);
+          // the next chunk's patch: fetched one tap before it is needed (the barrier above drains every outstanding
+          // load, so an earlier prefetch would only stall an earlier tap)
+          if (NGRP > 1 && grp == NGRP - 2 && cc + 1 < nchunks) load_a(cc + 1);
+        }
+        taps_mma(FROZEN ? 0 : grp, buf);
       }
     }
   } else {
@@ -462,7 +513,7 @@ static void make_tiles_v2(const scan_pyramid_t* d, TileTab2* tt, int TH) {
   }
 }
 
-template <int BN, int TH, int NT, int KS, int TPB = 1, bool GL = false>
+template <int BN, int TH, int NT, int KS, int TPB = 1, bool GL = false, int EXP = 0>
 static void launch_v2(const float* x, const scan_pyramid_t* od, int32_t Cs, const __bf16* h, const __bf16* l, int32_t Csw,
                       const float* bias, const float* mask, float* y, int32_t Nout, int32_t Ns, int32_t relu,
                       hipStream_t st, double* gn_ws, const scan_pyramid_t* sd, int map) {
@@ -474,12 +525,12 @@ static void launch_v2(const float* x, const scan_pyramid_t* od, int32_t Cs, cons
   const size_t sh = (size_t)(2 * (TH + 2 * HALO) * (V2_TW + 2 * HALO) * 32 + 4 * TPB * BN * 32) * sizeof(__bf16);
   static bool done = false;
   if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB, GL>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB, GL, EXP>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     done = true;
   }
-  hipLaunchKernelGGL((conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB, GL>), dim3(tiles * n_tiles), dim3(NT), sh, st, x, *od, Cs, h,
-                     l, Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *sd, map, gn_ws);
+  hipLaunchKernelGGL((conv_bf16x3_v2_kernel<BN, TH, NT, KS, TPB, GL, EXP>), dim3(tiles * n_tiles), dim3(NT), sh, st, x, *od,
+                     Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, tt, n_tiles, *sd, map, gn_ws);
 }
 
 // Instance choice for an output pyramid and channel count: 64 (8x16-pixel tiles, 256 threads), 128 or 256 (16x16-pixel
@@ -503,6 +554,8 @@ int g_scan_conv_tpb3 = 1;
 // 1431 -> 1349 (458 TFLOP/s); neutral on the 128-channel instance; the 64-channel instance gets slower (1906 -> 2040)
 // and stays on registers.  Training step, three alternating runs on one box: 70.6 / 70.3 / 71.2 -> 69.3 / 69.2 / 69.4 ms.
 int g_scan_conv_glds = 1;
+// scan_tune "conv_exp": timing ablations of the 256-channel LDS-DMA instance (wrong results; see the kernel)
+int g_scan_conv_exp = 0;
 // scan_tune "conv_bn64_th16": the <= 64-channel 3x3 instance on 16x16-pixel tiles (4 waves x 64 px x 64 ch: 48 MFMAs per
 // wave and barrier instead of 24) instead of 8x16 -- 1 (default): single-level pyramids with H, W multiples of 16, 0:
 // never.  conv1_2 (64 -> 64 at 1024x2048, 4 frames) 2047 -> 1940 us, conv2_1 990 -> 981 us (tools/conv_bench.py).
@@ -535,7 +588,13 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
     case 256:
       if ((g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1)) && g_scan_conv_glds && Csw % 32 == 0 &&
           Nout % 256 == 0)
-        launch_v2<256, 16, 1024, 3, 1, true>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+        switch (g_scan_conv_exp) {
+          case 1: launch_v2<256, 16, 1024, 3, 1, true, 1>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+          case 2: launch_v2<256, 16, 1024, 3, 1, true, 2>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+          case 3: launch_v2<256, 16, 1024, 3, 1, true, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+          case 4: launch_v2<256, 16, 1024, 3, 1, true, 4>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
+          default: launch_v2<256, 16, 1024, 3, 1, true>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+        }
       else if (g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1))
         launch_v2<256, 16, 1024, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       else

@@ -430,6 +430,12 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
   // ---- epilogue.  C/D map of 16x16: column = lane & 15 = pixel x of tile row tm, row = 4 * (lane >> 4) + reg = output
   // channel inside channel tile tn: one lane owns four consecutive channels of one pixel
   const int x = tx0 + lr;
+  // GroupNorm sums leave the workgroup as ONE fp64 atomic pair per group (not one per wave and group): every tile of a frame
+  // adds to the same 64 doubles, and same-address device-scope atomics serialise -- with a pair per wave the towers' forward
+  // ran 20 % behind their data gradient (same kernel, same shape, no sums).  The waves' partials meet in the LDS the main
+  // loop is done with.
+  double* gn_red = reinterpret_cast<double*>(smem_raw);  // [WM_WAVES][BN / 8][2]
+  if (gn_ws != nullptr) __syncthreads();
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
     const int o4 = n0 + wn * 16 * TN + tn * 16 + 4 * kg;
@@ -510,11 +516,21 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
         ds += __shfl_xor(ds, sh, 64);
         dq += __shfl_xor(dq, sh, 64);
       }
-      if (lr == 0 && (kg & 1) == 0 && o4 < Nout) {
-        const int64_t slot = ((int64_t)(lvl * d.n_images + img) * 32 + (o4 >> 3)) * 2;
-        atomicAdd(&gn_ws[slot], ds);
-        atomicAdd(&gn_ws[slot + 1], dq);
+      if (lr == 0 && (kg & 1) == 0) {
+        double* r = gn_red + (wm * (BN / 8) + ((o4 - n0) >> 3)) * 2;
+        r[0] = ds;
+        r[1] = dq;
       }
+    }
+  }
+  if (gn_ws != nullptr) {
+    __syncthreads();
+    if (tid < BN / 8 * 2) {
+      const int g = n0 / 8 + (tid >> 1);
+      double v = 0.0;
+#pragma unroll
+      for (int w = 0; w < WM_WAVES; ++w) v += gn_red[w * (BN / 8) * 2 + tid];
+      if (g * 8 < Nout) atomicAdd(&gn_ws[((int64_t)(lvl * d.n_images + img) * 32 + g) * 2 + (tid & 1)], v);
     }
   }
 }

@@ -89,6 +89,8 @@ def symbol_of(name):
     if m:
         bn = int(m.group(3))
         th, nt = (8, 256) if bn == 64 else (16, 512)
+        if bn > 2000:  # the 8-wave LDS-DMA instance of the 256-channel tile
+            return "conv_bf16x3_v2_kernel<%d,%d,512,3,1,true>" % (bn - 2000, th)
         if bn > 1000:
             bn, nt = bn - 1000, 1024
         return "conv_bf16x3_v2_kernel<%d,%d,%d,%d>" % (bn, th, nt, 3 if m.group(1) == "3x3" else 1)

@@ -31,6 +31,9 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 #ifndef SCAN_CONV_MID
 #define SCAN_CONV_MID 0  // channel tile of a barrier interval behind whose MFMAs the LDS-DMA path feeds the next tile; -1: right behind the barrier
 #endif
+#ifndef SCAN_CONV_PFA
+#define SCAN_CONV_PFA 1  // 8-wave LDS-DMA instance: patch fragments of the next tap prefetched in front of the barrier
+#endif
 #ifndef SCAN_CONV_WN4
 #define SCAN_CONV_WN4 0  // 1: 4 x 4 wave grid on the 16-wave 256-channel tile (measured 1-3 % slower: profiles/r03_conv_exp.txt)
 #endif
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
   // LDS-DMA of the weight tiles as buffer loads: a lane's byte offset inside its plane (row n0 + row, source k-group of
   // its destination slot) is constant, the (chunk, tap) position is the scalar offset -- no 64-bit per-lane pointers
   // (they were what the 16-wave instances spilled to scratch), no per-tap address arithmetic
-  static_assert(!GL || BSEG <= 2, "the LDS-DMA path keeps at most two descriptors");
+  static_assert(!GL || BSEG <= 4, "the LDS-DMA path keeps at most four descriptors");
   unsigned boff[BSEG > 0 ? BSEG : 1];
 #pragma unroll
   for (int i = 0; i < BSEG; ++i) {
@@ -252,6 +255,10 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
       uniform_rsrc_v2(reinterpret_cast<const float*>((tid / (BN * 4)) ? wl : wh), 0x7ffffff0);
   const __amdgpu_buffer_rsrc_t b_src1 =
       uniform_rsrc_v2(reinterpret_cast<const float*>(((tid + NT) / (BN * 4)) ? wl : wh), 0x7ffffff0);
+  const __amdgpu_buffer_rsrc_t b_src2 =
+      uniform_rsrc_v2(reinterpret_cast<const float*>(((tid + 2 * NT) / (BN * 4)) ? wl : wh), 0x7ffffff0);
+  const __amdgpu_buffer_rsrc_t b_src3 =
+      uniform_rsrc_v2(reinterpret_cast<const float*>(((tid + 3 * NT) / (BN * 4)) ? wl : wh), 0x7ffffff0);
   auto issue_b = [&](int cc, int grp, int buf) {
 #pragma unroll
     for (int tt = 0; tt < TPB; ++tt) {
@@ -263,7 +270,8 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
         const int plane = slot / (BN * 4);
         const int rem = slot - plane * BN * 4;
         __bf16* dst = Bs + (((buf * TPB + tt) * 2 + plane) * BN) * 32 + (rem - lane) * 8;  // the wave's first slot
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(i == 0 ? b_src0 : b_src1, (v2_lds_ptr)dst, 16, (int)boff[i], soff, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(i == 0 ? b_src0 : i == 1 ? b_src1 : i == 2 ? b_src2 : b_src3, (v2_lds_ptr)dst, 16,
+                                                 (int)boff[i], soff, 0, 0);
       }
     }
   };
@@ -372,6 +380,64 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
   };
   auto no_mid = []() {};
 
+  // 8-wave LDS-DMA instance (two waves per SIMD, 64 px x 128 ch per wave): the patch fragments of the NEXT tap are read
+  // behind the last channel tile's MFMAs, in front of the barrier -- the patch does not change inside a chunk, only the
+  // weight fragments have to wait for the barrier.  With two waves per SIMD nothing else hides those eight reads.
+  constexpr bool PFA = GL && NT == 512 && TPB == 1 && EXP == 0 && SCAN_CONV_PFA;
+  bf16x8 nph[TM], npl[TM];
+  auto patch_off = [&](int tap) {
+    const int ky = tap / KS, kx = tap - KS * ky;
+    const int pxs = lr + kx;
+    return ((wm * TM + ky) * PWK + pxs) * 32 + ((kg ^ swz(pxs)) << 3);
+  };
+  auto taps_mma_pf = [&](int grp, int buf, auto&& mid) {
+    const __bf16* bh = Bs + (buf * 2 + 0) * BN * 32 + w_off;
+    const __bf16* bl = Bs + (buf * 2 + 1) * BN * 32 + w_off;
+    if (grp == 0) {  // first tap of a chunk: the patch was stored just now
+      const int p_off = patch_off(0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        nph[tm] = *reinterpret_cast<const bf16x8*>(Ah + p_off + tm * PWK * 32);
+        npl[tm] = *reinterpret_cast<const bf16x8*>(Al + p_off + tm * PWK * 32);
+      }
+    }
+#pragma unroll
+    for (int tn = 0; tn < TN - 1; ++tn) {
+      const bf16x8 whv = *reinterpret_cast<const bf16x8*>(bh + tn * 16 * 32);
+      const bf16x8 wlv = *reinterpret_cast<const bf16x8*>(bl + tn * 16 * 32);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, npl[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlv, nph[tm], acc[tm][tn], 0, 0, 0);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, nph[tm], acc[tm][tn], 0, 0, 0);
+      if (tn == SCAN_CONV_MID) {
+        __builtin_amdgcn_sched_barrier(0);
+        mid();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    {
+      constexpr int tn = TN - 1;
+      const bf16x8 whv = *reinterpret_cast<const bf16x8*>(bh + tn * 16 * 32);
+      const bf16x8 wlv = *reinterpret_cast<const bf16x8*>(bl + tn * 16 * 32);
+      const bool more = grp < NGRP - 1;
+      const int p_off = patch_off(more ? grp + 1 : grp);
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, npl[tm], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlv, nph[tm], acc[tm][tn], 0, 0, 0);
+        acc[tm][tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whv, nph[tm], acc[tm][tn], 0, 0, 0);
+        // unconditional (the last tap of a chunk re-reads its own fragments, unused): no branch between the MFMAs
+        nph[tm] = *reinterpret_cast<const bf16x8*>(Ah + p_off + tm * PWK * 32);
+        npl[tm] = *reinterpret_cast<const bf16x8*>(Al + p_off + tm * PWK * 32);
+      }
+    }
+  };
+
   load_a(0);
   if constexpr (GL) {
     issue_b(0, 0, 0);
@@ -399,6 +465,8 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
         };
         if (FROZEN) {
           taps_mma(0, buf, no_mid);
+        } else if constexpr (PFA) {
+          taps_mma_pf(grp, buf, feed);
         } else if (SCAN_CONV_MID >= 0 && EXP == 0) {
           taps_mma(grp, buf, feed);
         } else {
@@ -483,7 +551,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
                     : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
-    float gs = 0.f, gq = 0.f;
+    double ds = 0.0, dq = 0.0;  // fp32 over a pixel's four channels, fp64 from there on: the same for every instance
 #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int y = ty0 + wm * TM + tm;
@@ -503,14 +571,13 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_bf16x3_v2_kernel(
           o.w = (mk[tm].w > 0.f) ? o.w : 0.f;
         }
         *reinterpret_cast<float4*>(dst + (rowbase + (int64_t)y * W + x) * Ns + o4) = o;
-        gs += (o.x + o.y) + (o.z + o.w);
-        gq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+        ds += (double)((o.x + o.y) + (o.z + o.w));
+        dq += (double)((o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w));
       }
     }
     if (gn_ws != nullptr) {
       // GroupNorm(32) sums of the 256-channel output: a group = 8 channels = the lane-group pair kg, kg ^ 1; reduce
       // over the 16 pixels (lanes) and that pair, one fp64 atomic pair per group and wave
-      double ds = (double)gs, dq = (double)gq;
 #pragma unroll
       for (int sh = 1; sh <= 16; sh <<= 1) {
         ds += __shfl_xor(ds, sh, 64);
@@ -578,6 +645,9 @@ extern int g_scan_conv_bn256;
 // (profiles/r02_conv_instances.txt): tower layer over P3..P7 603 -> 554 us (+8 %: the small levels' partial tiles
 // leave 8-wave workgroups short of work to hide latency), single-level layers +1...3 %, none slower.
 int g_scan_conv_wg1024 = 1;
+// scan_tune "conv_w8": 1 = the 256-channel LDS-DMA instance runs as 8 waves (two per SIMD, 64 px x 128 ch per wave, up to 256
+// registers: 24 fragment reads per 96 MFMAs instead of 20 per 48) instead of 16; numbers in profiles/r03_conv_exp.txt
+int g_scan_conv_w8 = 1;
 // scan_tune "conv_tpb3": stage the three taps of a ky row per barrier (4 barriers per 32-channel chunk instead of 10)
 // -- bit 0 (default on): the 128-channel 3x3 instance, bit 1: the 64-channel one (196 instead of 140 registers: two
 // instead of three workgroups per CU).  Register-staged it measured +-1 % on every layer
@@ -622,7 +692,9 @@ int conv3x3_bf16x3_v2_launch(const float* x, const scan_pyramid_t* d, int32_t Cs
         launch_v2<64, 8, 256, 3>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
       break;
     case 256:
-      if ((g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1)) && g_scan_conv_glds && Csw % 32 == 0 &&
+      if (g_scan_conv_w8 && g_scan_conv_wg1024 == 1 && g_scan_conv_glds && g_scan_conv_exp == 0 && Csw % 32 == 0 && Nout % 256 == 0)
+        launch_v2<256, 16, 512, 3, 1, true>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0);
+      else if ((g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1)) && g_scan_conv_glds && Csw % 32 == 0 &&
           Nout % 256 == 0)
         switch (g_scan_conv_exp) {
           case 1: launch_v2<256, 16, 1024, 3, 1, true, 1>(x, d, Cs, h, l, Csw, bias, mask, y, Nout, Ns, relu, st, gn_ws, d, 0); break;
@@ -670,10 +742,12 @@ int conv1x1_bf16x3_v2_launch(const float* x, const scan_pyramid_t* xd, int32_t C
 }
 
 // which instance a 3x3 launch on pyramid d with Nout output channels takes (bench.py labels its timings with it)
-// 64 / 128 / 256, or 1128 / 1256 for the 128- / 256-channel tile run by 16-wave (1024-thread) workgroups
+// 64 / 128 / 256, or 1128 / 1256 for the 128- / 256-channel tile run by 16-wave (1024-thread) workgroups, 2256 for the
+// 256-channel tile on the 8-wave LDS-DMA instance (Csw % 32 == 0 assumed: true for every 3x3 plane ops.py splits)
 extern "C" int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout) {
   if (!d) return -1;
   const int bn = v2_instance(d, Nout);
+  if (bn == 256 && g_scan_conv_w8 && g_scan_conv_wg1024 == 1 && g_scan_conv_glds) return 2256;
   if (bn == 256 && (g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1))) return 1256;
   if (bn == 128 && g_scan_conv_wg1024 == 1) return 1128;
   return bn;

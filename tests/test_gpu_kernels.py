@@ -346,7 +346,7 @@ def test_conv_16_wave_instance_on_pyramid(device):
     bit-identical results."""
     from scan_amd import _lib, ops
     pyr = ops.PyramidShape(4, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)])
-    assert _lib.query("scan_conv3x3_bf16x3_instance", pyr.ref(), 256) == 1256
+    assert _lib.query("scan_conv3x3_bf16x3_instance", pyr.ref(), 256) == (2256 if _lib.query("scan_tune_get", b"conv_w8") else 1256)
     assert _lib.query("scan_conv3x3_bf16x3_instance", ops.PyramidShape(2, [(64, 64)]).ref(), 256) == 1128
     torch.manual_seed(5)
     x = torch.randn(pyr.rows, 256, device=device)
@@ -360,6 +360,14 @@ def test_conv_16_wave_instance_on_pyramid(device):
         finally:
             _lib.query("scan_tune", b"conv_wg1024", old)
         assert torch.equal(y16, y8)
+        for w8 in (0, 1):  # the 256-channel LDS-DMA tile on 16 waves / on 8 waves
+            old = _lib.query("scan_tune", b"conv_w8", w8)
+            try:
+                assert _lib.query("scan_conv3x3_bf16x3_instance", pyr.ref(), 256) == (2256 if w8 else 1256)
+                yw = ops.conv2d(x, w, b, pyr, 3, 1, relu=True)
+            finally:
+                _lib.query("scan_tune", b"conv_w8", old)
+            assert torch.equal(y16, yw), w8
         w128 = w[:128].contiguous(memory_format=torch.channels_last)
         ya = ops.conv2d(x, w128, b[:128], pyr, 3, 1)
         old = _lib.query("scan_tune", b"conv_tpb3", 3)

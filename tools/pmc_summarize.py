@@ -16,6 +16,7 @@ import sys
 
 GROUPS = [  # (substring of the kernel name, group key); conv keys = the symbols bench.py's roofline names
     ("conv_bf16x3_v2_kernelILi256ELi16ELi1024ELi3", "conv_bf16x3_v2_kernel<256,16,1024,3>"),
+    ("conv_bf16x3_v2_kernelILi256ELi16ELi512ELi3ELi1ELb1E", "conv_bf16x3_v2_kernel<256,16,512,3,1,true>"),
     ("conv_bf16x3_v2_kernelILi256ELi16ELi512ELi3", "conv_bf16x3_v2_kernel<256,16,512,3>"),
     ("conv_bf16x3_v2_kernelILi128ELi16ELi1024ELi3", "conv_bf16x3_v2_kernel<128,16,1024,3>"),
     ("conv_bf16x3_v2_kernelILi128ELi16ELi512ELi3", "conv_bf16x3_v2_kernel<128,16,512,3>"),

@@ -428,7 +428,7 @@ def main():
         n_inf = max(3, a.steps)
         t0i = time.time()
         for _ in range(n_inf):
-            dets = engine.inference(model, frames)
+            dets = engine.inference(model, frames, static_weights=True)  # a dataset loop: nothing trains between batches
         torch.cuda.synchronize()
         dti = (time.time() - t0i) / n_inf
         nms_rec = fcos_mod.last_nms_record()

@@ -790,11 +790,18 @@ class Trainer:
 
 
 @torch.no_grad()
-def inference(model, images):
-    """reference engine/inference.py:15-37 on one batch: list of (boxes, scores, labels) per image."""
+def inference(model, images, static_weights=False):
+    """reference engine/inference.py:15-37 on one batch: list of (boxes, scores, labels) per image.
+
+    static_weights=True is the caller's promise that no parameter changed since the previous inference() call (a
+    dataset loop, serving): the bf16 weight planes split in that call are reused instead of being split again (31
+    launches per batch).  Anything that updates parameters through this package (optimizer step, checkpoint /
+    state-dict load) drops the planes regardless, so the flag only matters for writes from outside."""
     for m in model.values():
         m.eval()
-    ops.invalidate_weight_planes()  # weights may have been updated / loaded since the planes were cached
+    if not (static_weights and ops.SPLIT_EPOCH is not None):
+        ops.invalidate_weight_planes()  # weights may have been updated / loaded since the planes were cached
+        ops.begin_weight_epoch()
     return forward_detector(model, images, None)
 
 
@@ -807,8 +814,8 @@ def inference_distributed(model, batches):
     from . import comm
     results, ids = [], []
     dev = next(next(iter(model.values())).parameters()).device
-    for images, image_ids in batches:
-        out = inference(model, images)
+    for k, (images, image_ids) in enumerate(batches):
+        out = inference(model, images, static_weights=k > 0)  # nothing trains between the batches of one pass
         results.extend(out)
         ids.extend(int(i) for i in image_ids)
     merged = comm.gather_detections(results, ids, device=dev)
@@ -833,7 +840,7 @@ def validation(model, dataset, batch_size=4, size_divisible=32, output_folder=No
     results, ids = [], []
     for k in range(0, len(mine), batch_size):
         il, _, idxs = collate([dataset[i] for i in mine[k:k + batch_size]])
-        for (boxes, scores, labels), (h, w), idx in zip(inference(model, il), il.image_sizes, idxs):
+        for (boxes, scores, labels), (h, w), idx in zip(inference(model, il, static_weights=k > 0), il.image_sizes, idxs):
             info = dataset.get_img_info(idx)
             boxes = datasets.resize_detections(boxes, (w, h), (info["width"], info["height"]))
             results.append((boxes, scores, labels))

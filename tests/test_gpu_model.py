@@ -203,6 +203,21 @@ def test_inference_after_training_uses_fresh_weights(device):
     for (b1, s1, l1), (b2, s2, l2) in zip(after, again):
         assert torch.equal(b1, b2) and torch.equal(s1, s2) and torch.equal(l1, l2)
     assert any(len(s0) != len(s1) or not torch.allclose(s0, s1) for (_, s0, _), (_, s1, _) in zip(before, after))
+    # static_weights=True: the planes of the previous inference call are served (no split launches), same detections;
+    # a training step in between drops them whatever the flag says
+    n_cached = len(ops._split_cache)
+    assert n_cached > 0 and ops.SPLIT_EPOCH is not None
+    epoch = ops.SPLIT_EPOCH
+    reuse = engine.inference(model, imgs, static_weights=True)
+    assert ops.SPLIT_EPOCH == epoch and len(ops._split_cache) == n_cached
+    for (b1, s1, l1), (b2, s2, l2) in zip(again, reuse):
+        assert torch.equal(b1, b2) and torch.equal(s1, s2) and torch.equal(l1, l2)
+    trainer.step(synth.synth_images(2, 128, 256, 5).to(device), synth.synth_targets(2, 128, 256, 8, 12, 6),
+                 synth.synth_images(2, 128, 256, 7).to(device))
+    stepped = engine.inference(model, imgs, static_weights=True)
+    fresh = engine.inference(model, imgs)
+    for (b1, s1, l1), (b2, s2, l2) in zip(stepped, fresh):
+        assert torch.equal(b1, b2) and torch.equal(s1, s2) and torch.equal(l1, l2)
 
 
 @pytest.mark.parametrize("conv_mode", ["fp32", "bf16x3"])

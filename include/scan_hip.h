@@ -74,6 +74,10 @@ int scan_abi_version(void);
  *   "wgrad_v6"    1 (default): the 3x3 launches take the producer / consumer sixth generation (12 waves: 8 issue MFMAs, 4
  *                 stage; bit-identical to "wgrad_v4"); "wgrad_prio" 1 (default): its producer waves run at s_setprio 3.
  *   "conv_exp"    1..4: timing ablations of the 256-channel forward instance (WRONG results; profiles/r03_conv_exp.txt).
+ *   "conv_w8"     1 (default): the 256-channel LDS-DMA forward / dgrad tile runs on 8 waves (64 px x 128 ch per wave); 0: 16
+ *                 waves.  Same results bit for bit.
+ *   "dbscan_bf16x3" 1 (default): scan_dbscan_prepare's pairwise-distance GEMM runs as bf16x3 with a wider exact re-check
+ *                 band; 0: exact fp32 matrix cores.  Same neighbour bits (pairs inside the band are decided in fp64).
  *   "wgrad_exp"   1..4: timing ablations of the second-generation kernel, 5..7 of the sixth (WRONG results;
  *                 profiles/r03_wgrad_exp.txt, r03_wgrad_v6_exp.txt).
  *   "conv_glds"   1 (default): the 16-wave 128- / 256-channel 3x3 instances stage weight tiles by LDS-DMA

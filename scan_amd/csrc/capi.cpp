@@ -23,6 +23,7 @@ extern int g_scan_conv_v2;
 extern int g_scan_wgrad_v2;
 extern int g_scan_conv_wg1024;
 extern int g_scan_conv_w8;
+extern int g_scan_dbscan_bf16x3;
 extern int g_scan_conv_tpb3;
 extern int g_scan_wgrad_wg1024;
 extern int g_scan_wgrad_v3;
@@ -45,6 +46,7 @@ static int* tune_slot(const char* key) {
   if (strcmp(key, "wgrad_v2") == 0) slot = &g_scan_wgrad_v2;
   if (strcmp(key, "conv_wg1024") == 0) slot = &g_scan_conv_wg1024;
   if (strcmp(key, "conv_w8") == 0) slot = &g_scan_conv_w8;
+  if (strcmp(key, "dbscan_bf16x3") == 0) slot = &g_scan_dbscan_bf16x3;
   if (strcmp(key, "conv_tpb3") == 0) slot = &g_scan_conv_tpb3;
   if (strcmp(key, "wgrad_wg1024") == 0) slot = &g_scan_wgrad_wg1024;
   if (strcmp(key, "wgrad_v3") == 0) slot = &g_scan_wgrad_v3;

@@ -7,7 +7,9 @@
 // cluster that reaches it.  Hence cluster 0 = the connected component (over core-core eps links) of the lowest-index
 // core point, plus every non-core point within eps of one of its core points -- no other cluster matters.
 //
-//   1. neighbours   tiled P P^T on the fp32 matrix cores (v_mfma_f32_32x32x2_f32), d2 = |p_i|^2 + |p_j|^2 - 2 p_i.p_j
+//   1. neighbours   tiled P P^T on the matrix cores -- bf16x3 (operands split hi + lo bf16, three v_mfma_f32_32x32x16_bf16
+//                   per product, the convolutions' arithmetic; scan_tune "dbscan_bf16x3", default) or exact fp32
+//                   (v_mfma_f32_32x32x2_f32) --, d2 = |p_i|^2 + |p_j|^2 - 2 p_i.p_j
 //                   thresholded at eps^2; pairs whose fp32 value lies within the rounding band of the threshold are
 //                   recomputed as sum (a - b)^2 in fp64 (sklearn's brute-force radius query decides in fp64).  The
 //                   adjacency is kept as a bit matrix (n^2 / 8 bytes in HBM) built with wave ballots; row popcounts
@@ -39,11 +41,30 @@ __global__ __launch_bounds__(256) void dbscan_sqnorm_kernel(const float* __restr
   if (lane == 0) sq[row] = s;
 }
 
+typedef __bf16 db_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 db_bf16x4 __attribute__((ext_vector_type(4)));
+#define DB_LDH 40  // bf16 row pitch of the split planes: 32 + 8, rows stay 16-byte aligned
+
+// hi = bf16(x), lo = bf16(x - hi): the split of the convolution kernels (conv_bf16x3_v2.hip)
+__device__ __forceinline__ void db_split4(const float4 v, db_bf16x4& hi, db_bf16x4& lo) {
+  hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
+  lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
+  lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
+}
+
+template <bool BF>
 __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __restrict__ p, int64_t n, int D,
                                                                const double* __restrict__ sq, double eps2,
                                                                uint32_t* __restrict__ bits, int64_t nw) {
-  __shared__ float As[DB_T * DB_LD];
-  __shared__ float Bs[DB_T * DB_LD];
+  // fp32: As / Bs [128][36] floats; bf16x3: four planes (A hi, A lo, B hi, B lo) [128][40] bf16 in the same bytes
+  constexpr int F32_FLOATS = 2 * DB_T * DB_LD, BF_FLOATS = 4 * DB_T * DB_LDH / 2;
+  __shared__ __align__(16) float smem[BF && BF_FLOATS > F32_FLOATS ? BF_FLOATS : F32_FLOATS];
+  float* As = smem;
+  float* Bs = smem + DB_T * DB_LD;
+  __bf16* Ah = reinterpret_cast<__bf16*>(smem);
+  __bf16* Al = Ah + DB_T * DB_LDH;
+  __bf16* Bh = Al + DB_T * DB_LDH;
+  __bf16* Bl = Bh + DB_T * DB_LDH;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   // the relation is symmetric: only tiles on or above the diagonal are computed, each writes its bits in both
   // orientations (row words by wave ballot, column words from the lane's own 16 accumulator rows)
@@ -78,6 +99,43 @@ __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __re
   fetch(0);
   for (int k0 = 0; k0 < D; k0 += DB_K) {
     __syncthreads();
+    if constexpr (BF) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = r0 + 32 * i;
+        db_bf16x4 h, l;
+        db_split4(ra[i], h, l);
+        *reinterpret_cast<db_bf16x4*>(Ah + r * DB_LDH + 4 * c4) = h;
+        *reinterpret_cast<db_bf16x4*>(Al + r * DB_LDH + 4 * c4) = l;
+        db_split4(rb[i], h, l);
+        *reinterpret_cast<db_bf16x4*>(Bh + r * DB_LDH + 4 * c4) = h;
+        *reinterpret_cast<db_bf16x4*>(Bl + r * DB_LDH + 4 * c4) = l;
+      }
+      if (k0 + DB_K < D) fetch(k0 + DB_K);
+      __syncthreads();
+      // 32x32x16: lane l holds row l & 31, k = 8 (l >> 5) .. + 7 of a 16-wide k step
+      const int fo = (wm * 64 + lrow) * DB_LDH + 8 * lh, go = (wn * 64 + lrow) * DB_LDH + 8 * lh;
+#pragma unroll
+      for (int ks = 0; ks < DB_K / 16; ++ks) {
+        db_bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          ah[t] = *reinterpret_cast<const db_bf16x8*>(Ah + fo + t * 32 * DB_LDH + 16 * ks);
+          al[t] = *reinterpret_cast<const db_bf16x8*>(Al + fo + t * 32 * DB_LDH + 16 * ks);
+          bh[t] = *reinterpret_cast<const db_bf16x8*>(Bh + go + t * 32 * DB_LDH + 16 * ks);
+          bl[t] = *reinterpret_cast<const db_bf16x8*>(Bl + go + t * 32 * DB_LDH + 16 * ks);
+        }
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+          for (int tn = 0; tn < 2; ++tn) {
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+            acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
+          }
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int r = r0 + 32 * i;
@@ -109,10 +167,23 @@ __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __re
   }
 
   // C/D map of 32x32: col = lane & 31 (j), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (i)
+  // The threshold test runs in fp32 (one subtract, two FMAs, two compares per pair -- in fp64 this epilogue cost more than
+  // the bf16x3 GEMM in front of it); what fp32 adds to the rounding band is 3 * 2^-24 (si + sj) + 2^-24 eps2, far inside
+  // the margin the band constants carry.  Squared norms of the tile's rows / columns as floats, through LDS.
+  __syncthreads();
+  float* sqa = smem;            // [128] rows i0 ..
+  float* sqb = smem + DB_T;     // [128] columns j0 ..
+  if (tid < DB_T) {
+    sqa[tid] = i0 + tid < n ? (float)sq[i0 + tid] : 0.f;
+    sqb[tid] = j0 + tid < n ? (float)sq[j0 + tid] : 0.f;
+  }
+  __syncthreads();
+  const float eps2f = (float)eps2;
+  const float bandc = BF ? 5.9e-5f : 1.7e-5f;
 #pragma unroll
   for (int tn = 0; tn < 2; ++tn) {
     const int64_t j = j0 + (wn * 2 + tn) * 32 + lrow;
-    const double sj = j < n ? sq[j] : 0.0;
+    const float sjf = sqb[(wn * 2 + tn) * 32 + lrow];
     const int64_t jw = (j0 + (wn * 2 + tn) * 32) >> 5;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm) {
@@ -122,16 +193,16 @@ __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __re
         const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
         const int64_t i = i0 + (wm * 2 + tm) * 32 + rr;
         const bool valid = i < n && j < n;
-        double d2 = 0.0;
-        bool inband = false;
-        if (valid) {
-          const double si = sq[i];
-          d2 = si + sj - 2.0 * (double)acc[tm][tn][r];
-          // worst-case fp32 accumulation error of the 256-term dot product: (K - 1) 2^-24 sum |a_k b_k|
-          // <= 1.53e-5 (si + sj) / 2, doubled by the factor 2 in front of it
-          const double band = 1.6e-5 * (si + sj) + 1e-9;
-          inband = fabs(d2 - eps2) <= band;
-        }
+        const float ssum = sqa[(wm * 2 + tm) * 32 + rr] + sjf;
+        // d2 - eps2 in fp32.  Band: worst-case fp32 accumulation error of the 256-term dot product, (K - 1) 2^-24
+        // sum |a_k b_k| <= 1.53e-5 (si + sj) / 2, doubled by the factor 2 in front of it.  bf16x3: with a = ah + al + da,
+        // |da| <= 2^-18 |a| (two round-to-nearest bf16 steps), the dropped part of a product is al bl + da b + a db,
+        // <= 3 * 2^-18 |a b| = 1.15e-5 |a b|; the products kept are exact in fp32 and there are three times as many
+        // of them to add up, (3 K - 1) 2^-24 = 4.6e-5 in the same worst-case count: 5.8e-5 (si + sj) on d2
+        const float t = __builtin_fmaf(-2.0f, acc[tm][tn][r], ssum - eps2f);
+        const float band = __builtin_fmaf(bandc, ssum, 1e-6f * eps2f + 1e-9f);
+        const bool inband = valid && fabsf(t) <= band;
+        bool pred = valid && t <= 0.f;
         // pairs inside the rounding band are decided in fp64 from the points themselves -- by the WHOLE wave, one
         // pair at a time (coalesced reads of both rows, butterfly sum): a lane looping over D on its own while 63
         // others wait made dense point sets (many pairs near eps) ~100x slower than the GEMM itself
@@ -148,9 +219,8 @@ __global__ __launch_bounds__(256) void dbscan_neighbors_kernel(const float* __re
           }
 #pragma unroll
           for (int o = 32; o > 0; o >>= 1) e += __shfl_xor(e, o, 64);
-          if (lane == src) d2 = e;
+          if (lane == src) pred = e <= eps2;
         }
-        const bool pred = valid && d2 <= eps2;
         colbits |= pred ? (1u << rr) : 0u;
         const unsigned long long m = __ballot(pred);
         // lanes 0..31 hold row i(lh = 0), lanes 32..63 row i + 4
@@ -281,6 +351,10 @@ static DbWs db_split(void* ws, int64_t n) {
 }
 
 // steps 1-2 and the seed of step 3.  info (device, int32[2]) <- {lowest core index or n if there is none, 0}
+// scan_tune "dbscan_bf16x3": 1 (default) = the pairwise-distance GEMM runs as bf16x3 (three bf16 MFMAs per product) with the
+// wider exact re-check band; 0 = exact fp32 MFMA.  Same neighbour bits either way (the band decides in fp64).
+int g_scan_dbscan_bf16x3 = 1;
+
 extern "C" int scan_dbscan_prepare(const float* pts, int64_t n, int32_t D, float eps, int32_t min_samples, void* ws,
                                    int32_t* info, void* stream) {
   SCAN_CHECK_ARG(pts && ws && info, "dbscan_prepare: null pointer");
@@ -297,8 +371,12 @@ extern "C" int scan_dbscan_prepare(const float* pts, int64_t n, int32_t D, float
   hipLaunchKernelGGL(dbscan_init_kernel, dim3(1), dim3(1), 0, st, w.first_core, (int)n);
   hipLaunchKernelGGL(dbscan_sqnorm_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, pts, n, D, w.sq);
   const unsigned tiles = (unsigned)((n + DB_T - 1) / DB_T);
-  hipLaunchKernelGGL(dbscan_neighbors_kernel, dim3(tiles, tiles), dim3(256), 0, st, pts, n, D, w.sq,
-                     (double)eps * (double)eps, w.bits, w.nw);
+  if (g_scan_dbscan_bf16x3)
+    hipLaunchKernelGGL(dbscan_neighbors_kernel<true>, dim3(tiles, tiles), dim3(256), 0, st, pts, n, D, w.sq,
+                       (double)eps * (double)eps, w.bits, w.nw);
+  else
+    hipLaunchKernelGGL(dbscan_neighbors_kernel<false>, dim3(tiles, tiles), dim3(256), 0, st, pts, n, D, w.sq,
+                       (double)eps * (double)eps, w.bits, w.nw);
   hipLaunchKernelGGL(dbscan_core_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, w.bits, n, w.nw, min_samples,
                      w.counts, w.core, w.first_core);
   hipLaunchKernelGGL(dbscan_seed_kernel, dim3(1), dim3(1), 0, st, w.first_core, n, w.visited, w.fa);

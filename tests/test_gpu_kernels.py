@@ -609,11 +609,13 @@ def _sk_in0(pts, eps, min_samples=5):
     return cluster.DBSCAN(eps=eps, min_samples=min_samples).fit_predict(pts) == 0
 
 
+@pytest.mark.parametrize("gemm", ["bf16x3", "fp32"])
 @pytest.mark.parametrize("case", ["blobs", "chain", "all_noise", "one_blob", "duplicates", "ragged_n", "borders"])
-def test_dbscan_cluster0_matches_sklearn(device, case):
+def test_dbscan_cluster0_matches_sklearn(device, case, gemm):
     """scan_dbscan_* against sklearn.cluster.DBSCAN labels: membership of cluster 0 (all the reference's selection uses,
-    rpn/fcos/loss.py:417-421) must be identical point by point."""
-    from scan_amd import ops
+    rpn/fcos/loss.py:417-421) must be identical point by point -- with the pairwise-distance GEMM on the bf16x3 path (the
+    default) and on the exact fp32 matrix cores; pairs inside the rounding band of either are decided in fp64."""
+    from scan_amd import _lib, ops
     import zlib
     rs = np.random.RandomState(zlib.crc32(case.encode()) % 100000)
     D, eps = 256, 3.0
@@ -648,7 +650,11 @@ def test_dbscan_cluster0_matches_sklearn(device, case):
         pts = np.concatenate([ring[:30], a, mid, b, ring[30:] + np.eye(1, D)[0] * 5.0])
     pts = pts.astype(np.float32)
     ref = _sk_in0(pts, eps)
-    got = ops.dbscan_in_cluster0(torch.from_numpy(pts).to(device), eps, 5).cpu().numpy()
+    old = _lib.query("scan_tune", b"dbscan_bf16x3", 1 if gemm == "bf16x3" else 0)
+    try:
+        got = ops.dbscan_in_cluster0(torch.from_numpy(pts).to(device), eps, 5).cpu().numpy()
+    finally:
+        _lib.query("scan_tune", b"dbscan_bf16x3", old)
     assert got.shape == ref.shape
     assert np.array_equal(got, ref), "cluster-0 membership differs at %d of %d points" % ((got != ref).sum(), len(ref))
 

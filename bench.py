@@ -311,8 +311,10 @@ def main():
         if flag:
             trainer._saved_dis = trainer.dis_streams
             trainer.dis_streams = {}
+            model["middle_head"].out_stream = None
         elif hasattr(trainer, "_saved_dis"):
             trainer.dis_streams = trainer._saved_dis
+            model["middle_head"].out_stream = trainer.out_stream
 
     if a.serial_streams:
         set_serial(True)

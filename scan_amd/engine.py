@@ -360,6 +360,10 @@ class Trainer:
         pool = [torch.cuda.Stream() for _ in range(n_side)] if on_gpu else []
         self.dis_streams = {lvl: pool[i % n_side] for i, lvl in enumerate(("P4", "P5", "P6", "P7"))} if on_gpu else {}
         self.tgt_stream = torch.cuda.Stream() if on_gpu else None
+        # head_out's feature share (97 % of that conv) beside the graph tier's tiny launches, forward and backward
+        self.out_stream = torch.cuda.Stream() if on_gpu and os.environ.get("SCAN_OUT_STREAM", "1") != "0" else None
+        if "middle_head" in model and hasattr(model["middle_head"], "out_stream"):
+            model["middle_head"].out_stream = self.out_stream
         self.overlap_target = True
         self.merge_source_backward = True
         # source and target frames as ONE batch through backbone / middle head / discriminators and one backward
@@ -397,6 +401,8 @@ class Trainer:
                 self.comm_stream.wait_stream(s)
             if self.tgt_stream is not None:
                 self.comm_stream.wait_stream(self.tgt_stream)
+            if self.out_stream is not None:
+                self.comm_stream.wait_stream(self.out_stream)
         with torch.cuda.stream(self.comm_stream):
             g = self.grad_arena[lo:hi]
             g.div_(ws)
@@ -518,6 +524,8 @@ class Trainer:
             main.wait_stream(s)
         if self.tgt_stream is not None:
             main.wait_stream(self.tgt_stream)
+        if self.out_stream is not None:
+            main.wait_stream(self.out_stream)
 
     def _optimizer_step(self):
         """optimizer.step() + scheduler.step() of every sub-model (reference engine/trainer.py:418-424)."""

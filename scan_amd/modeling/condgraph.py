@@ -194,6 +194,7 @@ class GRAPHModule(nn.Module):
         self.register_buffer("prototype", torch.randn(K, 256, proto_iter))
         self.head_out = GRAPHHead(in_channels + K, in_channels, 1, mode="out")
         self.cat_stride = ops.pad4(in_channels + K)
+        self.out_stream = None  # engine.Trainer: the stream head_out's feature share runs on beside the graph tier
         self.act_loss_func = FocalLoss(K)
         self.proto_cls_hidden = nn.Linear(256, 512)
         self.proto_cls = nn.Linear(512, K)
@@ -255,8 +256,33 @@ class GRAPHModule(nn.Module):
         return F.linear(x, w, self.cond_nx1.bias)
 
     # ---- HIP tier ----
-    def _act_and_out(self, feats, shape, kernels):
+    def _out_features(self, feats, shape):
+        """head_out's share of the 256 feature channels (ops.HEAD_OUT_SPLIT): conv(cat(feats, maps)) = conv(feats; W[:, :256])
+        + conv(maps; W[:, 256:]), and the first -- 97 % of the layer -- does not wait for the graph tier (node sampling,
+        GCN, attention, paradigm RNN: a few hundred tiny launches with the GPU nearly idle).  With ``out_stream`` set (by
+        engine.Trainer) it runs on that stream BESIDE the graph tier, and so do its data and weight gradients in the
+        backward; the 265-channel input the kernels handled badly (a third, almost empty 128-wide channel tile in the data
+        gradient, the old weight-gradient kernel) becomes 256 clean channels.  Returns None when the split is off."""
+        if not ops.HEAD_OUT_SPLIT or self.head_out.num_convs != 1:
+            return None
+        conv = self.head_out.middle_tower[0]
+        C = feats.shape[1]
+        if self.out_stream is None:
+            return ops.conv2d(feats, conv.weight[:, :C], conv.bias, shape, 3, 1)
+        self.out_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.out_stream):
+            return ops.conv2d(feats, conv.weight[:, :C], conv.bias, shape, 3, 1)
+
+    def _act_and_out(self, feats, shape, kernels, main=None):
         logits, maps = ops.dynconv_softmax(feats, kernels)
+        if main is not None:  # relu(feature share + act-map share): same sum as the one conv over the concatenation
+            conv = self.head_out.middle_tower[0]
+            C, K = feats.shape[1], maps.shape[1]
+            thin_in = maps if K % 4 == 0 else F.pad(maps, (0, ops.pad4(K) - K))
+            thin = ops.conv2d(thin_in, conv.weight[:, C:C + K], None, shape, 3, 1)
+            if self.out_stream is not None:
+                torch.cuda.current_stream().wait_stream(self.out_stream)
+            return logits, maps, ops.add_relu(main, thin)
         pad = self.cat_stride - feats.shape[1] - maps.shape[1]
         cat = torch.cat([feats, maps, feats.new_zeros(feats.shape[0], pad)], 1)
         return logits, maps, self.head_out(cat, shape)
@@ -278,8 +304,9 @@ class GRAPHModule(nn.Module):
     def _forward_train_target(self, feats, shape):
         """reference condgraph.py:500-534 (GCN_SELF_TRAINING False): act maps with the conditioned kernels (HIP),
         DBSCAN node sampling (host), graph aggregation + GST losses (torch tier)."""
+        main = self._out_features(feats, shape)
         kernels = self.get_conded_weight()
-        _, maps, out = self._act_and_out(feats, shape, kernels)
+        _, maps, out = self._act_and_out(feats, shape, kernels, main)
         pts, labs = sample_target_nodes(feats, maps, shape, self.dbscan_eps, self.dbscan_thr)
         if pts is not None and self.transfer_cfg and self.transfer_cfg[0] is not None:
             _, tg_proto = self._forward_gcns(pts, labs)
@@ -293,19 +320,21 @@ class GRAPHModule(nn.Module):
         """-> feats [M,256], (node_loss, transfer_loss) or None, act_loss or None, act_maps [M,K]."""
         feats = self.head_in(rows, shape)
         if self.training and targets and mode == "source":
+            main = self._out_features(feats, shape)
             plan = target_plan(shape, targets, rows.device)
             labels = plan.labels
             pts, labs = feats[plan.node_index], plan.node_labels
             node_loss, proto_batch = self._forward_gcns(pts, labs)
             self.update_prototype_nx1_rnn(proto_batch)
             kernels = self.get_conded_weight()
-            logits, maps, out = self._act_and_out(feats, shape, kernels)
+            logits, maps, out = self._act_and_out(feats, shape, kernels, main)
             act_loss = self.lamda2 * self.act_loss_func(logits, labels.long())
             return out, (node_loss, 0), act_loss, maps
         if self.training and mode == "target" and forward_target:
             return self._forward_train_target(feats, shape)
+        main = self._out_features(feats, shape)
         kernels = self.get_conded_weight()
-        _, maps, out = self._act_and_out(feats, shape, kernels)
+        _, maps, out = self._act_and_out(feats, shape, kernels, main)
         return out, None, None, maps
 
 
@@ -318,12 +347,13 @@ class GRAPHModule(nn.Module):
         aggregation and the GST losses (_forward_train_target).
         -> out [M,256], node_loss, act_loss, act_maps [M,K], consistency loss or None."""
         feats = self.head_in(rows, shape)
+        main = self._out_features(feats, shape)
         src, shape_src = ops.take_images(feats, shape, 0, n_src)
         plan = target_plan(shape_src, targets, rows.device)
         node_loss, proto_batch = self._forward_gcns(src[plan.node_index], plan.node_labels)
         self.update_prototype_nx1_rnn(proto_batch)
         kernels = self.get_conded_weight()
-        logits, maps, out = self._act_and_out(feats, shape, kernels)
+        logits, maps, out = self._act_and_out(feats, shape, kernels, main)
         act_loss = self.lamda2 * self.act_loss_func(ops.take_images(logits, shape, 0, n_src)[0], plan.labels.long())
         consistency = None
         if forward_target:

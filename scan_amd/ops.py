@@ -187,6 +187,9 @@ CAT_IN_PLACE = os.environ.get("SCAN_CAT_IN_PLACE", "1") != "0"
 # SCAN_FPN_DIRECT=0: the FPN output convs write tensors of their own that are concatenated afterwards, and the top-down
 # join is an up-sampling copy + add (torch), for A/B.  Same values.
 FPN_DIRECT = os.environ.get("SCAN_FPN_DIRECT", "1") != "0"
+# SCAN_HEAD_OUT_SPLIT=0: the middle head's output conv runs as ONE conv over cat(features, act maps) as in the reference,
+# instead of feature share + act-map share (modeling/condgraph.py: _out_features), for A/B.  Same sum, other rounding order.
+HEAD_OUT_SPLIT = os.environ.get("SCAN_HEAD_OUT_SPLIT", "1") != "0"
 SPLIT_EPOCH = None
 _split_cache = {}
 _epoch_counter = [0]

@@ -312,9 +312,11 @@ def main():
             trainer._saved_dis = trainer.dis_streams
             trainer.dis_streams = {}
             model["middle_head"].out_stream = None
+            ops.WGRAD_STREAM = None
         elif hasattr(trainer, "_saved_dis"):
             trainer.dis_streams = trainer._saved_dis
             model["middle_head"].out_stream = trainer.out_stream
+            ops.WGRAD_STREAM = trainer.wgrad_stream
 
     if a.serial_streams:
         set_serial(True)

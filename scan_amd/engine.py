@@ -364,6 +364,9 @@ class Trainer:
         self.out_stream = torch.cuda.Stream() if on_gpu and os.environ.get("SCAN_OUT_STREAM", "1") != "0" else None
         if "middle_head" in model and hasattr(model["middle_head"], "out_stream"):
             model["middle_head"].out_stream = self.out_stream
+        # weight gradients of flat-buffer parameters on a stream of their own (ops.WGRAD_STREAM)
+        self.wgrad_stream = torch.cuda.Stream() if on_gpu and os.environ.get("SCAN_WGRAD_STREAM", "0") != "0" else None
+        ops.WGRAD_STREAM = self.wgrad_stream
         self.overlap_target = True
         self.merge_source_backward = True
         # source and target frames as ONE batch through backbone / middle head / discriminators and one backward
@@ -403,6 +406,8 @@ class Trainer:
                 self.comm_stream.wait_stream(self.tgt_stream)
             if self.out_stream is not None:
                 self.comm_stream.wait_stream(self.out_stream)
+        if self.wgrad_stream is not None:  # a bucket declared final: its weight gradients may still sit on that stream
+            self.comm_stream.wait_stream(self.wgrad_stream)
         with torch.cuda.stream(self.comm_stream):
             g = self.grad_arena[lo:hi]
             g.div_(ws)
@@ -526,6 +531,8 @@ class Trainer:
             main.wait_stream(self.tgt_stream)
         if self.out_stream is not None:
             main.wait_stream(self.out_stream)
+        if self.wgrad_stream is not None:
+            main.wait_stream(self.wgrad_stream)
 
     def _optimizer_step(self):
         """optimizer.step() + scheduler.step() of every sub-model (reference engine/trainer.py:418-424)."""

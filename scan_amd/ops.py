@@ -9,6 +9,7 @@ Activations are "pyramids": a contiguous fp32 matrix [M, Cs] (rows = pixels in
 level-major / image / y / x order, Cs = channel stride, a multiple of 4) plus a
 ``PyramidShape`` describing how rows split into levels (see include/scan_hip.h).
 """
+import contextlib
 import ctypes
 import os
 import weakref
@@ -187,6 +188,11 @@ CAT_IN_PLACE = os.environ.get("SCAN_CAT_IN_PLACE", "1") != "0"
 # SCAN_FPN_DIRECT=0: the FPN output convs write tensors of their own that are concatenated afterwards, and the top-down
 # join is an up-sampling copy + add (torch), for A/B.  Same values.
 FPN_DIRECT = os.environ.get("SCAN_FPN_DIRECT", "1") != "0"
+# Stream the weight-gradient launches of flat-buffer parameters are queued on (engine.Trainer sets it; None = the stream
+# of the backward pass).  A weight gradient is a leaf of the backward graph -- nothing but the optimizer step (and the
+# gradient all-reduce) reads it -- so on a stream of its own it fills what the dependent chain leaves idle: the graph
+# tier's tiny launches, the tails of launches that are 1.4 waves of workgroups long.
+WGRAD_STREAM = None
 # SCAN_HEAD_OUT_SPLIT=0: the middle head's output conv runs as ONE conv over cat(features, act maps) as in the reference,
 # instead of feature share + act-map share (modeling/condgraph.py: _out_features), for A/B.  Same sum, other rounding order.
 HEAD_OUT_SPLIT = os.environ.get("SCAN_HEAD_OUT_SPLIT", "1") != "0"
@@ -446,17 +452,23 @@ class _Conv2d(torch.autograd.Function):
         direct_b = direct_w and ctx.bgrad_buf is not None
         db_done = False
         if ctx.needs_input_grad[1] and fast and ksize == 3:
-            ws = x.new_empty((query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),))
-            dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
-            ev = kernel_timer.begin("conv3x3_bf16x3_wgrad_g%d" % query("scan_conv_wgrad_bf16x3_generation", cs)
-                                    if kernel_timer.enabled else "", 2.0 * oshape.rows * cout * T * cin)
             want_db = has_bias and ctx.needs_input_grad[2]
-            if want_db:
-                db = ctx.bgrad_buf if direct_b else x.new_empty((cout,))
-                db_done = True
-            call("scan_conv3x3_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), cout, cout_s, _ptr(dwp),
-                 _ptr(db) if want_db else None, int(direct_w), _ptr(ws), st)
-            kernel_timer.end(ev)
+            side = WGRAD_STREAM if (direct_w and (direct_b or not want_db) and not kernel_timer.enabled) else None
+            if side is not None:  # in place into the flat gradient buffers, nothing returned to autograd: off the chain
+                side.wait_stream(torch.cuda.current_stream())
+                x.record_stream(side)
+                dy.record_stream(side)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                ws = x.new_empty((query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),))
+                dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
+                ev = kernel_timer.begin("conv3x3_bf16x3_wgrad_g%d" % query("scan_conv_wgrad_bf16x3_generation", cs)
+                                        if kernel_timer.enabled else "", 2.0 * oshape.rows * cout * T * cin)
+                if want_db:
+                    db = ctx.bgrad_buf if direct_b else x.new_empty((cout,))
+                    db_done = True
+                call("scan_conv3x3_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), cout, cout_s, _ptr(dwp),
+                     _ptr(db) if want_db else None, int(direct_w), _ptr(ws), _stream())
+                kernel_timer.end(ev)
             if want_db and direct_w and not direct_b:
                 raise RuntimeError("conv2d: flat weight gradient without a flat bias gradient")
             dw = None if direct_w else unpack_weight_grad(dwp, weight)

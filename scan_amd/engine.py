@@ -361,7 +361,9 @@ class Trainer:
         self.dis_streams = {lvl: pool[i % n_side] for i, lvl in enumerate(("P4", "P5", "P6", "P7"))} if on_gpu else {}
         self.tgt_stream = torch.cuda.Stream() if on_gpu else None
         # head_out's feature share (97 % of that conv) beside the graph tier's tiny launches, forward and backward
-        self.out_stream = torch.cuda.Stream() if on_gpu and os.environ.get("SCAN_OUT_STREAM", "1") != "0" else None
+        # (an existing side stream, idle at that point of the step -- the P7 discriminator's: one more HIP stream shifts the
+        #  stream -> hardware-queue assignment of all the others, which cost the three-phase schedule 1.5 ms)
+        self.out_stream = self.dis_streams.get("P7") if on_gpu and os.environ.get("SCAN_OUT_STREAM", "1") != "0" else None
         if "middle_head" in model and hasattr(model["middle_head"], "out_stream"):
             model["middle_head"].out_stream = self.out_stream
         # weight gradients of flat-buffer parameters on a stream of their own (ops.WGRAD_STREAM)

@@ -256,32 +256,35 @@ class GRAPHModule(nn.Module):
         return F.linear(x, w, self.cond_nx1.bias)
 
     # ---- HIP tier ----
-    def _out_features(self, feats, shape):
+    def _out_features(self, feats, shape, side=False):
         """head_out's share of the 256 feature channels (ops.HEAD_OUT_SPLIT): conv(cat(feats, maps)) = conv(feats; W[:, :256])
         + conv(maps; W[:, 256:]), and the first -- 97 % of the layer -- does not wait for the graph tier (node sampling,
         GCN, attention, paradigm RNN: a few hundred tiny launches with the GPU nearly idle).  With ``out_stream`` set (by
-        engine.Trainer) it runs on that stream BESIDE the graph tier, and so do its data and weight gradients in the
-        backward; the 265-channel input the kernels handled badly (a third, almost empty 128-wide channel tile in the data
-        gradient, the old weight-gradient kernel) becomes 256 clean channels.  Returns None when the split is off."""
+        engine.Trainer) and side=True (the paired step; in the three-phase schedule the passes already run beside each
+        other and a third MFMA-dense stream cost 1.3 ms) it runs on that stream BESIDE the graph tier, and so do its data
+        and weight gradients in the backward; the 265-channel input the kernels handled badly (a third, almost empty 128-wide channel tile in the data
+        gradient, the old weight-gradient kernel) becomes 256 clean channels.  Returns (rows, stream they are produced on or
+        None), or None when the split is off."""
         if not ops.HEAD_OUT_SPLIT or self.head_out.num_convs != 1:
             return None
         conv = self.head_out.middle_tower[0]
         C = feats.shape[1]
-        if self.out_stream is None:
-            return ops.conv2d(feats, conv.weight[:, :C], conv.bias, shape, 3, 1)
+        if self.out_stream is None or not side:
+            return ops.conv2d(feats, conv.weight[:, :C], conv.bias, shape, 3, 1), None
         self.out_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.out_stream):
-            return ops.conv2d(feats, conv.weight[:, :C], conv.bias, shape, 3, 1)
+            return ops.conv2d(feats, conv.weight[:, :C], conv.bias, shape, 3, 1), self.out_stream
 
     def _act_and_out(self, feats, shape, kernels, main=None):
         logits, maps = ops.dynconv_softmax(feats, kernels)
         if main is not None:  # relu(feature share + act-map share): same sum as the one conv over the concatenation
+            main, main_stream = main
             conv = self.head_out.middle_tower[0]
             C, K = feats.shape[1], maps.shape[1]
             thin_in = maps if K % 4 == 0 else F.pad(maps, (0, ops.pad4(K) - K))
             thin = ops.conv2d(thin_in, conv.weight[:, C:C + K], None, shape, 3, 1)
-            if self.out_stream is not None:
-                torch.cuda.current_stream().wait_stream(self.out_stream)
+            if main_stream is not None:
+                torch.cuda.current_stream().wait_stream(main_stream)
             return logits, maps, ops.add_relu(main, thin)
         pad = self.cat_stride - feats.shape[1] - maps.shape[1]
         cat = torch.cat([feats, maps, feats.new_zeros(feats.shape[0], pad)], 1)
@@ -347,7 +350,7 @@ class GRAPHModule(nn.Module):
         aggregation and the GST losses (_forward_train_target).
         -> out [M,256], node_loss, act_loss, act_maps [M,K], consistency loss or None."""
         feats = self.head_in(rows, shape)
-        main = self._out_features(feats, shape)
+        main = self._out_features(feats, shape, side=True)
         src, shape_src = ops.take_images(feats, shape, 0, n_src)
         plan = target_plan(shape_src, targets, rows.device)
         node_loss, proto_batch = self._forward_gcns(src[plan.node_index], plan.node_labels)

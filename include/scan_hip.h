@@ -243,6 +243,11 @@ int scan_conv_smallcin_bf16x3(const float* x, int32_t N, int32_t H, int32_t W, c
 int scan_conv3x3_gn_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
                            int32_t Csw, const float* bias, float* y, int32_t Nout, int32_t Ns, float* gn_ws,
                            void* stream);
+/* The same with the sums ADDED to gn_ws as it stands: the caller has cleared it (one memset per training iteration over a
+ * buffer all such workspaces are slices of, instead of one memset launch per call). */
+int scan_conv3x3_gn_acc_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                               int32_t Csw, const float* bias, float* y, int32_t Nout, int32_t Ns, float* gn_ws,
+                               void* stream);
 int scan_groupnorm_stats_from_sums(const float* ws, const scan_pyramid_t* d, int32_t C, int32_t G, float eps,
                                    float* stats, void* stream);
 /* conv3x3 + bias (+ ReLU) + nn.MaxPool2d(2, 2) in one launch (last conv of a FROZEN VGG stage, vgg.py:8-33: forward only):
@@ -282,6 +287,7 @@ int scan_groupnorm_relu_forward_from_sums(const float* x, const scan_pyramid_t* 
 int64_t scan_groupnorm_ws_floats(const scan_pyramid_t* d, int32_t C, int32_t G);
 /* dx, dgamma[C] (+)=, dbeta[C] (+)=; beta [C] is the forward's shift: the ReLU mask is recomputed from x with the
  * forward's exact operation order instead of reading y back (may be NULL when relu == 0);
+ * accumulate: bit 0 = add to dgamma / dbeta instead of overwriting, bit 1 = ws arrives cleared (else the call clears it);
  * ws: scan_groupnorm_ws_floats */
 int scan_groupnorm_relu_backward(const float* x, const float* beta, const float* dy, const scan_pyramid_t* d, int32_t C,
                                  int32_t G, const float* stats, const float* gamma, int32_t relu, float* dx,

@@ -100,6 +100,7 @@ SIGNATURES = {
     "scan_maxpool2x2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_maxpool2x2_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "scan_conv3x3_gn_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
+    "scan_conv3x3_gn_acc_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp]),
     "scan_groupnorm_stats_from_sums": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_f32, c_vp, c_vp]),
     "scan_conv3x3_pool2_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "scan_conv1x1_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, _PD, c_i32, c_i32, c_i32,

@@ -509,6 +509,18 @@ extern "C" int scan_conv3x3_gn_bf16x3(const float* x, const scan_pyramid_t* d, i
                                reinterpret_cast<double*>(gn_ws));
 }
 
+// the same with the sums ADDED to gn_ws as it is: the caller cleared it (scan_amd/ops.py hands out slices of one buffer it
+// clears with one memset per training iteration instead of one memset launch per call)
+extern "C" int scan_conv3x3_gn_acc_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wl,
+                                          int32_t Csw, const float* bias, float* y, int32_t Nout, int32_t Ns, float* gn_ws,
+                                          void* stream) {
+  SCAN_CHECK_ARG(Nout == 256 && gn_ws, "conv3x3_gn_acc_bf16x3: needs Nout == 256 (GroupNorm(32, 256)) and a workspace");
+  SCAN_CHECK_ARG(d && d->n_levels >= 1 && d->n_levels <= SCAN_MAX_LEVELS && d->n_images >= 1,
+                 "conv3x3_gn_acc_bf16x3: bad pyramid");
+  return conv3x3_bf16x3_launch(x, d, Cs, wh, wl, Csw, bias, nullptr, y, Nout, Ns, 0, stream,
+                               reinterpret_cast<double*>(gn_ws));
+}
+
 // conv3x3 + bias (+ ReLU) + 2x2 / stride-2 max-pool in one launch: y [N, H/2, W/2, Ns] (forward only; single-level
 // pyramid with even H, W).  max and the monotone bias / ReLU commute, so the result equals pooling the conv output.
 extern "C" int scan_conv3x3_pool2_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh,

@@ -411,7 +411,8 @@ extern "C" int scan_groupnorm_relu_backward_ld(const float* x, const float* beta
   double* ws_g = reinterpret_cast<double*>(ws);
   const int64_t ng = (int64_t)d->n_levels * d->n_images * G * 2;
   double* ws_c = ws_g + ng;
-  if (hipMemsetAsync(ws_g, 0, sizeof(double) * (ng + 2 * C * GN_REP), st) != hipSuccess) {
+  // accumulate bit 1: ws arrives cleared (a slice of the caller's once-per-iteration cleared buffer)
+  if (!(accumulate & 2) && hipMemsetAsync(ws_g, 0, sizeof(double) * (ng + 2 * C * GN_REP), st) != hipSuccess) {
     scan_set_error("groupnorm_relu_backward: memset failed");
     return -2;
   }
@@ -421,7 +422,7 @@ extern "C" int scan_groupnorm_relu_backward_ld(const float* x, const float* beta
                      lddy);
   SCAN_LAUNCH_CHECK("gn_bwd_reduce");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(nblk), dim3(256), 0, st, x, beta, dy, *d, tab, G, stats, gamma, relu, ws_g, dx,
-                     ws_c, dgamma, dbeta, accumulate, lddy);
+                     ws_c, dgamma, dbeta, accumulate & 1, lddy);
   SCAN_LAUNCH_CHECK("gn_bwd_apply");
   return 0;
 }

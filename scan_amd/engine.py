@@ -354,7 +354,8 @@ class Trainer:
         # The five CKA discriminators are independent; P4..P7 have 16 K ... 256 pixel rows, far too few tiles to
         # fill 256 CUs, so they run on side HIP streams next to P3 (autograd replays each backward on the stream
         # of its forward, so the backward overlaps the same way).
-        on_gpu = next(next(iter(model.values())).parameters()).is_cuda
+        self.device = next(next(iter(model.values())).parameters()).device
+        on_gpu = self.device.type == "cuda"
         # SCAN_DIS_STREAMS = number of side streams the four small levels share (default 4: one each)
         n_side = max(1, min(4, int(os.environ.get("SCAN_DIS_STREAMS", "4"))))
         pool = [torch.cuda.Stream() for _ in range(n_side)] if on_gpu else []
@@ -623,7 +624,7 @@ class Trainer:
         accumulate into the same .grad, so ONE backward of the summed losses leaves identical gradients."""
         model, lam = self.model, self.con_dis_lambda
         self._throttle()
-        ops.begin_weight_epoch(self._split_plan)
+        ops.begin_weight_epoch(self._split_plan, self.device)
         fcos_mod.reset_target_plan()
         for m in model.values():
             if not m.training:  # walking every sub-module costs ~0.1 ms of host time per model
@@ -732,7 +733,7 @@ class Trainer:
             if _padded_shape(il_s) == _padded_shape(il_t):
                 return self.step_paired(il_s, targets_s, il_t, forward_target)
         model, lam = self.model, self.con_dis_lambda
-        ops.begin_weight_epoch(self._split_plan)  # parameters change once per iteration: reuse their bf16 planes within it
+        ops.begin_weight_epoch(self._split_plan, self.device)  # parameters change once per iteration: reuse their bf16 planes within it
         fcos_mod.reset_target_plan()
         for m in model.values():
             if not m.training:  # walking every sub-module costs ~0.1 ms of host time per model

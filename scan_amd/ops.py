@@ -248,7 +248,43 @@ class SplitPlan:
             _split_cache[k] = (SPLIT_EPOCH, j[7], j[8], ev)
 
 
-def begin_weight_epoch(plan=None):
+# GroupNorm workspaces (fp64 sums the kernels accumulate into with atomics) must start at zero.  Cleared one by one that is a
+# memset launch per conv-with-sums and per GroupNorm backward, 60 per training step; instead they are slices of one buffer
+# that begin_weight_epoch() clears with ONE memset (what the previous iteration used of it), and the library is told not to
+# clear (scan_conv3x3_gn_acc_bf16x3; bit 1 of scan_groupnorm_relu_backward's accumulate).  Outside an epoch, or when the buffer
+# runs out, the workspace is a fresh allocation the library call clears itself.
+ZERO_POOL = os.environ.get("SCAN_ZERO_POOL", "1") != "0"
+_zero_pool = {"buf": None, "off": 0, "active": False}
+_ZERO_POOL_DOUBLES = 1 << 20
+
+
+def _ws_f64(n, device):
+    """n doubles on `device` for a kernel that accumulates into them -> (tensor, True if it is already zero: a slice of
+    the pool, valid until the next begin_weight_epoch; False: uninitialised, the library call clears it)."""
+    zp = _zero_pool
+    n_al = (n + 31) // 32 * 32
+    if ZERO_POOL and zp["active"] and zp["buf"] is not None and zp["buf"].device == device \
+            and zp["off"] + n_al <= _ZERO_POOL_DOUBLES:
+        out = zp["buf"][zp["off"]:zp["off"] + n]
+        zp["off"] += n_al
+        return out, True
+    return torch.empty((n,), dtype=torch.float64, device=device), False
+
+
+def _reset_zero_pool(device):
+    zp = _zero_pool
+    if not ZERO_POOL or device is None or device.type != "cuda":
+        zp["active"] = False
+        return
+    if zp["buf"] is None or zp["buf"].device != device:
+        zp["buf"] = torch.zeros((_ZERO_POOL_DOUBLES,), dtype=torch.float64, device=device)
+    elif zp["off"] > 0:
+        zp["buf"][:zp["off"]].zero_()
+    zp["off"] = 0
+    zp["active"] = True
+
+
+def begin_weight_epoch(plan=None, device=None):
     """Start of a span in which parameters do not change (one training iteration): the bf16 planes split inside it are
     reused by every launch that reads the same weight (forward, data gradient, source / target passes).  With a
     SplitPlan the planes it knows are produced right here, in one launch."""
@@ -257,6 +293,7 @@ def begin_weight_epoch(plan=None):
     SPLIT_EPOCH = _epoch_counter[0]
     _split_cache.clear()
     _active_plan = plan if BATCHED else None
+    _reset_zero_pool(device)
     if _active_plan is not None:
         _active_plan.run()
 
@@ -268,6 +305,7 @@ def invalidate_weight_planes():
     global SPLIT_EPOCH, _active_plan
     SPLIT_EPOCH = None
     _active_plan = None
+    _zero_pool["active"] = False
     _split_cache.clear()
 
 
@@ -315,8 +353,8 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
     else:
         ev = None
     if gn_sums:
-        sums = torch.empty((shape.n_levels * shape.n_images * 32 * 2,), dtype=torch.float64, device=x.device)
-        call("scan_conv3x3_gn_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(y), nout,
+        sums, cleared = _ws_f64(shape.n_levels * shape.n_images * 32 * 2, x.device)
+        call("scan_conv3x3_gn_acc_bf16x3" if cleared else "scan_conv3x3_gn_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(y), nout,
              ns, _ptr(sums), st)
         _gn_sums.clear()  # at most one pending hand-over: conv and its GroupNorm are adjacent calls of one thread
         _gn_sums[y.data_ptr()] = sums
@@ -803,13 +841,13 @@ class _GroupNormReLU(torch.autograd.Function):
         if lddy is None:
             dy, lddy = dy.contiguous(), C
         nws = query("scan_groupnorm_ws_floats", shape.ref(), C, 32)
-        ws = torch.empty((nws // 2 + 1,), dtype=torch.float64, device=x.device)
+        ws, cleared = _ws_f64(nws // 2 + 1, x.device)
         dx = torch.empty_like(x)
         direct = ctx.gbuf is not None
         dg = ctx.gbuf if direct else x.new_empty((C,))
         db = ctx.bbuf if direct else x.new_empty((C,))
         call("scan_groupnorm_relu_backward_ld", _ptr(x), _ptr(beta), _ptr(dy), lddy, shape.ref(), C, 32, _ptr(stats),
-             _ptr(gamma), int(relu), _ptr(dx), _ptr(dg), _ptr(db), int(direct), _ptr(ws), _stream())
+             _ptr(gamma), int(relu), _ptr(dx), _ptr(dg), _ptr(db), int(direct) | (2 if cleared else 0), _ptr(ws), _stream())
         if direct:
             return dx, None, None, None, None, None, None
         return dx, dg, db, None, None, None, None

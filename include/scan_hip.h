@@ -471,6 +471,20 @@ int scan_normalize_image_u8(const uint8_t* src, int32_t H, int32_t W, int32_t fl
                             const float* mean3, const float* std3, float* dst, int32_t Hp, int32_t Wp, int32_t layout,
                             void* stream);
 
+/* Conditioned-kernel generator of the graph middle head (rpn/fcos/condgraph.py:313-319 get_conded_weight: paradigm
+ * [K, 256, T] -> nn.RNN(256, 512, num_layers=2, nonlinearity tanh, h0 = 0) over the T slots, batch = the K classes ->
+ * Conv2d(512, 256, (T, 1)) -> kernels [K, 256]) as one launch per link of the dependent chain (2 T + 1 forward, 2 T + 2
+ * backward) instead of ~120 torch launches.  K <= 9, T <= 3.  x: the paradigm slot-major, [T, K, 256].
+ * weights / grads: ten device pointers in the order weight_ih_l0 [512,256], weight_hh_l0 [512,512], bias_ih_l0, bias_hh_l0,
+ * weight_ih_l1 [512,512], weight_hh_l1, bias_ih_l1, bias_hh_l1, cond_nx1.weight [256,512,T,1] (contiguous), cond_nx1.bias.
+ * forward: h0 / h1 [T, K, 512] = the two layers' states (kept for the backward), kernels [K, 256].
+ * backward: every gradient is overwritten (the paradigm is a buffer: no input gradient); ws: scan_cond_rnn_ws_floats(). */
+int scan_cond_rnn_forward(const float* x, int32_t K, int32_t T, const float* const* weights, float* h0, float* h1,
+                          float* kernels, void* stream);
+int64_t scan_cond_rnn_ws_floats(void);
+int scan_cond_rnn_backward(const float* x, int32_t K, int32_t T, const float* const* weights, const float* h0,
+                           const float* h1, const float* dkernels, float* const* grads, float* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

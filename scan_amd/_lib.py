@@ -48,6 +48,9 @@ SIGNATURES = {
     "scan_last_error": (ctypes.c_char_p, []),
     "scan_abi_version": (ctypes.c_int, []),
     "scan_tune": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "scan_cond_rnn_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "scan_cond_rnn_ws_floats": (ctypes.c_int64, []),
+    "scan_cond_rnn_backward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "scan_tune_get": (ctypes.c_int, [ctypes.c_char_p]),
     "scan_conv3x3_bf16x3_instance": (ctypes.c_int, [_PD, c_i32]),
     "scan_conv_wgrad_bf16x3_generation": (ctypes.c_int, [c_i32]),

@@ -249,6 +249,11 @@ class GRAPHModule(nn.Module):
 
     def get_conded_weight(self):
         """reference condgraph.py:313-319: paradigm [K,256,T] -> RNN -> Conv2d(512,256,(T,1)) -> [K,256]."""
+        r = self.cond_rnn
+        params = [getattr(r, "%s_l%d" % (n, l)) for l in range(r.layers)
+                  for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh")] + [self.cond_nx1.weight, self.cond_nx1.bias]
+        if r.layers == 2 and ops.cond_rnn_supported(self.prototype, params):
+            return ops.cond_rnn(self.prototype, params)  # the whole chain below as one launch (csrc/condrnn.hip)
         seq = self.cond_rnn(self.prototype.permute(2, 0, 1))  # [T, K, 512]
         # Conv2d(512, 256, (T,1)) over a [K,512,T,1] input is one linear map over (c, t)
         x = seq.permute(1, 2, 0).reshape(seq.shape[1], -1)  # [K, 512*T], (c, t) order

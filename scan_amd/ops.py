@@ -1321,6 +1321,55 @@ def gconv3x3_to1(x, w, bias, shape, G, mask_dx=False):
 
 
 # ----------------------------------------------------------------------------- optimizer
+# SCAN_COND_RNN=0: the conditioned-kernel generator (paradigm -> 2-layer tanh RNN -> (T, 1) conv) runs as the torch loop it is
+# written as in modeling/condgraph.py (T x 2 x (2 linear + add + tanh), ~120 launches with its backward) instead of the
+# 15 launches of csrc/condrnn.hip (one per link of the chain, spread over 8-32 workgroups), for A/B.  Same values up to the summation order.
+COND_RNN_FUSED = os.environ.get("SCAN_COND_RNN", "1") != "0"
+
+
+class _CondRnn(torch.autograd.Function):
+    """proto [K, 256, T] (a buffer: no gradient), the ten parameters in scan_cond_rnn_forward's order -> kernels [K, 256]"""
+
+    @staticmethod
+    def forward(ctx, proto, *params):
+        if not (proto.is_cuda and all(p.is_cuda and p.dtype == torch.float32 for p in params)):
+            raise RuntimeError("scan_amd ops run only on the GPU (HIP); no CPU fallback")
+        K, C, T = proto.shape
+        proto = proto.permute(2, 0, 1).contiguous()  # [T, K, 256]: the RNN's sequence-first input
+        ws_ = [p.detach().contiguous() for p in params]
+        h0 = proto.new_empty((T, K, 512))
+        h1 = torch.empty_like(h0)
+        ker = proto.new_empty((K, 256))
+        wptr = (ctypes.c_void_p * 10)(*[w.data_ptr() for w in ws_])
+        call("scan_cond_rnn_forward", _ptr(proto), K, T, wptr, _ptr(h0), _ptr(h1), _ptr(ker), _stream())
+        ctx.save_for_backward(proto, h0, h1, *ws_)
+        return ker
+
+    @staticmethod
+    def backward(ctx, dker):
+        proto, h0, h1, *ws_ = ctx.saved_tensors
+        T, K, C = proto.shape
+        dker = dker.contiguous()
+        grads = [torch.empty_like(w) for w in ws_]
+        wptr = (ctypes.c_void_p * 10)(*[w.data_ptr() for w in ws_])
+        gptr = (ctypes.c_void_p * 10)(*[g.data_ptr() for g in grads])
+        ws = proto.new_empty((query("scan_cond_rnn_ws_floats"),))
+        call("scan_cond_rnn_backward", _ptr(proto), K, T, wptr, _ptr(h0), _ptr(h1), _ptr(dker), gptr, _ptr(ws), _stream())
+        return (None, *grads)
+
+
+def cond_rnn_supported(proto, params):
+    K, C, T = proto.shape
+    return (COND_RNN_FUSED and proto.is_cuda and K <= 9 and T <= 3 and C == 256 and tuple(params[0].shape) == (512, 256)
+            and tuple(params[8].shape[:3]) == (256, 512, T))
+
+
+def cond_rnn(proto, params):
+    """reference condgraph.py:313-319 get_conded_weight as one launch (two in the backward); params: weight_ih_l0,
+    weight_hh_l0, bias_ih_l0, bias_hh_l0, weight_ih_l1, weight_hh_l1, bias_ih_l1, bias_hh_l1, cond_nx1.weight, cond_nx1.bias"""
+    return _CondRnn.apply(proto, *params)
+
+
 def sgd_momentum_multi_(segments, momentum):
     """segments: list of (p, g, buf, lr, wd, first_step) flat fp32 tensors of equal length -- all updated by ONE launch
     (scan_sgd_momentum_multi), element arithmetic as sgd_momentum_."""

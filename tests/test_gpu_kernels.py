@@ -1182,3 +1182,36 @@ def test_split_levels_grl_equals_split_then_grl(device):
         grads.append(r.grad.clone())
     assert torch.equal(grads[0], grads[1])
     assert float(grads[1][shape.row_off[2]:].abs().sum()) == 0.0
+
+
+@pytest.mark.parametrize("K,T", [(9, 3), (2, 3), (5, 2), (9, 1)])
+def test_cond_rnn_fused_equals_torch_loop(device, K, T):
+    """scan_cond_rnn_forward / _backward (paradigm -> 2-layer tanh RNN -> (T, 1) conv -> kernels [K, 256], reference
+    condgraph.py:313-319) against the torch loop GRAPHModule.get_conded_weight spells out: values and the gradients of
+    all ten parameters."""
+    from scan_amd import ops
+    from scan_amd.modeling import condgraph
+    torch.manual_seed(100 * K + T)
+    m = condgraph.GRAPHModule(256, K, proto_iter=T).to(device)
+    with torch.no_grad():
+        m.prototype.copy_(torch.randn(K, 256, T, device=device))
+        for p in list(m.cond_rnn.parameters()) + list(m.cond_nx1.parameters()):
+            p.copy_(torch.randn_like(p) * 0.05)
+    params = list(m.cond_rnn.parameters()) + list(m.cond_nx1.parameters())
+    dk = torch.randn(K, 256, device=device)
+    res = {}
+    for fused in (True, False):
+        keep = ops.COND_RNN_FUSED
+        ops.COND_RNN_FUSED = fused
+        try:
+            for p in params:
+                p.grad = None
+            ker = m.get_conded_weight()
+            ker.backward(dk)
+            res[fused] = (ker.detach().clone(), [p.grad.clone() for p in params])
+        finally:
+            ops.COND_RNN_FUSED = keep
+    assert torch.allclose(res[True][0], res[False][0], rtol=1e-4, atol=1e-5)
+    for (name, _), a, b in zip(list(m.cond_rnn.named_parameters()) + list(m.cond_nx1.named_parameters()), res[True][1], res[False][1]):
+        scale = max(1.0, float(b.abs().max()))
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * scale), (name, float((a - b).abs().max()), scale)

@@ -271,7 +271,27 @@ def _ws_f64(n, device):
     return torch.empty((n,), dtype=torch.float64, device=device), False
 
 
+_loss_zero = {"buf": None, "off": 0}
+
+
+def _zeros_f32(n, device):
+    """n zeroed floats for a loss kernel's accumulators.  Inside a training iteration they are carved from ONE torch.zeros
+    allocated per iteration (a NEW tensor every iteration, so loss scalars that are views of it stay valid after the next
+    iteration starts) -- ten fill launches per step become one."""
+    lz = _loss_zero
+    n_al = (n + 15) // 16 * 16
+    if ZERO_POOL and _zero_pool["active"] and lz["buf"] is not None and lz["buf"].device == device \
+            and lz["off"] + n_al <= lz["buf"].numel():
+        out = lz["buf"][lz["off"]:lz["off"] + n]
+        lz["off"] += n_al
+        return out
+    return torch.zeros((n,), dtype=torch.float32, device=device)
+
+
 def _reset_zero_pool(device):
+    _loss_zero["buf"] = torch.zeros((1024,), dtype=torch.float32, device=device) \
+        if ZERO_POOL and device is not None and device.type == "cuda" else None
+    _loss_zero["off"] = 0
     zp = _zero_pool
     if not ZERO_POOL or device is None or device.type != "cuda":
         zp["active"] = False
@@ -1041,7 +1061,7 @@ class _CkaBce(torch.autograd.Function):
         _chk(logits, act)
         M = logits.shape[0]
         assert logits.shape[1] == cf and act.shape[1] == cf + 1
-        out = logits.new_zeros((2 * cf + 2,))
+        out = _zeros_f32(2 * cf + 2, logits.device)
         if M > 0:
             call("scan_cka_bce_forward_loss", _ptr(logits), _ptr(act), M, cf, target, _ptr(out), _stream())
         ctx.save_for_backward(logits, act, out)
@@ -1057,6 +1077,35 @@ class _CkaBce(torch.autograd.Function):
             call("scan_cka_bce_backward_loss", _ptr(logits), _ptr(act), logits.shape[0], cf, target,
                  _ptr(g.reshape(1).contiguous()), _ptr(out), _ptr(d), _stream())
         return d, None, None, None
+
+
+class _SplitRows2(torch.autograd.Function):
+    """(x[:m], x[m:]) as views; the backward writes the two gradients into ONE buffer (torch's two slice backwards each
+    zero-fill a full-size tensor, copy their part and are then added: 2 fills + 2 copies + 1 add per use)."""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        ctx.m = m
+        ctx.shape = x.shape
+        return x[:m], x[m:]
+
+    @staticmethod
+    def backward(ctx, g1, g2):
+        m = ctx.m
+        g = (g1 if g1 is not None else g2).new_empty(ctx.shape)
+        if g1 is not None:
+            g[:m] = g1
+        else:
+            g[:m].zero_()
+        if g2 is not None:
+            g[m:] = g2
+        else:
+            g[m:].zero_()
+        return g, None
+
+
+def split_rows2(x, m):
+    return _SplitRows2.apply(x, m)
 
 
 def cka_bce(logits, act_detached, target, cf):

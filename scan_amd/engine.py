@@ -431,7 +431,8 @@ class Trainer:
             out.append(("dis", [(min(ar[k][0] for k in dis), max(ar[k][1] for k in dis))], True))
         rest = [k for k in self.groups if k != "fcos" and k not in dis and k != "backbone"]
         for k in rest:
-            out.append((k, [ar[k]], False))
+            # the middle head's output conv back-propagates its feature share on a side stream (condgraph._out_features)
+            out.append((k, [ar[k]], True))
         if "backbone" in self.groups:
             g, base = self.groups["backbone"], ar["backbone"][0]
             stages = getattr(self.model["backbone"], "grad_stage_params", None)

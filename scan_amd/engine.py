@@ -371,6 +371,7 @@ class Trainer:
         self.wgrad_stream = torch.cuda.Stream() if on_gpu and os.environ.get("SCAN_WGRAD_STREAM", "0") != "0" else None
         ops.WGRAD_STREAM = self.wgrad_stream
         self.overlap_target = True
+        self.fcos_beside_dis = os.environ.get("SCAN_FCOS_STREAM", "1") != "0"  # paired step: FCOS head beside the discriminators
         self.merge_source_backward = True
         # source and target frames as ONE batch through backbone / middle head / discriminators and one backward
         # (step_paired): same losses and gradients as the three phases, larger launches.  Used when both batches
@@ -654,7 +655,7 @@ class Trainer:
         main = torch.cuda.current_stream()
         # the FCOS head (source rows) is independent of the discriminators: it takes the side stream the three-phase
         # schedule uses for the target forward and fills the tails of the P3 discriminator's kernels (~1.2 ms)
-        fstream = self.tgt_stream if self.overlap_target else None
+        fstream = self.tgt_stream if self.overlap_target and self.fcos_beside_dis else None
         if fstream is not None:
             fstream.wait_stream(main)
         with torch.cuda.stream(fstream if fstream is not None else main):

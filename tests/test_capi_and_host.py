@@ -357,3 +357,21 @@ def test_reference_written_checkpoint_loads(gold_dir, tmp_path):
     tr2 = engine.Trainer(engine.build_model(9, device="cpu"))
     tr2.load_checkpoint(path, load_opt_sch=False)
     assert tr2.iteration == 0 and tr2.groups["dis_P3_CON"].first
+
+
+def test_split_rows2_backward_equals_two_slices():
+    """ops.split_rows2 (the discriminators' source / target halves of a level): same values and gradient as x[:m], x[m:],
+    also when only one half is used."""
+    import torch
+    from scan_amd import ops
+    x = torch.randn(7, 3, requires_grad=True)
+    a, b = ops.split_rows2(x, 4)
+    (a.sum() * 2 + (b ** 2).sum()).backward()
+    y = x.detach().clone().requires_grad_(True)
+    (y[:4].sum() * 2 + (y[4:] ** 2).sum()).backward()
+    assert torch.equal(x.grad, y.grad)
+    x.grad = None
+    a, b = ops.split_rows2(x, 4)
+    assert torch.equal(a, x[:4]) and torch.equal(b, x[4:])
+    b.sum().backward()
+    assert torch.equal(x.grad, torch.cat([torch.zeros(4, 3), torch.ones(3, 3)]))

@@ -1215,3 +1215,29 @@ def test_cond_rnn_fused_equals_torch_loop(device, K, T):
     for (name, _), a, b in zip(list(m.cond_rnn.named_parameters()) + list(m.cond_nx1.named_parameters()), res[True][1], res[False][1]):
         scale = max(1.0, float(b.abs().max()))
         assert torch.allclose(a, b, rtol=1e-4, atol=2e-5 * scale), (name, float((a - b).abs().max()), scale)
+
+
+def test_zero_pool_slices_are_cleared_every_epoch(device):
+    """GroupNorm workspaces come from ops' pool: zero when handed out, again zero after the next begin_weight_epoch even if a
+    kernel left sums in them, fresh (library-cleared) allocations outside an epoch or when the pool is exhausted."""
+    from scan_amd import ops
+    ops.begin_weight_epoch(None, device)
+    try:
+        a, cleared = ops._ws_f64(1000, device)
+        assert cleared and float(a.abs().sum()) == 0.0
+        a.fill_(3.0)
+        b, cleared_b = ops._ws_f64(70, device)
+        assert cleared_b and float(b.abs().sum()) == 0.0 and b.data_ptr() != a.data_ptr()
+        z = ops._zeros_f32(18, device)
+        z.fill_(1.0)
+        ops.begin_weight_epoch(None, device)
+        a2, _ = ops._ws_f64(1000, device)
+        assert a2.data_ptr() == a.data_ptr() and float(a2.abs().sum()) == 0.0
+        z2 = ops._zeros_f32(18, device)
+        assert float(z2.abs().sum()) == 0.0 and float(z.sum()) == 18.0  # last epoch's loss accumulators are left alone
+        big, cleared_big = ops._ws_f64(ops._ZERO_POOL_DOUBLES + 1, device)
+        assert not cleared_big
+    finally:
+        ops.invalidate_weight_planes()
+    c, cleared_c = ops._ws_f64(10, device)
+    assert not cleared_c  # outside an epoch: the library call clears its workspace itself

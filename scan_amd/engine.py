@@ -361,6 +361,8 @@ class Trainer:
         pool = [torch.cuda.Stream() for _ in range(n_side)] if on_gpu else []
         self.dis_streams = {lvl: pool[i % n_side] for i, lvl in enumerate(("P4", "P5", "P6", "P7"))} if on_gpu else {}
         self.tgt_stream = torch.cuda.Stream() if on_gpu else None
+        if on_gpu and not ops.SIDE_STREAMS:
+            ops.SIDE_STREAMS.extend(pool)  # idle outside a training step: inference borrows them instead of making more
         # head_out's feature share (97 % of that conv) beside the graph tier's tiny launches, forward and backward
         # (an existing side stream, idle at that point of the step -- the P7 discriminator's: one more HIP stream shifts the
         #  stream -> hardware-queue assignment of all the others, which cost the three-phase schedule 1.5 ms)

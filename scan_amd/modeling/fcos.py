@@ -7,6 +7,7 @@ Because a pyramid's rows are already in the reference's flatten order (level-maj
 image, y, x; rpn/fcos/loss.py:191-202) the losses consume the conv outputs with no
 permute/reshape/cat copies.
 """
+import contextlib
 import ctypes
 import math
 
@@ -326,6 +327,7 @@ class FCOSPostProcessor:
         self.min_size = min_size
         self.num_classes = num_classes
         self.mode = mode
+        self._nms_streams = None  # two side streams for the per-image NMS chains, made on first use with a batch > 1
 
     def __call__(self, shape, box_cls, box_regression, centerness, image_sizes):
         """box_cls [M,C] (logits for 'common', fused probabilities otherwise), box_regression [M,4],
@@ -368,25 +370,48 @@ class FCOSPostProcessor:
         ws, hs = det[..., 2] - det[..., 0] + 1, det[..., 3] - det[..., 1] + 1
         ok = (val > 0) & (ws >= self.min_size) & (hs >= self.min_size)
         counts = ok.sum(1).tolist()  # the one host round trip of the selection
-        results = []
+        # Phase 1, no host read: every image's candidates are gathered (their number is known from `counts`, so
+        # nonzero_static needs no round trip) and its NMS is queued -- image i on side stream i % 2, since one NMS is a chain
+        # of single-workgroup kernels that leaves the GPU to the next image's.  Phase 2 reads the kept counts.
+        main = torch.cuda.current_stream() if det.is_cuda else None
+        if main is not None and N > 1 and self._nms_streams is None:
+            self._nms_streams = ops.borrow_side_streams(2)  # the trainer's, when there is one in the process
+        pending = []
         for i in range(N):
             if counts[i] == 0:
+                pending.append(None)
+                continue
+            side = self._nms_streams[i % 2] if main is not None and N > 1 else None
+            if side is not None:
+                side.wait_stream(main)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                sel = ok[i].nonzero_static(size=counts[i]).squeeze(1)
+                boxes, scores, labels = det[i][sel], torch.sqrt(val[i][sel]), lab[i][sel]
+                # per-class NMS (reference inference.py:160-176 loops classes and calls boxlist_nms on each) as ONE
+                # class-aware launch: a box is suppressed only by a kept, higher-scored box of the SAME label, which is
+                # exactly greedy NMS run per class; output order = class-major, original index ascending within a class
+                _last_nms[0] = (boxes, scores, labels, self.nms_thresh)
+                finish = ops.nms_by_label_async(boxes, scores, labels, self.nms_thresh)
+            pending.append((boxes, scores, labels, finish, side))
+        results = []
+        for i in range(N):
+            if pending[i] is None:
                 results.append((det.new_zeros((0, 4)), det.new_zeros((0,)), lab.new_zeros((0,))))
                 continue
-            m = ok[i]
-            boxes, scores, labels = det[i][m], torch.sqrt(val[i][m]), lab[i][m]
-            # per-class NMS (reference inference.py:160-176 loops classes and calls boxlist_nms on each) as ONE
-            # class-aware launch: a box is suppressed only by a kept, higher-scored box of the SAME label, which is
-            # exactly greedy NMS run per class; output order = class-major, original index ascending within a class
-            _last_nms[0] = (boxes, scores, labels, self.nms_thresh)
-            keep = ops.nms_by_label(boxes, scores, labels, self.nms_thresh).to(dev)
-            keep = keep[torch.argsort(labels[keep], stable=True)]
-            rb, rs, rl = boxes[keep], scores[keep], labels[keep]
-            n = len(rs)
-            if n > self.fpn_post_nms_top_n > 0:
-                th, _ = torch.kthvalue(rs, n - self.fpn_post_nms_top_n + 1)
-                k = torch.nonzero(rs >= th).squeeze(1)
-                rb, rs, rl = rb[k], rs[k], rl[k]
+            boxes, scores, labels, finish, side = pending[i]
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                keep = finish().to(dev)
+                keep = keep[torch.argsort(labels[keep], stable=True)]
+                rb, rs, rl = boxes[keep], scores[keep], labels[keep]
+                n = len(rs)
+                if n > self.fpn_post_nms_top_n > 0:
+                    th, _ = torch.kthvalue(rs, n - self.fpn_post_nms_top_n + 1)
+                    k = torch.nonzero(rs >= th).squeeze(1)
+                    rb, rs, rl = rb[k], rs[k], rl[k]
+            if side is not None:
+                main.wait_stream(side)
+                for t in (rb, rs, rl):
+                    t.record_stream(main)
             results.append((rb, rs, rl))
         return results
 

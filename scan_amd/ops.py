@@ -190,6 +190,18 @@ CAT_IN_PLACE = os.environ.get("SCAN_CAT_IN_PLACE", "1") != "0"
 # SCAN_FPN_DIRECT=0: the FPN output convs write tensors of their own that are concatenated afterwards, and the top-down
 # join is an up-sampling copy + add (torch), for A/B.  Same values.
 FPN_DIRECT = os.environ.get("SCAN_FPN_DIRECT", "1") != "0"
+# Side streams other parts may borrow for short independent chains (the post-processor's per-image NMS): engine.Trainer
+# registers the ones it made.  Borrowing instead of creating matters: one more HIP stream in the process shifts the stream ->
+# hardware-queue assignment of all the others (profiles/r03_head_out_split.txt).
+SIDE_STREAMS = []
+
+
+def borrow_side_streams(n):
+    while len(SIDE_STREAMS) < n:
+        SIDE_STREAMS.append(torch.cuda.Stream())
+    return SIDE_STREAMS[:n]
+
+
 # Stream the weight-gradient launches of flat-buffer parameters are queued on (engine.Trainer sets it; None = the stream
 # of the backward pass).  A weight gradient is a leaf of the backward graph -- nothing but the optimizer step (and the
 # gradient all-reduce) reads it -- so on a stream of its own it fills what the dependent chain leaves idle: the graph
@@ -1177,12 +1189,33 @@ def _nms_impl(dets, scores, labels, thr, rule_ge):
     scores = scores.contiguous().float()
     if labels is not None:
         labels = labels.contiguous().float()
+    keep, cnt = _nms_launch(dets, scores, labels, thr, rule_ge)
+    return keep[:int(cnt.item())]
+
+
+def _nms_launch(dets, scores, labels, thr, rule_ge):
+    """the launches of one NMS without the host read of the count: (keep buffer [n], count [1] int32)"""
+    n = dets.shape[0]
     ws = torch.empty((query("scan_nms_ws_bytes", n) + 15) // 16 * 2, dtype=torch.float64, device=dets.device)
     keep = torch.empty((n,), dtype=torch.int64, device=dets.device)
-    cnt = torch.zeros((1,), dtype=torch.int32, device=dets.device)
+    cnt = torch.empty((1,), dtype=torch.int32, device=dets.device)
     call("scan_nms", _ptr(dets), _ptr(scores), _ptr(labels), n, float(thr), int(rule_ge), _ptr(keep), _ptr(cnt),
          _ptr(ws), _stream())
-    return keep[:int(cnt.item())]
+    return keep, cnt
+
+
+def nms_by_label_async(dets, scores, labels, thr):
+    """ml_nms / per-class NMS launched on the current stream, nothing read back: returns finish() -> kept indices.  Lets a
+    caller queue the NMS of several images (each a single-workgroup chain of kernels) on different streams before the
+    first host read."""
+    n = dets.shape[0]
+    if n == 0:
+        return lambda: torch.empty((0,), dtype=torch.int64, device="cpu")
+    _chk(dets, scores, labels)
+    if n > _lib.NMS_MAX:
+        raise RuntimeError("nms: n=%d exceeds SCAN_NMS_MAX=%d" % (n, _lib.NMS_MAX))
+    keep, cnt = _nms_launch(dets.contiguous().float(), scores.contiguous().float(), labels.contiguous().float(), thr, True)
+    return lambda: keep[:int(cnt.item())]
 
 
 def nms(dets, scores, thr, rule_ge=True):

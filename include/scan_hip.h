@@ -471,6 +471,12 @@ int scan_normalize_image_u8(const uint8_t* src, int32_t H, int32_t W, int32_t fl
                             const float* mean3, const float* std3, float* dst, int32_t Hp, int32_t Wp, int32_t layout,
                             void* stream);
 
+/* Gradient of taking the rows of images [i0, i1) out of a pyramid matrix [M, C] (the paired step splits source and target
+ * frames that way, reference trainer.py:284-352 runs them as separate batches): out [M, C] = g's rows at the taken images'
+ * places, zero elsewhere, in one pass.  g: [(i1 - i0) * sum_l h_l w_l, C], level-major like the pyramid. */
+int scan_take_images_backward(const float* g, const scan_pyramid_t* d, int32_t i0, int32_t i1, int32_t C, float* out,
+                              void* stream);
+
 /* Conditioned-kernel generator of the graph middle head (rpn/fcos/condgraph.py:313-319 get_conded_weight: paradigm
  * [K, 256, T] -> nn.RNN(256, 512, num_layers=2, nonlinearity tanh, h0 = 0) over the T slots, batch = the K classes ->
  * Conv2d(512, 256, (T, 1)) -> kernels [K, 256]) as one launch per link of the dependent chain (2 T + 1 forward, 2 T + 2

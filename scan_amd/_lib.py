@@ -48,6 +48,7 @@ SIGNATURES = {
     "scan_last_error": (ctypes.c_char_p, []),
     "scan_abi_version": (ctypes.c_int, []),
     "scan_tune": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
+    "scan_take_images_backward": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_cond_rnn_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "scan_cond_rnn_ws_floats": (ctypes.c_int64, []),
     "scan_cond_rnn_backward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),

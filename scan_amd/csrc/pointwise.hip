@@ -896,3 +896,40 @@ extern "C" int scan_downsample2x_sum(const float* g, int32_t N, int32_t h, int32
   SCAN_LAUNCH_CHECK("downsample2x_sum");
   return 0;
 }
+
+// ---- gradient of "the rows of images [i0, i1) of a pyramid" (ops.take_images): the full pyramid's gradient in ONE pass --
+// rows of the taken images copied from g (the sub-pyramid's rows, level-major), every other row zero.  Written with torch ops
+// this is a zero fill of the whole matrix plus one slice copy per level.
+__global__ __launch_bounds__(256) void take_images_bwd_kernel(const float* __restrict__ g, scan_pyramid_t d, int i0, int i1,
+                                                              int C, float* __restrict__ out) {
+  const int64_t total = d.row_off[d.n_levels] * (int64_t)C;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = e / C;
+    const int c = (int)(e - m * C);
+    int lvl = 0;
+#pragma unroll
+    for (int i = 1; i < SCAN_MAX_LEVELS; ++i)
+      if (i < d.n_levels && m >= d.row_off[i]) lvl = i;
+    const int64_t hw = (int64_t)d.h[lvl] * d.w[lvl];
+    const int64_t r = m - d.row_off[lvl];
+    const int64_t n = r / hw;
+    float v = 0.f;
+    if (n >= i0 && n < i1) {
+      // rows of the sub-pyramid before this level: (i1 - i0) images of every earlier level
+      const int64_t sub_off = d.row_off[lvl] / d.n_images * (i1 - i0);
+      v = g[(sub_off + (n - i0) * hw + (r - n * hw)) * C + c];
+    }
+    out[e] = v;
+  }
+}
+
+extern "C" int scan_take_images_backward(const float* g, const scan_pyramid_t* d, int32_t i0, int32_t i1, int32_t C, float* out,
+                                         void* stream) {
+  SCAN_CHECK_ARG(g && d && out && C >= 1 && d->n_levels >= 1 && d->n_levels <= SCAN_MAX_LEVELS && 0 <= i0 && i0 < i1 &&
+                     i1 <= d->n_images,
+                 "take_images_backward: bad arguments");
+  const int64_t total = d->row_off[d->n_levels] * (int64_t)C;
+  hipLaunchKernelGGL(take_images_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), g, *d, i0, i1, C, out);
+  SCAN_LAUNCH_CHECK("take_images_backward");
+  return 0;
+}

@@ -1241,3 +1241,23 @@ def test_zero_pool_slices_are_cleared_every_epoch(device):
         ops.invalidate_weight_planes()
     c, cleared_c = ops._ws_f64(10, device)
     assert not cleared_c  # outside an epoch: the library call clears its workspace itself
+
+
+@pytest.mark.parametrize("C,i0,i1", [(256, 0, 2), (9, 2, 4), (12, 1, 2), (8, 0, 4)])
+def test_take_images_backward_one_pass(device, C, i0, i1):
+    """ops.take_images: the sub-pyramid of images [i0, i1) and its gradient (scan_take_images_backward: copied rows, zeros
+    elsewhere, one launch) against the slice-by-slice torch spelling."""
+    from scan_amd import ops
+    shape = ops.PyramidShape(4, [(16, 24), (8, 12), (4, 6), (2, 3), (1, 2)])
+    torch.manual_seed(C + i0)
+    x = torch.randn(shape.rows, C, device=device, requires_grad=True)
+    y, sub = ops.take_images(x, shape, i0, i1)
+    parts = [x[shape.row_off[l] + i0 * h * w:shape.row_off[l] + i1 * h * w] for l, (h, w) in enumerate(shape.sizes)]
+    ref = torch.cat(parts, 0)
+    assert sub.n_images == i1 - i0 and torch.equal(y.detach(), ref.detach())
+    g = torch.randn_like(ref)
+    y.backward(g)
+    got = x.grad.clone()
+    x.grad = None
+    ref.backward(g)
+    assert torch.equal(got, x.grad)

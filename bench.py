@@ -35,10 +35,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # /opt/skills/guides/MI355X_MICROARCH.md: dense MFMA peaks.  fp32 kernels: v_mfma_f32_32x32x2_f32 157.3 TFLOP/s.
-# bf16x3 kernels issue THREE v_mfma_f32_32x32x16_bf16 per fp32-equivalent product (hi*hi + hi*lo + lo*hi), so
-# their ceiling in algorithmic (fp32-equivalent) FLOPs is the 2.5 PFLOP/s dense bf16 peak / 3.
+# The split-operand kernels (scan_amd/csrc/conv_split.h) issue SIX ("bf16x6": three bf16 pieces per operand, all 24
+# significand bits -- the reference's fp32 arithmetic) or THREE ("bf16x3": two pieces, 16 bits) bf16 MFMAs per fp32-equivalent
+# product, so their ceilings in algorithmic (fp32-equivalent) FLOPs are the 2.5 PFLOP/s dense bf16 peak / 6 and / 3.
 PEAK_FP32_MFMA_TFLOPS = 157.3
+PEAK_BF16X6_TFLOPS = 2500.0 / 6.0
 PEAK_BF16X3_TFLOPS = 2500.0 / 3.0
+HEADLINE_MODE = "bf16x6"
+XGMI_LINK_GBS = 153.0  # per link and direction; 7 links per GPU (MI355X_MICROARCH.md)
 
 
 def csrc_sha1():
@@ -82,25 +86,25 @@ def pmc_traffic(kernel_name):
 
 # timer record name (scan_amd/ops.py) -> kernel symbol as rocprofv3 lists it: forward and data-gradient launches of
 # a conv are the SAME kernel (dgrad = forward on dY with flipped/transposed weights); the _bnNNN suffix is the
-# output-channel tile of the instance the launch took (scan_conv3x3_bf16x3_instance)
+# output-channel tile of the instance the launch took (scan_conv3x3_bf16x6_instance / _bf16x3_instance)
 def symbol_of(name):
     import re
-    m = re.match(r"conv(3x3|1x1)_bf16x3_(fwd|dgrad)_bn(\d+)$", name)
+    m = re.match(r"conv(3x3|1x1)_bf16x(6|3)_(fwd|dgrad)_bn(\d+)$", name)
     if m:
-        bn = int(m.group(3))
-        th, nt = (8, 256) if bn == 64 else (16, 512)
+        np_, bn, ks = (3 if m.group(2) == "6" else 2), int(m.group(4)), (3 if m.group(1) == "3x3" else 1)
+        th, nt, tail = (8, 256, "") if bn == 64 else (16, 512, "")
+        if np_ == 3:  # three pieces: 8-wave workgroups, weight tiles by LDS-DMA on the 128- / 256-channel 3x3 tiles
+            if bn == 64 and ks == 3:
+                return "conv_split_kernel<3,64,8|16,256,3>"
+            return "conv_split_kernel<3,%d,%d,%d,%d%s>" % (bn, th, nt, ks, ",1,true" if (bn > 64 and ks == 3) else "")
         if bn > 2000:  # the 8-wave LDS-DMA instance of the 256-channel tile
-            return "conv_bf16x3_v2_kernel<%d,%d,512,3,1,true>" % (bn - 2000, th)
+            return "conv_split_kernel<2,%d,%d,512,3,1,true>" % (bn - 2000, th)
         if bn > 1000:
             bn, nt = bn - 1000, 1024
-        return "conv_bf16x3_v2_kernel<%d,%d,%d,%d>" % (bn, th, nt, 3 if m.group(1) == "3x3" else 1)
-    # the _g1 / _g2 suffix is the round-2 generation choice by input channel count (scan_conv_wgrad_bf16x3_generation);
-    # since round 3 every bf16x3 weight-gradient launch runs conv_wgrad_bf16x3_v6_kernel (3x3) / _v4_kernel (1x1)
-    return {"conv1x1_bf16x3_wgrad_g1": "conv_wgrad_bf16x3_v4_kernel<1,S>",
-            "conv1x1_bf16x3_wgrad_g2": "conv_wgrad_bf16x3_v4_kernel<1,S>",
-            "conv3x3_bf16x3_wgrad_g1": "conv_wgrad_bf16x3_v6_kernel<3>",
-            "conv3x3_bf16x3_wgrad_g2": "conv_wgrad_bf16x3_v6_kernel<3>",
-            "conv_smallcin_bf16x3": "conv_smallcin_kernel",
+        return "conv_split_kernel<2,%d,%d,%d,%d>" % (bn, th, nt, ks)
+    return {"conv1x1_bf16x3_wgrad": "conv_wgrad_v4_kernel<2,1,S>", "conv1x1_bf16x6_wgrad": "conv_wgrad_v4_kernel<3,1,S>",
+            "conv3x3_bf16x3_wgrad": "conv_wgrad_v6_kernel<2,64,3>", "conv3x3_bf16x6_wgrad": "conv_wgrad_v6_kernel<3,32,3>",
+            "conv_smallcin_bf16x3": "conv_smallcin_kernel<2>", "conv_smallcin_bf16x6": "conv_smallcin_kernel<3>",
             "conv_igemm_fwd": "conv_igemm_kernel<0,4>", "conv_igemm_dgrad": "conv_igemm_kernel<1,4>",
             "conv_wgrad": "conv_wgrad_kernel"}.get(name, name)
 
@@ -119,7 +123,12 @@ def by_symbol(ksum):
 
 
 def peak_for(kernel_name):
-    return PEAK_BF16X3_TFLOPS if "bf16x3" in kernel_name else PEAK_FP32_MFMA_TFLOPS
+    """dense-MFMA ceiling of a conv kernel symbol in fp32-equivalent TFLOP/s"""
+    import re
+    m = re.match(r"conv_(split|wgrad_v[46]|smallcin)_kernel<(\d)", kernel_name)
+    if m:
+        return PEAK_BF16X6_TFLOPS if m.group(2) == "3" else PEAK_BF16X3_TFLOPS
+    return PEAK_FP32_MFMA_TFLOPS
 
 
 def cpu_baseline(h, w, timed=3):
@@ -249,7 +258,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-companions", action="store_true",
                     help="skip the companion legs of the line (strict fp32-MFMA steps, the three-phase schedule, inference)")
-    ap.add_argument("--strict-steps", type=int, default=10, help="timed steps of the strict fp32-MFMA companion leg")
+    ap.add_argument("--strict-steps", type=int, default=5, help="timed steps of the strict fp32-MFMA companion leg")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run everything on one stream (no side-stream overlap): what the per-kernel roofline "
                          "figures and the rocprof summaries under profiles/ are taken with")
@@ -347,6 +356,7 @@ def main():
         losses = step()
     barrier()
     dt = time.time() - t0
+    dt_local = dt
     # per-kernel roofline figures: HIP events around every conv launch on its stream.  With the side-stream overlap
     # of the timed region an event pair also spans whatever co-runs on the other streams, so the kernels are timed
     # in two extra steps with the overlap switched off (same kernels, same shapes; rocprof: profiles/*serial*).
@@ -372,21 +382,22 @@ def main():
     finite = all(bool(torch.isfinite(v)) for v in losses.values())
 
     # ---- companion legs (N = 1, headline model only): same frames, same trainer, outside the timed region
-    strict = three_phase = infer = None
-    if world == 1 and not a.no_companions and not a.forward_target:
-        # (a) the SAME step with every convolution on the exact fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32 /
-        # 16x16x4_f32 = an fp32 fma chain, the reference's arithmetic): what the headline costs without the bf16 split
+    strict = fast = three_phase = infer = dp1 = None
+
+    def mode_leg(conv_mode, steps, what):
+        """the SAME step with every convolution in another arithmetic (ops.CONV_MODE), timed over `steps` steps, plus one
+        serial step under the kernel timer for its dominant kernel"""
         set_serial(a.serial_streams)
-        ops.CONV_MODE = "fp32"
+        ops.CONV_MODE = conv_mode
         try:
             for _ in range(2):
                 trainer.step(imgs_s, tg, imgs_t)
             torch.cuda.synchronize()
             t0s = time.time()
-            for _ in range(a.strict_steps):
+            for _ in range(steps):
                 ls = trainer.step(imgs_s, tg, imgs_t)
             torch.cuda.synchronize()
-            dts = (time.time() - t0s) / a.strict_steps
+            dts = (time.time() - t0s) / steps
             set_serial(True)
             trainer.step(imgs_s, tg, imgs_t)
             torch.cuda.synchronize()
@@ -397,15 +408,23 @@ def main():
             ops.kernel_timer.enabled = False
             ks = by_symbol(ops.kernel_timer.summary())
             sdom = max(ks.items(), key=lambda kv: kv[1]["total_ms"])
-            strict = {"dtype": "f32 (exact fp32 MFMA, v_mfma_f32_32x32x2_f32 / 16x16x4_f32)",
-                      "ms_per_step": round(dts * 1e3, 2), "pairs_per_s": round(B / dts, 4), "steps": a.strict_steps,
-                      "dominant_kernel": sdom[0], "dominant_tflops": round(sdom[1]["tflops"], 2),
-                      "frac_of_157.3": round(sdom[1]["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4),
-                      "dominant_avg_launch_ms": round(sdom[1]["avg_ms"], 4), "dominant_launches": sdom[1]["launches"],
-                      "losses_finite": all(bool(torch.isfinite(v)) for v in ls.values())}
+            return {"dtype": what, "ms_per_step": round(dts * 1e3, 2), "pairs_per_s": round(B / dts, 4), "steps": steps,
+                    "dominant_kernel": sdom[0], "dominant_tflops": round(sdom[1]["tflops"], 2),
+                    "dominant_peak_tflops": round(peak_for(sdom[0]), 1),
+                    "dominant_frac": round(sdom[1]["tflops"] / peak_for(sdom[0]), 4),
+                    "dominant_avg_launch_ms": round(sdom[1]["avg_ms"], 4), "dominant_launches": sdom[1]["launches"],
+                    "losses_finite": all(bool(torch.isfinite(v)) for v in ls.values())}
         finally:
-            ops.CONV_MODE = "bf16x3"
+            ops.CONV_MODE = HEADLINE_MODE
             set_serial(a.serial_streams)
+
+    if world == 1 and not a.no_companions and not a.forward_target:
+        # (a) the exact fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32 / 16x16x4_f32 = an fp32 fma chain): the same
+        # arithmetic as the headline on the 16x narrower pipe; and the two-piece split (16 significand bits per operand:
+        # NARROWER than the reference's arithmetic, 2e-6 on the losses) -- what giving up the third piece would buy
+        strict = mode_leg("fp32", a.strict_steps, "f32 (exact fp32 MFMA, v_mfma_f32_32x32x2_f32 / 16x16x4_f32)")
+        fast = mode_leg("bf16x3", a.steps, "bf16x3 (two bf16 pieces per operand = 16 significand bits, 3 bf16 MFMAs per "
+                                           "product: narrower than the reference's fp32 multiply; not the headline)")
         # (b) the reference's three-phase schedule (source forward/backward, target forward/backward as separate
         # pyramids): what do_train runs when source and target batches pad to different sizes
         trainer.paired = False
@@ -453,6 +472,51 @@ def main():
             infer["n_candidates"] = n_c
         for m_ in model.values():
             m_.train()
+        # (d) the data-parallel machinery with ONE rank on RCCL (gradient hooks, buckets, side-stream all-reduces, the
+        # 1 / world scale, paradigm all-reduce, loss reduce): a regression there shows without a multi-GPU box
+        if not dist.is_initialized():
+            try:
+                dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
+                                        device_id=dev)
+                tr_dp = engine.Trainer(model, settings=mcfg, distributed=True)
+                for _ in range(2):
+                    comm.reduce_loss_dict(tr_dp.step(imgs_s, tg, imgs_t))
+                torch.cuda.synchronize()
+                t0d = time.time()
+                for _ in range(a.steps):
+                    comm.reduce_loss_dict(tr_dp.step(imgs_s, tg, imgs_t))
+                torch.cuda.synchronize()
+                dtd = (time.time() - t0d) / a.steps
+                dp1 = {"ms_per_step": round(dtd * 1e3, 2), "pairs_per_s": round(B / dtd, 4), "steps": a.steps,
+                       "collective_backend": dist.get_backend(), "ranks_in_process_group": dist.get_world_size(),
+                       "gradient_allreduces_per_step": len(tr_dp.collective_log),
+                       "note": "same step through engine.Trainer(distributed=True) on a one-rank RCCL group"}
+                ops.WGRAD_STREAM = trainer.wgrad_stream
+                del tr_dp
+            except Exception as e:  # a broken collective path must not take the headline down with it
+                dp1 = {"error": repr(e)}
+            finally:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+
+    # gradient buckets of the data-parallel step: bytes and a per-link-bound ring model of their all-reduce over xGMI
+    def bucket_plan(n):
+        out = []
+        for name, rngs, _ in trainer._buckets():
+            nbytes = 4 * sum(hi - lo for lo, hi in rngs)
+            ring = 2.0 * (n - 1) / n * nbytes / (XGMI_LINK_GBS * 1e9) if n > 1 else 0.0
+            out.append({"bucket": name, "bytes": nbytes, "allreduces": len(rngs),
+                        "ring_ms_one_link": round(ring * 1e3, 3), "ring_ms_seven_links": round(ring * 1e3 / 7, 3)})
+        return out
+
+    n_model = world if world > 1 else 8
+    buckets = bucket_plan(n_model)
+    rank_ms = None
+    if world > 1:  # per-rank step time of the timed region (before the MAX): a straggler shows as max >> min
+        t = torch.tensor([dt_local / a.steps * 1e3], device=dev, dtype=torch.float64)
+        allt = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(allt, t)
+        rank_ms = [round(float(x.item()), 2) for x in allt]
 
     if rank == 0:
         pairs = B * world * a.steps
@@ -464,8 +528,8 @@ def main():
             traffic, prov = pmc_traffic(name)
             roof = {"bound": "mfma", "kernel": name, "achieved": round(r["tflops"], 2), "peak": round(peak_for(name), 1),
                     "unit": "TFLOP/s", "frac": round(r["tflops"] / peak_for(name), 4), "traffic": traffic,
-                    "peak_note": "algorithmic fp32-equivalent FLOPs; bf16x3 kernels spend 3 bf16 MFMAs per product, "
-                                 "peak = 2.5 PFLOP/s dense bf16 / 3",
+                    "peak_note": "algorithmic fp32-equivalent FLOPs; bf16x6 kernels spend 6 bf16 MFMAs per product: "
+                                 "peak = 2.5 PFLOP/s dense bf16 / 6 = 416.7",
                     "launches": r["launches"], "avg_launch_ms": round(r["avg_ms"], 4),
                     "measured": "HIP events on the launch stream, %d steps with side-stream overlap off "
                                 "(%.1f ms/step serial vs %.1f ms/step overlapped)" % (roof_steps, dtr / roof_steps * 1e3,
@@ -503,21 +567,26 @@ def main():
             "unit": "image pairs/s (1 source + 1 target frame per pair)", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(dt / a.steps * 1e3, 2), "higher_is_better": True,
             "scaling": a.scaling, "vs_baseline": None,
-            "dtype": "bf16x3 (fp32 storage + fp32 accumulate; every conv operand split hi+lo into 2 bf16, 3 bf16 MFMAs per "
-                     "product = 16 significand bits per operand; strict fp32-MFMA figure: strict_fp32)",
+            "dtype": "f32 (fp32 storage, fp32 multiply, fp32 accumulate -- the reference's arithmetic; the convolutions run it on "
+                     "the bf16 matrix cores as bf16x6: every fp32 operand cut into 3 bf16 pieces = all 24 significand bits, "
+                     "6 bf16 MFMAs per product)",
             "data": "synthetic",
             "config": {"workload": "SCAN %s %s DA iteration, %d src + %d tgt frames/GPU at %dx%d, "
                                    "forward_target=%s%s, procedural weights" % (
                            a.model.upper(), body, B, B, H, W, a.forward_target,
                            "" if a.ft_positives is None else " (%.3g of the act-map entries kept as clustering candidates)" % a.ft_positives),
-                       "arithmetic": "fp32 storage and accumulation; 3x3 convs split each fp32 operand hi+lo into "
-                                     "2 x bf16 and issue 3 bf16 MFMAs per product (1.7e-6 rel on the losses vs fp32)",
+                       "arithmetic": "bf16x6: exact 3-piece split of both operands, the six piece products >= 2^-24 of the "
+                                     "product accumulated in fp32 (dropped terms <= 2^-23 per product, below fp32 rounding); "
+                                     "distance from an fp64 conv <= the exact fp32-MFMA kernels' (tests/test_gpu_kernels.py::"
+                                     "test_conv_error_vs_fp64)",
                        "global_batch_pairs": B * world, "frames_per_s": round(2 * value, 4), "parallelism": "dp%d" % world,
                        "ranks_in_process_group": dist.get_world_size() if dist.is_initialized() else 1,
                        "collective_backend": dist.get_backend() if dist.is_initialized() else None,
-                       "losses_finite": finite},
+                       "losses_finite": finite, "rank_ms_per_step": rank_ms,
+                       "gradient_buckets": buckets, "gradient_buckets_modelled_for_ranks": n_model},
             "roofline": roof, "roofline_pointwise": pointwise, "cpu_baseline": cpu,
-            "strict_fp32": strict, "three_phase_schedule": three_phase, "inference": infer,
+            "strict_fp32": strict, "bf16x3_two_piece": fast, "three_phase_schedule": three_phase, "inference": infer,
+            "dp1_nccl": dp1,
         }
         # RCCL prints a version banner through C stdio, which is still buffered here when stdout is a pipe: push it
         # out first so the JSON line is the LAST line on stdout

@@ -41,56 +41,40 @@ const char* scan_last_error(void);
 int scan_abi_version(void);
 
 /* Tuning knob for A/B measurements and tests (no reference counterpart): scan_tune(key, value) sets an integer
- * launch-selection parameter and returns its previous value, -1 for an unknown key.
+ * launch-selection parameter and returns its previous value, -1 for an unknown key.  Every setting of every key gives
+ * correct results (timing-ablation instances are not part of this library).
  *   "conv_bn256"  1 (default): 3x3 convs whose output channels are a multiple of 256 use 256-channel tiles
  *                 when the launch keeps >= 2 workgroups per CU; 0: always 128-channel tiles (same results).
- *   "conv_v2"     1 (default): bf16x3 forward / data-gradient convs run on the v_mfma_f32_16x16x32_bf16 kernel;
- *                 0: on the v_mfma_f32_32x32x16_bf16 kernel (same arithmetic, different summation order inside a
- *                 32-channel chunk).
- *   "wgrad_v2"    the same choice for the bf16x3 weight-gradient kernels: 1 / 0, or 2 (default) = by shape (the
- *                 16x16x32 kernel where the input channels fill whole 128-wide tiles).
- *   "wgrad_v3"    1: the double-buffered, staggered 16x16x32 weight-gradient kernel (default 0: measured slower).
- *   "wgrad_wg1024" 2 (default): 16-wave workgroups for the weight-gradient launches that stay on the 32x32x16 kernel;
- *                 1: for the 16x16x32 kernel (measured slower); 0: 8 waves.
- *   "conv_wg1024" 1 (default): the 128- / 256-channel forward / dgrad instances run 16 waves per workgroup; 0: 8 waves;
- *                 2: 16 waves only for the 256-channel tile on multi-level pyramids.  Same results bit for bit.
+ *   "conv_v2"     1 (default): bf16x3 forward / data-gradient convs run on the v_mfma_f32_16x16x32_bf16 kernel
+ *                 (csrc/conv_fwd.hip); 0: on the independent v_mfma_f32_32x32x16_bf16 kernel kept for cross-checks
+ *                 (csrc/conv_bf16x3.hip; same arithmetic, different summation order inside a 32-channel chunk).
+ *   "conv_wg1024" (bf16x3) 1 (default): the 128- / 256-channel forward / dgrad instances run 16 waves per workgroup; 0: 8
+ *                 waves; 2: 16 waves only for the 256-channel tile on multi-level pyramids.  Same results bit for bit.
+ *   "conv_w8"     (bf16x3) 1 (default): the 256-channel LDS-DMA forward / dgrad tile runs on 8 waves (64 px x 128 ch per
+ *                 wave); 0: 16 waves.  Same results bit for bit.
+ *   "conv_tpb3"   (bf16x3) bit 0 (default on) / bit 1: the 128- / 64-channel instance stages three taps per barrier (same
+ *                 results bit for bit).
  *   "conv_bn64_th16" 1 (default): convs with <= 64 output channels on single-level pyramids whose sizes are multiples of
  *                 16 use 16x16-pixel tiles; 0: 8x16.  Same results bit for bit.
- *   "wgrad_wgs"   768 (default): workgroups a bf16x3 weight-gradient launch aims at (tiles x split-K slabs); swept again on
- *                 the second-generation kernel: 512 / 640 / 896 / 1024 / 1280 / 1536 are 2...25 % slower on the 256- and
- *                 512-channel layers.
+ *   "conv_glds"   1 (default): the 128- / 256-channel 3x3 instances stage weight tiles by LDS-DMA (buffer_load ... lds) on
+ *                 whole tiles; 0: through registers.  Same results bit for bit.
+ *   "wgrad_v6"    1 (default): the 3x3 weight-gradient launches take the producer / consumer kernel (12 waves: 8 issue
+ *                 MFMAs, 4 stage); 0: the kernel in which all 8 waves stage and multiply in turn (always used by the 1x1
+ *                 convs).  bf16x3: bit-identical; bf16x6: other K-chunk length, i.e. other split-K boundaries.
+ *   "wgrad_prio"  1 (default): the producer waves of that kernel run at s_setprio 3.
+ *   "wgrad_wgs"   768 (default): workgroups a weight-gradient launch aims at (tiles x split-K slabs); 512 / 640 / 896 / 1024
+ *                 / 1280 / 1536 are 2...25 % slower on the 256- and 512-channel layers (bf16x3).
  *   "gconv_mfma"  0 (default): the grouped class-branch conv runs on fp32 FMAs; 1: tap products and data gradient on the
  *                 fp32 matrix cores (same products, different summation order; measured no faster in the step).
- *   "conv_tpb3"   bit 0 (default on) / bit 1: the 128- / 64-channel instance stages three taps per barrier (same
- *                 results bit for bit).
- *   "wgrad_v4"    2 (default): every bf16x3 weight-gradient launch runs the fourth-generation kernel (wave-uniform chunk
- *                 walk in scalar registers, range-checked buffer loads with per-lane constant offsets: no per-chunk
- *                 address arithmetic or predication); 1: only the launches "wgrad_v2" sends to the 16x16x32 kernel
- *                 (bit-identical to it); 0: the round-2 kernels.
- *   "wgrad_il"    1 (default): that kernel issues the next K chunk's loads one per MFMA block inside the MFMA phase;
- *                 2 / 3: two / three per block; 0: together before the barrier.  Same results.
- *   "wgrad_v5"    1: the fourth generation's staging in the double-buffered, staggered structure of "wgrad_v3"
- *                 (default 0: measured slower).
- *   "wgrad_v6"    1 (default): the 3x3 launches take the producer / consumer sixth generation (12 waves: 8 issue MFMAs, 4
- *                 stage; bit-identical to "wgrad_v4"); "wgrad_prio" 1 (default): its producer waves run at s_setprio 3.
- *   "conv_exp"    1..4: timing ablations of the 256-channel forward instance (WRONG results; profiles/r03_conv_exp.txt).
- *   "conv_w8"     1 (default): the 256-channel LDS-DMA forward / dgrad tile runs on 8 waves (64 px x 128 ch per wave); 0: 16
- *                 waves.  Same results bit for bit.
  *   "dbscan_bf16x3" 1 (default): scan_dbscan_prepare's pairwise-distance GEMM runs as bf16x3 with a wider exact re-check
- *                 band; 0: exact fp32 matrix cores.  Same neighbour bits (pairs inside the band are decided in fp64).
- *   "wgrad_exp"   1..4: timing ablations of the second-generation kernel, 5..7 of the sixth (WRONG results;
- *                 profiles/r03_wgrad_exp.txt, r03_wgrad_v6_exp.txt).
- *   "conv_glds"   1 (default): the 16-wave 128- / 256-channel 3x3 instances stage weight tiles by LDS-DMA
- *                 (global_load_lds_dwordx4) on whole tiles; 0: through registers.  Same results bit for bit. */
+ *                 band; 0: exact fp32 matrix cores.  Same neighbour bits (pairs inside the band are decided in fp64). */
 int scan_tune(const char* key, int value);
 /* read-only: the current value of a knob (nothing is written), -1 for an unknown key */
 int scan_tune_get(const char* key);
 
 /* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels;
- * 1128 / 1256 = the 128- / 256-channel tile on 16-wave workgroups. */
+ * 1128 / 1256 = the 128- / 256-channel tile on 16-wave workgroups, 2256 = the 256-channel tile on the 8-wave LDS-DMA instance. */
 int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout);
-/* Which bf16x3 weight-gradient kernel a launch with input channel stride Cs takes: 2 = 16x16x32 MFMA, 1 = 32x32x16. */
-int scan_conv_wgrad_bf16x3_generation(int32_t Cs);
 
 /* ---- SigmoidFocalLoss  (replaces _C.sigmoid_focalloss_forward / _backward,
  *      csrc/SigmoidFocalLoss.h:10-41, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-187) ----
@@ -261,6 +245,46 @@ int scan_conv3x3_pool2_bf16x3(const float* x, const scan_pyramid_t* d, int32_t C
 int64_t scan_conv3x3_wgrad_bf16x3_ws_floats(const scan_pyramid_t* d, int32_t Cs, int32_t Cout);
 int scan_conv3x3_wgrad_bf16x3(const float* x, const scan_pyramid_t* d, int32_t Cs, const float* dy, int32_t Cout,
                               int32_t Cout_s, float* dw, float* db, int32_t accumulate, float* ws, void* stream);
+/* ---- the same convolutions at the reference's arithmetic on the bf16 matrix cores ("bf16x6") ----
+ * The reference multiplies fp32 by fp32 and accumulates in fp32 (torch.nn.Conv2d: backbone/mmdetection/vgg.py:8-33,
+ * backbone/fpn.py:52-66, rpn/fcos/condgraph.py:86-106, rpn/fcos/fcos.py:25-64,
+ * discriminator/fcos_head_discriminator_con.py:20-62).  Here every fp32 operand is cut into THREE bf16 pieces
+ * hi + mid + lo -- 8 + 8 + 8 = all 24 significand bits, the split is exact -- and a product is accumulated in fp32 from the
+ * six piece products hi*lo, mid*mid, lo*hi, hi*mid, mid*hi, hi*hi (smallest first); the three dropped products are
+ * <= 2^-23 of the product, below the rounding of the fp32 accumulation itself.  bf16 x bf16 is exact in fp32, so the result
+ * is an fp32 convolution up to summation order: measured against an fp64 convolution it is as close as the exact
+ * v_mfma_f32_32x32x2_f32 kernels of scan_conv2d_* (tests/test_gpu_kernels.py::test_conv_error_vs_fp64), on a pipe whose
+ * ceiling is 2.5 PFLOP/s / 6 = 417 TFLOP/s fp32-equivalent instead of 157.
+ * Arguments as for the _bf16x3 functions with a third plane: wh / wm / wl = scan_weight_split3 planes (same layout and
+ * modes as scan_weight_split).  y and mask must be 16-byte aligned, Ns % 4 == 0.
+ * scan_conv3x3_gn_bf16x6: clear != 0 zeroes gn_ws first (scan_conv3x3_gn_bf16x3), 0 adds to it (.._gn_acc_bf16x3). */
+int scan_weight_split3(const float* w, int32_t O, int32_t T, int32_t Cs, int32_t mode, void* wh, void* wm, void* wl,
+                       int32_t Csw, void* stream);
+int scan_conv3x3_bf16x6(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wm,
+                        const void* wl, int32_t Csw, const float* bias, const float* mask, float* y, int32_t Nout,
+                        int32_t Ns, int32_t relu, void* stream);
+int scan_conv1x1_bf16x6(const float* x, const scan_pyramid_t* xd, int32_t Cs, const void* wh, const void* wm,
+                        const void* wl, int32_t Csw, const float* bias, const float* mask, float* y,
+                        const scan_pyramid_t* yd, int32_t Nout, int32_t Ns, int32_t relu, int32_t map, void* stream);
+int scan_conv3x3_gn_bf16x6(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wm,
+                           const void* wl, int32_t Csw, const float* bias, float* y, int32_t Nout, int32_t Ns,
+                           float* gn_ws, int32_t clear, void* stream);
+int scan_conv3x3_pool2_bf16x6(const float* x, const scan_pyramid_t* d, int32_t Cs, const void* wh, const void* wm,
+                              const void* wl, int32_t Csw, const float* bias, float* y, int32_t Nout, int32_t Ns,
+                              int32_t relu, void* stream);
+int scan_conv_smallcin_bf16x6(const float* x, int32_t N, int32_t H, int32_t W, const float* w, const float* bias,
+                              float* y, int32_t Cout, int32_t Cout_s, int32_t ksize, int32_t stride, int32_t relu,
+                              void* stream);
+/* weight gradients: x and dy are split inside the kernel, no planes; Cout_s % 4 == 0 */
+int64_t scan_conv3x3_wgrad_bf16x6_ws_floats(const scan_pyramid_t* d, int32_t Cs, int32_t Cout);
+int scan_conv3x3_wgrad_bf16x6(const float* x, const scan_pyramid_t* d, int32_t Cs, const float* dy, int32_t Cout,
+                              int32_t Cout_s, float* dw, float* db, int32_t accumulate, float* ws, void* stream);
+int64_t scan_conv1x1_wgrad_bf16x6_ws_floats(const scan_pyramid_t* yd, int32_t Cs, int32_t Cout);
+int scan_conv1x1_wgrad_bf16x6(const float* x, const scan_pyramid_t* xd, int32_t Cs, const float* dy,
+                              const scan_pyramid_t* yd, int32_t Cout, int32_t Cout_s, int32_t stride, float* dw,
+                              float* db, int32_t accumulate, float* ws, void* stream);
+/* output-channel tile (64 / 128 / 256) a scan_conv3x3_bf16x6 launch on pyramid d with Nout channels takes */
+int scan_conv3x3_bf16x6_instance(const scan_pyramid_t* d, int32_t Nout);
 /* w [Cout][T][Cin_s] -> wt [Cin_s][T][Cout_s] (zero padded) */
 int scan_weight_transpose(const float* w, int32_t Cout, int32_t T, int32_t Cin_s, float* wt, int32_t Cout_s,
                           void* stream);
@@ -390,10 +414,11 @@ int scan_sgd_momentum_multi(const scan_sgd_segment_t* segs, int32_t n_segs, floa
 
 /* ---- bf16 hi / lo planes of many conv weights in one launch (same element mapping as scan_weight_split) ----
  * jobs: DEVICE array of n_jobs records of SCAN_SPLIT_JOB_WORDS int64: {w, wh, wl (device addresses), O, T, Cs, mode,
- * rows (= mode ? Cs : O), Csw, first_block}; first_block = running sum of scan_weight_split_job_blocks() over the jobs
+ * rows (= mode ? Cs : O), Csw, first_block, third plane or 0}; with a third plane the job is the three-piece split of
+ * scan_weight_split3 and {wh, wl, third} = its {wh, wm, wl}; first_block = running sum of scan_weight_split_job_blocks() over the jobs
  * before it, total_blocks the sum over all.  No reference counterpart (the reference convolves in fp32 through
  * cuDNN); it exists because a DA iteration re-splits ~120 weights after every optimizer step. */
-#define SCAN_SPLIT_JOB_WORDS 10
+#define SCAN_SPLIT_JOB_WORDS 11
 int64_t scan_weight_split_job_blocks(int32_t O, int32_t T, int32_t Cs, int32_t mode, int32_t Csw);
 int scan_weight_split_batched(const int64_t* jobs, int32_t n_jobs, int64_t total_blocks, void* stream);
 

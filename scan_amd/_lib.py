@@ -41,7 +41,7 @@ class CkaBranch(ctypes.Structure):
 
 SGD_MAX_SEGMENTS = 32
 CKA_MAX_CLASSES = 16
-SPLIT_JOB_WORDS = 10
+SPLIT_JOB_WORDS = 11
 
 # name -> (restype, argtypes); every symbol include/scan_hip.h declares
 SIGNATURES = {
@@ -54,7 +54,7 @@ SIGNATURES = {
     "scan_cond_rnn_backward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "scan_tune_get": (ctypes.c_int, [ctypes.c_char_p]),
     "scan_conv3x3_bf16x3_instance": (ctypes.c_int, [_PD, c_i32]),
-    "scan_conv_wgrad_bf16x3_generation": (ctypes.c_int, [c_i32]),
+    "scan_conv3x3_bf16x6_instance": (ctypes.c_int, [_PD, c_i32]),
     "scan_sigmoid_focal_loss_forward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp]),
     "scan_sigmoid_focal_loss_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp]),
     "scan_iou_loss_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_vp, c_vp]),
@@ -112,6 +112,21 @@ SIGNATURES = {
     "scan_conv1x1_wgrad_bf16x3": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, _PD, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp,
                                                  c_vp]),
     "scan_conv_smallcin_bf16x3": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                                 c_i32, c_vp]),
+    "scan_weight_split3": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp]),
+    "scan_conv3x3_bf16x6": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "scan_conv1x1_bf16x6": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, _PD, c_i32, c_i32, c_i32,
+                                           c_i32, c_vp]),
+    "scan_conv3x3_gn_bf16x6": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_vp, c_i32,
+                                              c_vp]),
+    "scan_conv3x3_pool2_bf16x6": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_i32, c_i32,
+                                                 c_vp]),
+    "scan_conv3x3_wgrad_bf16x6_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
+    "scan_conv3x3_wgrad_bf16x6": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "scan_conv1x1_wgrad_bf16x6_ws_floats": (c_i64, [_PD, c_i32, c_i32]),
+    "scan_conv1x1_wgrad_bf16x6": (ctypes.c_int, [c_vp, _PD, c_i32, c_vp, _PD, c_i32, c_i32, c_i32, c_vp, c_vp, c_i32, c_vp,
+                                                 c_vp]),
+    "scan_conv_smallcin_bf16x6": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
                                                  c_i32, c_vp]),
     "scan_maxpool3x3s2_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_upsample2x_add": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -5,10 +5,11 @@
 // weights are stacked into two fat convolutions.  Launched one tensor at a time these are ~400 kernels of 3-8 us that
 // sit on the critical path between the MFMA kernels (tools/gpu_idle.py: "exposed small-kernel time"); here each group
 // is ONE grid whose workgroups look their tensor up in a table.
-#include "common.h"
+#include "conv_split.h"
 
-// ------------------------------------------------------------------ bf16 hi / lo planes of many weights
-// job layout (int64 x SCAN_SPLIT_JOB_WORDS, device memory): w, wh, wl, O, T, Cs, mode, rows, Csw, first block
+// ------------------------------------------------------------------ bf16 planes of many weights
+// job layout (int64 x SCAN_SPLIT_JOB_WORDS, device memory): w, plane 0 (hi), plane 1, O, T, Cs, mode, rows, Csw, first
+// block, plane 2 (0: a two-piece split -- conv_split.h)
 //
 // HBM-bound byte work: 4 B read + 4 B written per plane element.  Both modes move 16 bytes per lane on the plane side
 // (8 bf16) and float4 on the weight side:
@@ -22,19 +23,21 @@
 // Same element arithmetic as weight_split_kernel (conv_bf16x3.hip): bit-identical planes.
 #define SPLIT_ELEMS_PER_BLOCK 2048
 #define SPLIT_TILE 64
-typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ void split8_store(const float (&v)[8], __bf16* __restrict__ wh, __bf16* __restrict__ wl,
-                                             int64_t i) {
-  bf16x8_t h, l;
+__device__ __forceinline__ void split8_store(const float (&v)[8], __bf16* __restrict__ w0, __bf16* __restrict__ w1,
+                                             __bf16* __restrict__ w2, int64_t i) {
+  bf16x8 q0, q1, q2;
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
-    const __bf16 hk = (__bf16)v[k];
-    h[k] = hk;
-    l[k] = (__bf16)(v[k] - (float)hk);
+    __bf16 q[3];
+    split1_np<3>(v[k], q);  // the first two pieces of a three-piece split ARE the two-piece split
+    q0[k] = q[0];
+    q1[k] = q[1];
+    q2[k] = q[2];
   }
-  *reinterpret_cast<bf16x8_t*>(wh + i) = h;
-  *reinterpret_cast<bf16x8_t*>(wl + i) = l;
+  *reinterpret_cast<bf16x8*>(w0 + i) = q0;
+  *reinterpret_cast<bf16x8*>(w1 + i) = q1;
+  if (w2 != nullptr) *reinterpret_cast<bf16x8*>(w2 + i) = q2;
 }
 
 __global__ __launch_bounds__(256) void weight_split_batched_kernel(const int64_t* __restrict__ jobs, int n_jobs) {
@@ -47,6 +50,7 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const int64_t
   const float* __restrict__ w = reinterpret_cast<const float*>(job[0]);
   __bf16* __restrict__ wh = reinterpret_cast<__bf16*>(job[1]);
   __bf16* __restrict__ wl = reinterpret_cast<__bf16*>(job[2]);
+  __bf16* __restrict__ w2 = reinterpret_cast<__bf16*>(job[10]);
   const int O = (int)job[3], T = (int)job[4], Cs = (int)job[5], mode = (int)job[6], rows = (int)job[7],
             Csw = (int)job[8];
   const int64_t blk = (int64_t)blockIdx.x - job[9];
@@ -69,7 +73,7 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const int64_t
 #pragma unroll
       for (int k = 0; k < 8; ++k) v[k] = (col + k < Cs) ? src[k] : 0.f;
     }
-    split8_store(v, wh, wl, i);
+    split8_store(v, wh, wl, w2, i);
     return;
   }
   // mode 1: block -> (tap tt of the OUTPUT, c tile, o tile)
@@ -109,7 +113,7 @@ __global__ __launch_bounds__(256) void weight_split_batched_kernel(const int64_t
         float v[8];
 #pragma unroll
         for (int k = 0; k < 8; ++k) v[k] = tile[o8 + k][cl + 32 * p];
-        split8_store(v, wh, wl, ((int64_t)c * T + tt) * Csw + o);
+        split8_store(v, wh, wl, w2, ((int64_t)c * T + tt) * Csw + o);
       }
     }
   }

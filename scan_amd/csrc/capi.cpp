@@ -20,48 +20,30 @@ extern "C" int scan_abi_version(void) { return 1; }
 // launch-selection knobs (scan_tune): defined next to the launch code that reads them
 extern int g_scan_conv_bn256;
 extern int g_scan_conv_v2;
-extern int g_scan_wgrad_v2;
 extern int g_scan_conv_wg1024;
 extern int g_scan_conv_w8;
-extern int g_scan_dbscan_bf16x3;
 extern int g_scan_conv_tpb3;
-extern int g_scan_wgrad_wg1024;
-extern int g_scan_wgrad_v3;
 extern int g_scan_conv_bn64_th16;
-extern int g_scan_gconv_mfma;
-extern int g_scan_wgrad_wgs;
 extern int g_scan_conv_glds;
-extern int g_scan_wgrad_exp;
-extern int g_scan_conv_exp;
-extern int g_scan_wgrad_v4;
-extern int g_scan_wgrad_v5;
-extern int g_scan_wgrad_il;
 extern int g_scan_wgrad_v6;
 extern int g_scan_wgrad_prio;
+extern int g_scan_wgrad_wgs;
+extern int g_scan_gconv_mfma;
+extern int g_scan_dbscan_bf16x3;
 
 static int* tune_slot(const char* key) {
-  int* slot = nullptr;
-  if (strcmp(key, "conv_bn256") == 0) slot = &g_scan_conv_bn256;
-  if (strcmp(key, "conv_v2") == 0) slot = &g_scan_conv_v2;
-  if (strcmp(key, "wgrad_v2") == 0) slot = &g_scan_wgrad_v2;
-  if (strcmp(key, "conv_wg1024") == 0) slot = &g_scan_conv_wg1024;
-  if (strcmp(key, "conv_w8") == 0) slot = &g_scan_conv_w8;
-  if (strcmp(key, "dbscan_bf16x3") == 0) slot = &g_scan_dbscan_bf16x3;
-  if (strcmp(key, "conv_tpb3") == 0) slot = &g_scan_conv_tpb3;
-  if (strcmp(key, "wgrad_wg1024") == 0) slot = &g_scan_wgrad_wg1024;
-  if (strcmp(key, "wgrad_v3") == 0) slot = &g_scan_wgrad_v3;
-  if (strcmp(key, "conv_bn64_th16") == 0) slot = &g_scan_conv_bn64_th16;
-  if (strcmp(key, "gconv_mfma") == 0) slot = &g_scan_gconv_mfma;
-  if (strcmp(key, "wgrad_wgs") == 0) slot = &g_scan_wgrad_wgs;
-  if (strcmp(key, "conv_glds") == 0) slot = &g_scan_conv_glds;
-  if (strcmp(key, "wgrad_exp") == 0) slot = &g_scan_wgrad_exp;
-  if (strcmp(key, "conv_exp") == 0) slot = &g_scan_conv_exp;
-  if (strcmp(key, "wgrad_v4") == 0) slot = &g_scan_wgrad_v4;
-  if (strcmp(key, "wgrad_v5") == 0) slot = &g_scan_wgrad_v5;
-  if (strcmp(key, "wgrad_il") == 0) slot = &g_scan_wgrad_il;
-  if (strcmp(key, "wgrad_v6") == 0) slot = &g_scan_wgrad_v6;
-  if (strcmp(key, "wgrad_prio") == 0) slot = &g_scan_wgrad_prio;
-  return slot;
+  static const struct {
+    const char* key;
+    int* slot;
+  } knobs[] = {
+      {"conv_bn256", &g_scan_conv_bn256},   {"conv_v2", &g_scan_conv_v2},         {"conv_wg1024", &g_scan_conv_wg1024},
+      {"conv_w8", &g_scan_conv_w8},         {"conv_tpb3", &g_scan_conv_tpb3},     {"conv_bn64_th16", &g_scan_conv_bn64_th16},
+      {"conv_glds", &g_scan_conv_glds},     {"wgrad_v6", &g_scan_wgrad_v6},       {"wgrad_prio", &g_scan_wgrad_prio},
+      {"wgrad_wgs", &g_scan_wgrad_wgs},     {"gconv_mfma", &g_scan_gconv_mfma},   {"dbscan_bf16x3", &g_scan_dbscan_bf16x3},
+  };
+  for (const auto& k : knobs)
+    if (strcmp(key, k.key) == 0) return k.slot;
+  return nullptr;
 }
 
 extern "C" int scan_tune(const char* key, int value) {

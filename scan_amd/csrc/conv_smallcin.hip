@@ -8,18 +8,16 @@
 //               LDS reads at (tap -> patch offset) addresses: im2col never exists in memory
 //   B operand   the whole weight matrix [64][K] is split once per workgroup into LDS (row pitch K+8: 16-byte reads of
 //               32 consecutive rows fall on distinct banks); workgroups are persistent over tiles to amortise it
-//   product     bf16x3 as in conv_bf16x3.hip (hi*hi + hi*lo + lo*hi, fp32 accumulate)
+//   product     split operands as in conv_split.h: NPC = 2 pieces ("bf16x3") or 3 ("bf16x6"), fp32 accumulate
 // HBM-bound by construction: 7x7/2 at 2 x 1024x2048 reads 67 MB and writes 268 MB; 3x3/1 writes 1.07 GB.
-#include "common.h"
+#include "conv_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
 #define SC_TH 8
 #define SC_TW 32
 
-template <int KS, int S>
+template <int NPC, int KS, int S>
 __global__ __launch_bounds__(256) void conv_smallcin_kernel(const float* __restrict__ x, int N, int H, int W,
                                                             const float* __restrict__ wgt,
                                                             const float* __restrict__ bias, float* __restrict__ y,
@@ -28,10 +26,8 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(const float* __restr
   constexpr int T = KS * KS, K = T * 4, KSTEPS = (K + 15) / 16, KP = KSTEPS * 16, BROW = KP + 8;
   constexpr int PH = (SC_TH - 1) * S + KS, PWD = (SC_TW - 1) * S + KS, NP = PH * PWD, PAD = KS / 2;
   extern __shared__ __align__(16) unsigned char smem_raw[];
-  __bf16* Bh = reinterpret_cast<__bf16*>(smem_raw);  // [64][BROW]
-  __bf16* Bl = Bh + 64 * BROW;
-  __bf16* Ah = Bl + 64 * BROW;                       // [NP][4]
-  __bf16* Al = Ah + NP * 4;
+  __bf16* Bs = reinterpret_cast<__bf16*>(smem_raw);  // [NPC piece][64][BROW]
+  __bf16* As = Bs + NPC * 64 * BROW;                 // [NPC piece][NP][4]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -39,9 +35,10 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(const float* __restr
   for (int i = tid; i < 64 * KP; i += 256) {
     const int o = i / KP, k = i - o * KP;
     const float v = (k < K && o < Nout) ? wgt[(int64_t)o * K + k] : 0.f;
-    const __bf16 h = (__bf16)v;
-    Bh[o * BROW + k] = h;
-    Bl[o * BROW + k] = (__bf16)(v - (float)h);
+    __bf16 q[NPC];
+    split1_np<NPC>(v, q);
+#pragma unroll
+    for (int p = 0; p < NPC; ++p) Bs[(p * 64 + o) * BROW + k] = q[p];
   }
 
   // per-step tap offsets of this lane's two taps (k = 16 step + 8 lh -> taps 4 step + 2 lh, +1), clamped into the
@@ -88,13 +85,10 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(const float* __restr
     for (int i = 0; i < NPR; ++i) {
       const int p = tid + 256 * i;
       if (p < NP) {
-        const float4 v = pre[i];
-        bf16x4 hi, lo;
-        hi[0] = (__bf16)v.x; hi[1] = (__bf16)v.y; hi[2] = (__bf16)v.z; hi[3] = (__bf16)v.w;
-        lo[0] = (__bf16)(v.x - (float)hi[0]); lo[1] = (__bf16)(v.y - (float)hi[1]);
-        lo[2] = (__bf16)(v.z - (float)hi[2]); lo[3] = (__bf16)(v.w - (float)hi[3]);
-        *reinterpret_cast<bf16x4*>(Ah + p * 4) = hi;
-        *reinterpret_cast<bf16x4*>(Al + p * 4) = lo;
+        bf16x4 pc[NPC];
+        split4_np<NPC>(pre[i], pc);
+#pragma unroll
+        for (int q = 0; q < NPC; ++q) *reinterpret_cast<bf16x4*>(As + (q * NP + p) * 4) = pc[q];
       }
     }
     if (tile + (int)gridDim.x < total_tiles) fetch(tile + gridDim.x);
@@ -112,32 +106,34 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(const float* __restr
     for (int tm = 0; tm < 2; ++tm) abase[tm] = ((2 * wid + tm) * S * PWD + lr * S) * 4;
 #pragma unroll
     for (int s = 0; s < KSTEPS; ++s) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
+      bf16x8 af[NPC][2], bf[NPC][2];
 #pragma unroll
-      for (int tm = 0; tm < 2; ++tm) {
-        const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(Ah + abase[tm] + toff[s][0]);
-        const bf16x4 h1 = *reinterpret_cast<const bf16x4*>(Ah + abase[tm] + toff[s][1]);
-        const bf16x4 l0 = *reinterpret_cast<const bf16x4*>(Al + abase[tm] + toff[s][0]);
-        const bf16x4 l1 = *reinterpret_cast<const bf16x4*>(Al + abase[tm] + toff[s][1]);
+      for (int q = 0; q < NPC; ++q)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          ah[tm][e] = h0[e]; ah[tm][4 + e] = h1[e];
-          al[tm][e] = l0[e]; al[tm][4 + e] = l1[e];
+        for (int tm = 0; tm < 2; ++tm) {
+          const bf16x4 h0 = *reinterpret_cast<const bf16x4*>(As + q * NP * 4 + abase[tm] + toff[s][0]);
+          const bf16x4 h1 = *reinterpret_cast<const bf16x4*>(As + q * NP * 4 + abase[tm] + toff[s][1]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            af[q][tm][e] = h0[e];
+            af[q][tm][4 + e] = h1[e];
+          }
         }
-      }
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn) {
-        bh[tn] = *reinterpret_cast<const bf16x8*>(Bh + (tn * 32 + lr) * BROW + 16 * s + 8 * lh);
-        bl[tn] = *reinterpret_cast<const bf16x8*>(Bl + (tn * 32 + lr) * BROW + 16 * s + 8 * lh);
-      }
+      for (int q = 0; q < NPC; ++q)
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn)
+          bf[q][tn] = *reinterpret_cast<const bf16x8*>(Bs + (q * 64 + tn * 32 + lr) * BROW + 16 * s + 8 * lh);
+      // piece products, smallest first; within a magnitude class the pixel piece index descends (lo * hi, hi * lo, hi * hi)
 #pragma unroll
       for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bl[tn], acc[tm][tn], 0, 0, 0);
-          acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[tm], bh[tn], acc[tm][tn], 0, 0, 0);
-        }
+        for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+          for (int d = NPC - 1; d >= 0; --d)
+#pragma unroll
+            for (int i = d; i >= 0; --i)
+              acc[tm][tn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][tm], bf[d - i][tn], acc[tm][tn], 0, 0, 0);
     }
     // C/D map of 32x32: col = lane & 31 (channel), row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) (pixel)
 #pragma unroll
@@ -160,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_smallcin_kernel(const float* __restr
   }
 }
 
-template <int KS, int S>
+template <int NPC, int KS, int S>
 static int launch_smallcin(const float* x, int N, int H, int W, const float* w, const float* bias, float* y, int Nout,
                            int Ns, int relu, hipStream_t st) {
   constexpr int T = KS * KS, K = T * 4, KP = ((K + 15) / 16) * 16, BROW = KP + 8;
@@ -168,29 +164,40 @@ static int launch_smallcin(const float* x, int N, int H, int W, const float* w, 
   const int Ho = (H + 2 * (KS / 2) - KS) / S + 1, Wo = (W + 2 * (KS / 2) - KS) / S + 1;
   const int tiles_x = (Wo + SC_TW - 1) / SC_TW, tiles_y = (Ho + SC_TH - 1) / SC_TH;
   const int total = N * tiles_x * tiles_y;
-  const size_t sh = (size_t)(2 * 64 * BROW + 2 * NP * 4) * sizeof(__bf16);
+  const size_t sh = (size_t)(NPC * 64 * BROW + NPC * NP * 4) * sizeof(__bf16);
   static bool done = false;
   if (!done) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_smallcin_kernel<KS, S>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(conv_smallcin_kernel<NPC, KS, S>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
     done = true;
   }
   const int grid = total < 1536 ? total : 1536;  // persistent: 6 workgroups' worth of tiles per CU
-  hipLaunchKernelGGL((conv_smallcin_kernel<KS, S>), dim3(grid), dim3(256), sh, st, x, N, H, W, w, bias, y, Ho, Wo, Nout,
+  hipLaunchKernelGGL((conv_smallcin_kernel<NPC, KS, S>), dim3(grid), dim3(256), sh, st, x, N, H, W, w, bias, y, Ho, Wo, Nout,
                      Ns, relu, tiles_x, tiles_y, total);
   SCAN_LAUNCH_CHECK("conv_smallcin");
   return 0;
 }
 
-extern "C" int scan_conv_smallcin_bf16x3(const float* x, int32_t N, int32_t H, int32_t W, const float* w,
-                                         const float* bias, float* y, int32_t Cout, int32_t Cout_s, int32_t ksize,
-                                         int32_t stride, int32_t relu, void* stream) {
+template <int NPC>
+static int smallcin_entry(const float* x, int32_t N, int32_t H, int32_t W, const float* w, const float* bias, float* y,
+                          int32_t Cout, int32_t Cout_s, int32_t ksize, int32_t stride, int32_t relu, void* stream) {
   SCAN_CHECK_ARG(x && w && y && N > 0 && H > 0 && W > 0, "conv_smallcin: bad arguments");
   SCAN_CHECK_ARG(Cout > 0 && Cout <= 64 && Cout_s >= Cout, "conv_smallcin: Cout=%d must be in 1..64 (Cout_s=%d)", Cout,
                  Cout_s);
   hipStream_t st = as_stream(stream);
-  if (ksize == 3 && stride == 1) return launch_smallcin<3, 1>(x, N, H, W, w, bias, y, Cout, Cout_s, relu, st);
-  if (ksize == 7 && stride == 2) return launch_smallcin<7, 2>(x, N, H, W, w, bias, y, Cout, Cout_s, relu, st);
+  if (ksize == 3 && stride == 1) return launch_smallcin<NPC, 3, 1>(x, N, H, W, w, bias, y, Cout, Cout_s, relu, st);
+  if (ksize == 7 && stride == 2) return launch_smallcin<NPC, 7, 2>(x, N, H, W, w, bias, y, Cout, Cout_s, relu, st);
   scan_set_error("conv_smallcin: only 3x3/1 and 7x7/2 are built (got %dx%d/%d)", ksize, ksize, stride);
   return -1;
+}
+
+extern "C" int scan_conv_smallcin_bf16x3(const float* x, int32_t N, int32_t H, int32_t W, const float* w,
+                                         const float* bias, float* y, int32_t Cout, int32_t Cout_s, int32_t ksize,
+                                         int32_t stride, int32_t relu, void* stream) {
+  return smallcin_entry<2>(x, N, H, W, w, bias, y, Cout, Cout_s, ksize, stride, relu, stream);
+}
+extern "C" int scan_conv_smallcin_bf16x6(const float* x, int32_t N, int32_t H, int32_t W, const float* w,
+                                         const float* bias, float* y, int32_t Cout, int32_t Cout_s, int32_t ksize,
+                                         int32_t stride, int32_t relu, void* stream) {
+  return smallcin_entry<3>(x, N, H, W, w, bias, y, Cout, Cout_s, ksize, stride, relu, stream);
 }

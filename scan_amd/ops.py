@@ -164,9 +164,19 @@ def unpack_weight_grad(dw, weight):
     return dw[:, :, :ci].reshape(co, kh, kw, ci).permute(0, 3, 1, 2)
 
 
-# "bf16x3": 3x3/stride-1 convs run on the bf16 matrix cores with hi/lo operand splitting (fp32-grade accuracy,
-# ~5x the fp32-MFMA rate); "fp32": everything on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain).
-CONV_MODE = "bf16x3"
+# How the 3x3 / stride-1 and 1x1 convolutions multiply (csrc/conv_split.h):
+#   "bf16x6" (default): on the bf16 matrix cores with every fp32 operand cut into THREE bf16 pieces (all 24 significand
+#            bits) and six piece products per product -- the reference's fp32 multiply / fp32 accumulate up to summation order;
+#   "bf16x3": two pieces (16 significand bits per operand), three piece products: 2e-6 on the losses of a DA iteration, 2x
+#            the rate of bf16x6;
+#   "fp32":  everything on v_mfma_f32_32x32x2_f32 (bit-for-bit an fp32 fma chain), the slowest.
+CONV_MODE = "bf16x6"
+SPLIT_MODES = {"bf16x6": 3, "bf16x3": 2}
+
+
+def split_pieces():
+    """bf16 pieces per fp32 operand in the current CONV_MODE (0: the exact fp32-MFMA kernels)."""
+    return SPLIT_MODES.get(CONV_MODE, 0)
 
 
 def _round32(c):
@@ -222,17 +232,17 @@ class SplitPlan:
     begin_weight_epoch(plan) re-splits ALL of them with ONE launch (scan_weight_split_batched) into the same buffers
     -- ~120 launches of 3-8 us on the critical path become one.  A job holds only a weak reference to its parameter:
     it is dropped when the parameter dies, and a weight that stops matching (another model at the same address) misses
-    on the shape test in _conv3x3_bf16x3 and replaces its job."""
+    on the shape test in _conv_split and replaces its job."""
 
     def __init__(self):
-        self.jobs = {}     # (data_ptr, mode, csw) -> (weakref to the parameter, O, T, cs_w, mode, rows, csw, wh, wl)
+        self.jobs = {}     # (data_ptr, mode, csw, pieces) -> (weakref to the parameter, O, T, cs_w, mode, rows, csw, planes)
         self.table = None  # device int64 [n_jobs, SPLIT_JOB_WORDS]
         self.order = []
         self.blocks = 0
         self.dirty = True
 
-    def add(self, key, param, O, T, cs_w, mode, rows, csw, wh, wl):
-        self.jobs[key] = (weakref.ref(param), O, T, cs_w, mode, rows, csw, wh, wl)
+    def add(self, key, param, O, T, cs_w, mode, rows, csw, planes):
+        self.jobs[key] = (weakref.ref(param), O, T, cs_w, mode, rows, csw, planes)
         self.dirty = True
 
     def run(self):
@@ -247,10 +257,11 @@ class SplitPlan:
             rows, off = [], 0
             self.order = list(self.jobs.keys())
             for k in self.order:
-                _, O, T, cs_w, mode, r, csw, wh, wl = self.jobs[k]
-                rows.append([k[0], wh.data_ptr(), wl.data_ptr(), O, T, cs_w, mode, r, csw, off])
+                _, O, T, cs_w, mode, r, csw, planes = self.jobs[k]
+                rows.append([k[0], planes[0].data_ptr(), planes[1].data_ptr(), O, T, cs_w, mode, r, csw, off,
+                             planes[2].data_ptr() if len(planes) == 3 else 0])
                 off += query("scan_weight_split_job_blocks", O, T, cs_w, mode, csw)
-            dev = self.jobs[self.order[0]][7].device
+            dev = self.jobs[self.order[0]][7][0].device
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
             self.blocks = off
             self.dirty = False
@@ -258,8 +269,7 @@ class SplitPlan:
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         for k in self.order:
-            j = self.jobs[k]
-            _split_cache[k] = (SPLIT_EPOCH, j[7], j[8], ev)
+            _split_cache[k] = (SPLIT_EPOCH, self.jobs[k][7], ev)
 
 
 # GroupNorm workspaces (fp64 sums the kernels accumulate into with atomics) must start at zero.  Cleared one by one that is a
@@ -347,11 +357,14 @@ def invalidate_weight_planes():
 _gn_sums = {}
 
 
-def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None,
-                    mask=None, dst_shape=None, cmap=0, pool=False, gn_sums=False, param=None, out=None):
-    """wp: packed fp32 weights [O][T][Cs_w], T = 9 (3x3 / stride 1) or 1 (1x1; dst_shape = output pyramid, cmap =
-    scan_conv1x1_bf16x3's map).  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
+def _conv_split(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name, flops, cache_key=None,
+                mask=None, dst_shape=None, cmap=0, pool=False, gn_sums=False, param=None, out=None, pieces=None):
+    """Forward / data gradient of a 3x3 / stride-1 or 1x1 conv on the bf16 matrix cores with split operands (pieces = 3:
+    "bf16x6", 2: "bf16x3"; default: the current CONV_MODE).  wp: packed fp32 weights [O][T][Cs_w], T = 9 or 1 (1x1; dst_shape = output pyramid, cmap =
+    scan_conv1x1_*'s map).  mode 0: forward (Nout = O); mode 1: dgrad (Nout = Cs_w)."""
     st = _stream()
+    npc = pieces or split_pieces()
+    sfx = "bf16x6" if npc == 3 else "bf16x3"
     O, T, cs_w = wp.shape
     # plane rows are zero-padded to whole 32-channel K chunks for the 3x3 kernels: the LDS-DMA weight path needs whole
     # chunks (a 264-channel input then takes it too); 1x1 planes keep the 8-element granule
@@ -362,43 +375,51 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
         rows, csw, nout = cs_w, rnd(max(O, cs_src)), cs_w
     hit = None
     if cache_key is not None and SPLIT_EPOCH is not None:
-        key = (cache_key, mode, csw)
+        key = (cache_key, mode, csw, npc)
         hit = _split_cache.get(key)
-        if hit is not None and (hit[0] != SPLIT_EPOCH or tuple(hit[1].shape) != (rows, T, csw)):
+        if hit is not None and (hit[0] != SPLIT_EPOCH or tuple(hit[1][0].shape) != (rows, T, csw)):
             hit = None
     if hit is not None:
-        wh, wl = hit[1], hit[2]
+        planes = hit[1]
         # planes written on another stream (e.g. the target pass on its side stream) must be complete
-        torch.cuda.current_stream().wait_event(hit[3])
+        torch.cuda.current_stream().wait_event(hit[2])
     else:
-        wh = torch.empty((rows, T, csw), dtype=torch.bfloat16, device=x.device)
-        wl = torch.empty_like(wh)
-        call("scan_weight_split", _ptr(wp), O, T, cs_w, mode, _ptr(wh), _ptr(wl), csw, st)
+        planes = tuple(torch.empty((rows, T, csw), dtype=torch.bfloat16, device=x.device) for _ in range(npc))
+        if npc == 3:
+            call("scan_weight_split3", _ptr(wp), O, T, cs_w, mode, _ptr(planes[0]), _ptr(planes[1]), _ptr(planes[2]), csw, st)
+        else:
+            call("scan_weight_split", _ptr(wp), O, T, cs_w, mode, _ptr(planes[0]), _ptr(planes[1]), csw, st)
         if cache_key is not None and SPLIT_EPOCH is not None:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
-            _split_cache[(cache_key, mode, csw)] = (SPLIT_EPOCH, wh, wl, ev)
+            _split_cache[(cache_key, mode, csw, npc)] = (SPLIT_EPOCH, planes, ev)
             if _active_plan is not None and param is not None and wp.data_ptr() == cache_key == param.data_ptr():
-                _active_plan.add((cache_key, mode, csw), param, O, T, cs_w, mode, rows, csw, wh, wl)
+                _active_plan.add((cache_key, mode, csw, npc), param, O, T, cs_w, mode, rows, csw, planes)
+    wptrs = [_ptr(t) for t in planes]
     y = out if out is not None else (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
     if kernel_timer.enabled:  # label the record with the template instance the launch takes (64 / 128 / 256 channels)
-        inst = query("scan_conv3x3_bf16x3_instance", (dst_shape or shape).ref(), nout) if T == 9 else (128 if nout > 64 else 64)
+        inst = query("scan_conv3x3_%s_instance" % sfx, (dst_shape or shape).ref(), nout) if T == 9 else (128 if nout > 64 else 64)
         ev = kernel_timer.begin("%s_bn%d" % (name, inst), flops)
     else:
         ev = None
     if gn_sums:
         sums, cleared = _ws_f64(shape.n_levels * shape.n_images * 32 * 2, x.device)
-        call("scan_conv3x3_gn_acc_bf16x3" if cleared else "scan_conv3x3_gn_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(y), nout,
-             ns, _ptr(sums), st)
+        if npc == 3:
+            call("scan_conv3x3_gn_bf16x6", _ptr(x), shape.ref(), cs_src, *wptrs, csw, _ptr(bias), _ptr(y), nout, ns,
+                 _ptr(sums), 0 if cleared else 1, st)
+        else:
+            call("scan_conv3x3_gn_acc_bf16x3" if cleared else "scan_conv3x3_gn_bf16x3", _ptr(x), shape.ref(), cs_src, *wptrs, csw,
+                 _ptr(bias), _ptr(y), nout, ns, _ptr(sums), st)
         _gn_sums.clear()  # at most one pending hand-over: conv and its GroupNorm are adjacent calls of one thread
         _gn_sums[y.data_ptr()] = sums
     elif pool:
-        call("scan_conv3x3_pool2_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(y),
+        call("scan_conv3x3_pool2_" + sfx, _ptr(x), shape.ref(), cs_src, *wptrs, csw, _ptr(bias), _ptr(y),
              nout, ns, int(bool(relu)), st)
     elif T == 1:
-        call("scan_conv1x1_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
+        call("scan_conv1x1_" + sfx, _ptr(x), shape.ref(), cs_src, *wptrs, csw, _ptr(bias), _ptr(mask),
              _ptr(y), (dst_shape or shape).ref(), nout, ns, int(bool(relu)), cmap, st)
     else:
+        fn = "scan_conv3x3_" + sfx
         rem = nout % 128
         if nout > 128 and 0 < rem <= 64 and cs_src >= 512 and rows_out >= 100000:
             # 128-wide output tiles plus a small remainder (data gradient of the 264-channel discriminator input at
@@ -410,14 +431,13 @@ def _conv3x3_bf16x3(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, 
             def off(t, nbytes):
                 return ctypes.c_void_p(t.data_ptr() + nbytes) if t is not None else ctypes.c_void_p(0)
 
-            call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
-                 _ptr(y), main, ns, int(bool(relu)), st)
-            call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, off(wh, main * T * csw * 2),
-                 off(wl, main * T * csw * 2), csw, off(bias, main * 4), off(mask, main * 4), off(y, main * 4), rem, ns,
+            call(fn, _ptr(x), shape.ref(), cs_src, *wptrs, csw, _ptr(bias), _ptr(mask), _ptr(y), main, ns,
                  int(bool(relu)), st)
+            call(fn, _ptr(x), shape.ref(), cs_src, *[off(t, main * T * csw * 2) for t in planes], csw, off(bias, main * 4),
+                 off(mask, main * 4), off(y, main * 4), rem, ns, int(bool(relu)), st)
         else:
-            call("scan_conv3x3_bf16x3", _ptr(x), shape.ref(), cs_src, _ptr(wh), _ptr(wl), csw, _ptr(bias), _ptr(mask),
-                 _ptr(y), nout, ns, int(bool(relu)), st)
+            call(fn, _ptr(x), shape.ref(), cs_src, *wptrs, csw, _ptr(bias), _ptr(mask), _ptr(y), nout, ns,
+                 int(bool(relu)), st)
     kernel_timer.end(ev)
     return y
 
@@ -446,17 +466,18 @@ class _Conv2d(torch.autograd.Function):
                             and tuple(out.shape) == (oshape.rows, cout_s) and cout_s == cout):
                 raise RuntimeError("conv2d(out=...): needs a contiguous fp32 [%d, %d] GPU block with Cout == Cout_s"
                                    % (oshape.rows, cout_s))
-        fast = CONV_MODE == "bf16x3" and ((ksize == 3 and stride == 1) or ksize == 1)
+        fast = split_pieces() > 0 and ((ksize == 3 and stride == 1) or ksize == 1)
+        tag = CONV_MODE  # kernel_timer labels
         flops = 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1]
         ckey = weight.data_ptr() if getattr(weight, "_scan_flat", False) else None
         # first layer (3 input channels): dedicated K = taps x 4 forward kernel (the backward, if any, is generic)
-        first = CONV_MODE == "bf16x3" and cs == 4 and cout <= 64 and (ksize, stride) in ((3, 1), (7, 2)) \
+        first = split_pieces() > 0 and cs == 4 and cout <= 64 and (ksize, stride) in ((3, 1), (7, 2)) \
             and shape.n_levels == 1
         if first:
             (h, w_), n = shape.sizes[0], shape.n_images
             y = out if out is not None else (x.new_zeros if cout_s != cout else x.new_empty)((oshape.rows, cout_s))
-            ev = kernel_timer.begin("conv_smallcin_bf16x3", flops)
-            call("scan_conv_smallcin_bf16x3", _ptr(x), n, h, w_, _ptr(wp), _ptr(bias), _ptr(y), cout, cout_s, ksize,
+            ev = kernel_timer.begin("conv_smallcin_" + tag, flops)
+            call("scan_conv_smallcin_" + tag, _ptr(x), n, h, w_, _ptr(wp), _ptr(bias), _ptr(y), cout, cout_s, ksize,
                  stride, int(bool(relu)), _stream())
             kernel_timer.end(ev)
         elif fast:
@@ -464,11 +485,11 @@ class _Conv2d(torch.autograd.Function):
                 if ksize != 3 or shape.n_levels != 1:
                     raise RuntimeError("conv2d(pool=True) needs a 3x3 conv on a single-level pyramid")
                 (h, w_) = shape.sizes[0]
-                y = _conv3x3_bf16x3(x, shape, wp, cout, shape.n_images * (h // 2) * (w_ // 2), cs, 0, bias, relu, cout_s,
-                                    "conv3x3_bf16x3_fwd", flops, cache_key=ckey, pool=True, param=weight)
+                y = _conv_split(x, shape, wp, cout, shape.n_images * (h // 2) * (w_ // 2), cs, 0, bias, relu, cout_s,
+                                    "conv3x3_%s_fwd" % tag, flops, cache_key=ckey, pool=True, param=weight)
             else:
-                y = _conv3x3_bf16x3(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s,
-                                    "conv3x3_bf16x3_fwd" if ksize == 3 else "conv1x1_bf16x3_fwd", flops,
+                y = _conv_split(x, shape, wp, cout, oshape.rows, cs, 0, bias, relu, cout_s,
+                                    ("conv3x3_%s_fwd" if ksize == 3 else "conv1x1_%s_fwd") % tag, flops,
                                     cache_key=ckey, dst_shape=oshape, cmap=stride - 1, param=weight,
                                     gn_sums=gn_sums and ksize == 3 and cout == 256 and cout_s == 256 and not relu,
                                     out=out)
@@ -480,6 +501,7 @@ class _Conv2d(torch.autograd.Function):
             kernel_timer.end(ev)
         ctx.save_for_backward(x, weight, y if relu is True else None)
         ctx.cfg = (shape, oshape, ksize, stride, relu, cout_s, bias is not None, fast)
+        ctx.conv_mode = CONV_MODE  # the backward runs on the kernels of the mode the forward ran in
         ctx.mask_dx = mask_dx
         ctx.ckey = ckey
         # parameters re-homed into a flat gradient buffer (engine.FlatGroup): accumulate straight into it
@@ -499,6 +521,7 @@ class _Conv2d(torch.autograd.Function):
         cout, cin = weight.shape[0], weight.shape[1]
         T = ksize * ksize
         st = _stream()
+        sfx = ctx.conv_mode if ctx.conv_mode in SPLIT_MODES else "bf16x3"
         dy = dy.contiguous()
         if relu is True:
             g = torch.empty_like(dy)
@@ -507,10 +530,10 @@ class _Conv2d(torch.autograd.Function):
         dx = dw = db = None
         mask = x if ctx.mask_dx else None  # x is a deferred-ReLU output: dx *= (x > 0) in the dgrad epilogue
         if ctx.needs_input_grad[0] and fast:
-            dx = _conv3x3_bf16x3(dy, oshape, pack_weight(weight, cs), cout, x.shape[0], cout_s, 1, None, False, cs,
-                                 "conv3x3_bf16x3_dgrad" if ksize == 3 else "conv1x1_bf16x3_dgrad",
+            dx = _conv_split(dy, oshape, pack_weight(weight, cs), cout, x.shape[0], cout_s, 1, None, False, cs,
+                                 ("conv3x3_%s_dgrad" if ksize == 3 else "conv1x1_%s_dgrad") % sfx,
                                  2.0 * oshape.rows * cout * T * cin, cache_key=ctx.ckey, mask=mask, dst_shape=shape,
-                                 cmap=0 if stride == 1 else 2, param=weight)
+                                 cmap=0 if stride == 1 else 2, param=weight, pieces=SPLIT_MODES[sfx])
         elif ctx.needs_input_grad[0]:
             wp = pack_weight(weight, cs)
             wt = x.new_empty((cs, T, cout_s))
@@ -531,14 +554,13 @@ class _Conv2d(torch.autograd.Function):
                 x.record_stream(side)
                 dy.record_stream(side)
             with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                ws = x.new_empty((query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),))
+                ws = x.new_empty((query("scan_conv3x3_wgrad_%s_ws_floats" % sfx, shape.ref(), cs, cout),))
                 dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
-                ev = kernel_timer.begin("conv3x3_bf16x3_wgrad_g%d" % query("scan_conv_wgrad_bf16x3_generation", cs)
-                                        if kernel_timer.enabled else "", 2.0 * oshape.rows * cout * T * cin)
+                ev = kernel_timer.begin("conv3x3_%s_wgrad" % sfx, 2.0 * oshape.rows * cout * T * cin)
                 if want_db:
                     db = ctx.bgrad_buf if direct_b else x.new_empty((cout,))
                     db_done = True
-                call("scan_conv3x3_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), cout, cout_s, _ptr(dwp),
+                call("scan_conv3x3_wgrad_" + sfx, _ptr(x), shape.ref(), cs, _ptr(dy), cout, cout_s, _ptr(dwp),
                      _ptr(db) if want_db else None, int(direct_w), _ptr(ws), _stream())
                 kernel_timer.end(ev)
             if want_db and direct_w and not direct_b:
@@ -547,15 +569,14 @@ class _Conv2d(torch.autograd.Function):
             if direct_b:
                 db = None
         elif ctx.needs_input_grad[1] and fast:  # 1x1, stride 1 or 2
-            ws = x.new_empty((query("scan_conv1x1_wgrad_bf16x3_ws_floats", oshape.ref(), cs, cout),))
+            ws = x.new_empty((query("scan_conv1x1_wgrad_%s_ws_floats" % sfx, oshape.ref(), cs, cout),))
             dwp = ctx.wgrad_buf if direct_w else x.new_empty((cout, T, cs))
-            ev = kernel_timer.begin("conv1x1_bf16x3_wgrad_g%d" % query("scan_conv_wgrad_bf16x3_generation", cs)
-                                    if kernel_timer.enabled else "", 2.0 * oshape.rows * cout * T * cin)
+            ev = kernel_timer.begin("conv1x1_%s_wgrad" % sfx, 2.0 * oshape.rows * cout * T * cin)
             want_db = has_bias and ctx.needs_input_grad[2]
             if want_db:
                 db = ctx.bgrad_buf if direct_b else x.new_empty((cout,))
                 db_done = True
-            call("scan_conv1x1_wgrad_bf16x3", _ptr(x), shape.ref(), cs, _ptr(dy), oshape.ref(), cout, cout_s, stride,
+            call("scan_conv1x1_wgrad_" + sfx, _ptr(x), shape.ref(), cs, _ptr(dy), oshape.ref(), cout, cout_s, stride,
                  _ptr(dwp), _ptr(db) if want_db else None, int(direct_w), _ptr(ws), st)
             kernel_timer.end(ev)
             if want_db and direct_w and not direct_b:
@@ -602,7 +623,7 @@ def conv_pool_fusable(x, weight, bias, shape):
     (h, w_) = shape.sizes[0]
     needs = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad
                                          or (bias is not None and bias.requires_grad))
-    return (CONV_MODE == "bf16x3" and shape.n_levels == 1 and h % 2 == 0 and w_ % 2 == 0 and x.shape[1] != 4
+    return (split_pieces() > 0 and shape.n_levels == 1 and h % 2 == 0 and w_ % 2 == 0 and x.shape[1] != 4
             and tuple(weight.shape[2:]) == (3, 3) and not needs)
 
 

@@ -3,7 +3,10 @@
 step), with HIP events on the launch stream, variants selected through scan_tune.  Each variant's output is compared
 with the first one's (they must agree bit for bit: the K order per output element is the same).
 
-    python tools/conv_bench.py [--reps 5] [--variants conv_bn256=0,conv_bn256=1]
+    python tools/conv_bench.py [--op fwd|dgrad|wgrad] [--mode bf16x6|bf16x3|fp32] [--reps 5] [--variants conv_bn256=0,conv_bn256=1]
+
+--op dgrad: the data gradient (the forward kernel on dY with flipped planes) through autograd's backward with the weight
+frozen.  TF = fp32-equivalent TFLOP/s; ceilings: bf16x6 416.7, bf16x3 833.3, fp32 157.3.
 """
 import argparse
 import os
@@ -56,6 +59,33 @@ def run(shape_def, reps, dev):
     return y, us, flops / us * 1e-6
 
 
+def run_dgrad(shape_def, reps, dev):
+    name, n, sizes, cin, cout = shape_def
+    shape = ops.PyramidShape(n, sizes)
+    g = torch.Generator(device=dev).manual_seed(0)
+    x = torch.randn((shape.rows, ops.pad4(cin)), device=dev, generator=g).requires_grad_(True)
+    w = (torch.randn((cout, cin, 3, 3), device=dev, generator=g) * 0.05).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn((shape.rows, cout), device=dev, generator=g)
+    flops = 2.0 * shape.rows * cout * 9 * cin
+    y = ops.conv2d(x, w, None, shape, 3, 1)
+
+    def go():
+        x.grad = None
+        y.backward(dy, retain_graph=True)
+
+    go()
+    torch.cuda.synchronize()
+    ops.kernel_timer.enabled = True
+    ops.kernel_timer.reset()
+    for _ in range(reps):
+        go()
+    torch.cuda.synchronize()
+    ops.kernel_timer.enabled = False
+    rec = [r for k, r in ops.kernel_timer.summary().items() if "dgrad" in k][0]
+    us = rec["total_ms"] * 1e3 / rec["launches"]
+    return x.grad.clone(), us, flops / us * 1e-6
+
+
 def run_wgrad(shape_def, reps, dev):
     name, n, sizes, cin, cout = shape_def
     shape = ops.PyramidShape(n, sizes)
@@ -65,12 +95,20 @@ def run_wgrad(shape_def, reps, dev):
     dy = torch.randn((shape.rows, cout), device=dev, generator=g)
     dw = torch.empty((cout, 9, cs), device=dev)
     db = torch.empty((cout,), device=dev)
-    ws = torch.empty((_lib.query("scan_conv3x3_wgrad_bf16x3_ws_floats", shape.ref(), cs, cout),), device=dev)
+    sfx = ops.CONV_MODE
+    if sfx == "fp32":
+        ws = torch.empty((_lib.query("scan_conv2d_wgrad_ws_floats", shape.ref(), cs, cout, 3),), device=dev)
+    else:
+        ws = torch.empty((_lib.query("scan_conv3x3_wgrad_%s_ws_floats" % sfx, shape.ref(), cs, cout),), device=dev)
     flops = 2.0 * shape.rows * cout * 9 * cin
 
     def go():
-        _lib.call("scan_conv3x3_wgrad_bf16x3", ops._ptr(x), shape.ref(), cs, ops._ptr(dy), cout, cout, ops._ptr(dw),
-                  ops._ptr(db), 0, ops._ptr(ws), ops._stream())
+        if sfx == "fp32":
+            _lib.call("scan_conv2d_wgrad", ops._ptr(x), shape.ref(), cs, ops._ptr(dy), shape.ref(), cout, cout, 3, 1,
+                      ops._ptr(dw), 0, ops._ptr(ws), ops._stream())
+        else:
+            _lib.call("scan_conv3x3_wgrad_" + sfx, ops._ptr(x), shape.ref(), cs, ops._ptr(dy), cout, cout, ops._ptr(dw),
+                      ops._ptr(db), 0, ops._ptr(ws), ops._stream())
 
     go()
     torch.cuda.synchronize()
@@ -86,14 +124,19 @@ def run_wgrad(shape_def, reps, dev):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--op", choices=("fwd", "wgrad"), default="fwd")
+    ap.add_argument("--op", choices=("fwd", "dgrad", "wgrad"), default="fwd")
+    ap.add_argument("--mode", choices=("bf16x6", "bf16x3", "fp32"), default="bf16x6")
+    ap.add_argument("--shapes", default="", help="comma-separated substrings selecting rows of SHAPES")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--variants", default="conv_bn256=0,conv_bn256=1")
     a = ap.parse_args()
     dev = torch.device("cuda:0")
+    ops.CONV_MODE = a.mode
+    print("op %s  mode %s" % (a.op, a.mode), flush=True)
+    shapes = [sd for sd in SHAPES if not a.shapes or any(t in sd[0] for t in a.shapes.split(","))]
     variants = [(v, "") for v in a.variants.split(",")]  # each variant: "key=value" or "key=value+key=value"
-    for sd in SHAPES:
+    for sd in shapes:
         ref = None
         line = "%-44s" % sd[0]
         best = {}
@@ -104,7 +147,7 @@ def main():
                     k, v = kv.split("=")
                     olds.append((k, _lib.query("scan_tune", k.encode(), int(v))))
                     assert olds[-1][1] >= 0, k
-                y, us, tf = (run if a.op == "fwd" else run_wgrad)(sd, a.reps, dev)
+                y, us, tf = {"fwd": run, "dgrad": run_dgrad, "wgrad": run_wgrad}[a.op](sd, a.reps, dev)
                 for k, o in olds:
                     _lib.query("scan_tune", k.encode(), o)
                 if ref is None:

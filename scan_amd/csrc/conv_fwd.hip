@@ -60,7 +60,8 @@ __device__ __forceinline__ void mma_pieces(const bf16x8 (&w)[NP], const bf16x8 (
 // GL: the weight tiles go global -> LDS by LDS-DMA (buffer_load ... lds) instead of through registers: no staging
 // registers, no ds_write pass, and the next tap's tile is in flight while the matrix cores work on the current one (the
 // slot swizzle moves to the per-lane SOURCE address: the DMA writes a wave's 64 x 16 bytes contiguously).  Needs whole
-// tiles: Nout % BN == 0 and Csw % 32 == 0 (masked lanes would leave stale LDS behind).
+// K chunks (Csw % 32 == 0).  Rows beyond Nout in the last channel tile lie beyond the plane, i.e. beyond the buffer
+// descriptor's num_records: the range check returns zeros for them, which is what the DMA writes.
 template <int NP, int BN, int TH, int NT, int KS, int TPB = 1, bool GL = false>
 __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
     const float* __restrict__ src, scan_pyramid_t d, int Cs, const __bf16* __restrict__ w0, const __bf16* __restrict__ w1,
@@ -77,12 +78,13 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
   constexpr int TM = TH / WM_WAVES;             // 16-pixel tile rows per wave
   constexpr int TN = BN / (16 * WN_WAVES);      // 16-channel tiles per wave (4, or 8 for BN = 256)
   constexpr int ASLOTS = (NPATCH * 8 + NT - 1) / NT;  // float4 of the halo patch per thread per chunk
-  constexpr int BSEG = BN * 4 * NP / NT;              // 16-byte weight segments per thread per (chunk, tap)
+  constexpr int BSLOTS = BN * 4 * NP;                 // 16-byte weight segments per (chunk, tap)
+  constexpr int BSEG = (BSLOTS + NT - 1) / NT;        // ... per thread
   constexpr int NGRP = NTAPS / TPB;                   // barrier intervals per chunk
   static_assert(NP == 2 || NP == 3, "two or three pieces per operand");
   static_assert(TM * WM_WAVES == TH && (TM % 2) == 0, "tile rows must split evenly (and pair up for the fused pool)");
   static_assert(NTAPS % TPB == 0, "taps per barrier must divide the tap count");
-  static_assert(BSEG * NT == BN * 4 * NP, "weight segments must divide evenly over the threads");
+  static_assert(BSLOTS % 64 == 0, "a wave's 64 weight segments lie in one plane (and past the end only as a whole wave)");
 
   extern __shared__ __align__(16) unsigned char smem_raw[];
   __bf16* As = reinterpret_cast<__bf16*>(smem_raw);  // [NP plane][NPATCH][32]
@@ -185,8 +187,9 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
         const int row = rem >> 2, seg = rem & 3;
         const int o = n0 + row, c = cc * V2_CK + 8 * seg;
         const __bf16* base = plane == 0 ? w0 : (plane == 1 ? w1 : w2);
-        rb[tt][i] = (o < Nout && c < Csw) ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * NTAPS + tap) * Csw + c)
-                                          : make_uint4(0u, 0u, 0u, 0u);
+        rb[tt][i] = (slot < BSLOTS && o < Nout && c < Csw)
+                        ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * NTAPS + tap) * Csw + c)
+                        : make_uint4(0u, 0u, 0u, 0u);
       }
     }
   };
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
         const int plane = slot / (BN * 4);
         const int rem = slot - plane * BN * 4;
         const int row = rem >> 2, seg = rem & 3;
-        *reinterpret_cast<uint4*>(Bs + (((buf * TPB + tt) * NP + plane) * BN + row) * 32 + ((seg ^ swz(row)) << 3)) = rb[tt][i];
+        if (slot < BSLOTS)
+          *reinterpret_cast<uint4*>(Bs + (((buf * TPB + tt) * NP + plane) * BN + row) * 32 + ((seg ^ swz(row)) << 3)) = rb[tt][i];
       }
     }
   };
@@ -219,9 +223,10 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
     boff[i] = (unsigned)((((n0 + row) * NTAPS) * Csw + 8 * seg) * 2);
   }
   // (separate variables, not an array: an array of __amdgpu_buffer_rsrc_t silently drops the kernel's host stub)
+  const int plane_bytes = Nout * NTAPS * Csw * 2;  // rows >= Nout are out of range: they read (and the DMA writes) zeros
   auto plane_rsrc = [&](int i) {
     const int wplane = __builtin_amdgcn_readfirstlane((tid + NT * i) / (BN * 4));
-    return uniform_rsrc_b(wplane == 0 ? w0 : (wplane == 1 ? w1 : w2), 0x7ffffff0);
+    return uniform_rsrc_b(wplane == 0 ? w0 : (wplane == 1 ? w1 : w2), plane_bytes);
   };
   const __amdgpu_buffer_rsrc_t b_src0 = plane_rsrc(0), b_src1 = plane_rsrc(1), b_src2 = plane_rsrc(2),
                                b_src3 = plane_rsrc(3), b_src4 = plane_rsrc(4), b_src5 = plane_rsrc(5);
@@ -233,6 +238,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
 #pragma unroll
       for (int i = 0; i < BSEG; ++i) {
         const int slot = tid + NT * i;
+        if (BSEG * NT != BSLOTS && slot - lane >= BSLOTS) continue;  // (wave-uniform) no such segments
         const int plane = slot / (BN * 4);
         const int rem = slot - plane * BN * 4;
         __bf16* dst_l = Bs + (((buf * TPB + tt) * NP + plane) * BN) * 32 + (rem - lane) * 8;  // the wave's first slot
@@ -595,10 +601,17 @@ int conv3x3_split_launch(int np, const float* x, const scan_pyramid_t* d, int32_
   const bool whole = g_scan_conv_glds && Csw % 32 == 0;
   const bool th16 = g_scan_conv_bn64_th16 && d->n_levels == 1 && d->h[0] % 16 == 0 && d->w[0] % 16 == 0;
   if (np == 3) {
+    // three pieces: every 3x3 instance stages its weight tiles by LDS-DMA when the planes have whole K chunks (register
+    // staging of three planes costs the 8-wave instances 24 registers and spills: 95-103 TFLOP/s against 215-246,
+    // tools/conv_bench.py --variants conv_glds=0)
     switch (v2_instance(d, Nout)) {
       case 64:
-        if (th16)
-          launch_v2<3, 64, 16, 256, 3>(a);
+        if (whole && th16)
+          launch_v2<3, 64, 16, 512, 3, 1, true>(a);
+        else if (whole)
+          launch_v2<3, 64, 8, 256, 3, 1, true>(a);
+        else if (th16)
+          launch_v2<3, 64, 16, 512, 3>(a);
         else
           launch_v2<3, 64, 8, 256, 3>(a);
         break;
@@ -609,7 +622,7 @@ int conv3x3_split_launch(int np, const float* x, const scan_pyramid_t* d, int32_
           launch_v2<3, 256, 16, 512, 3>(a);
         break;
       default:
-        if (whole && Nout % 128 == 0)
+        if (whole)
           launch_v2<3, 128, 16, 512, 3, 1, true>(a);
         else
           launch_v2<3, 128, 16, 512, 3>(a);
@@ -628,6 +641,7 @@ int conv3x3_split_launch(int np, const float* x, const scan_pyramid_t* d, int32_
         launch_v2<2, 64, 8, 256, 3>(a);
       break;
     case 256:
+      // (two pieces: LDS-DMA only on whole channel tiles, as measured in rounds 2 and 3; v2_instance returns 256 only then)
       if (g_scan_conv_w8 && g_scan_conv_wg1024 == 1 && whole)
         launch_v2<2, 256, 16, 512, 3, 1, true>(a);
       else if ((g_scan_conv_wg1024 == 1 || (g_scan_conv_wg1024 == 2 && d->n_levels > 1)) && whole)

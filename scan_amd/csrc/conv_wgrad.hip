@@ -43,6 +43,17 @@ __device__ __forceinline__ bf16x8 tr_read8(const __bf16* p0, const __bf16* p1) {
   return __builtin_bit_cast(bf16x8, r);
 }
 
+// the same from LDS byte addresses (kernels that keep "lane base + immediate" addressing in their own hands)
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+__device__ __forceinline__ bf16x8 tr_read8_at(unsigned a0, unsigned a1) {
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a0);
+  const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)a1);
+  s16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return __builtin_bit_cast(bf16x8, r);
+}
+
 // the piece products of one (dY fragment set, X fragment), smallest terms first; within a magnitude class the dY piece
 // index descends (the order the two-piece kernels have always used: lo * hi, hi * lo, hi * hi)
 template <int NP, int TO, int TOMAX>
@@ -373,6 +384,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v4_kernel(
 // 64-pixel chunk would need 2 x 112 KB) -- the MFMA work per chunk and barrier is the same (twice the products on half
 // the pixels), the producers convert half the elements into 1.5x the planes.
 // ------------------------------------------------------------------------------------------------
+#ifndef SCAN_WG_SB
+#define SCAN_WG_SB 1  // scheduling fence behind every (tap, column tile) block of the consumers' MFMAs, see wgrad_mma_v6
+#endif
 #define W6ROW 144  // bf16 elements per LDS row
 #define W6STAGE(NP, WKC, KX) (((WKC) + (WKC) + (KX) - 1) * (NP) * W6ROW)  // bf16 elements per stage
 __device__ __forceinline__ int wsw6(int row, int col) { return row * W6ROW + (col ^ (((row >> 3) & 1) << 6)); }
@@ -382,43 +396,48 @@ __device__ __forceinline__ int wsw6(int row, int col) { return row * W6ROW + (co
 // col4 < 16), and a row offset is an immediate wherever it cannot change bit 3 of the row -- true for the rows
 // 8 kg + q (+ kx) and 8 kg + q + 4, q = (lane & 15) >> 2; only rows 8 kg + q + 4 + kx, kx = 1, 2 may cross into the next
 // group of eight and get bases of their own.  Four address registers instead of one per (tile, tap, row group).
-struct W6Lane {
-  int a;        // (row 8 kg + q, column a_col + col4): A operand, rows + 4 and tiles + 16 t by immediate
-  int b;        // (row 8 kg + q, column b_col + col4): B operand, rows + kx, + 4 (kx = 0) and tiles + 16 tc by immediate
-  int b1[2];    // (row 8 kg + q + 4 + kx, same column), kx = 1, 2
+struct W6Lane {  // LDS BYTE addresses of stage 0 (the consumer loop flips them between the stages in place)
+  unsigned a;      // (row 8 kg + q, column a_col + col4) of dY plane 0: rows + 4, tiles + 16 t and planes by immediate
+  unsigned b;      // (row 8 kg + q, column b_col + col4) of X plane 0: rows + kx, + 4 (kx = 0), tiles + 16 tc, planes by immediate
+  unsigned b1[2];  // (row 8 kg + q + 4 + kx, same column), kx = 1, 2
 };
-__device__ __forceinline__ W6Lane w6_lane(int row_lane, int col4, int a_col, int b_col) {
+template <int NP, int WKC>
+__device__ __forceinline__ W6Lane w6_lane(unsigned lds_base, int row_lane, int col4, int a_col, int b_col) {
   W6Lane w;
-  w.a = wsw6(row_lane, a_col + col4);
-  w.b = wsw6(row_lane, b_col + col4);
-  w.b1[0] = wsw6(row_lane + 5, b_col + col4);
-  w.b1[1] = wsw6(row_lane + 6, b_col + col4);
+  const unsigned xb = lds_base + 2u * (NP * WKC * W6ROW);
+  w.a = lds_base + 2u * wsw6(row_lane, a_col + col4);
+  w.b = xb + 2u * wsw6(row_lane, b_col + col4);
+  w.b1[0] = xb + 2u * wsw6(row_lane + 5, b_col + col4);
+  w.b1[1] = xb + 2u * wsw6(row_lane + 6, b_col + col4);
   return w;
 }
 
 template <int NP, int WKC, int TO, int KX, int TOMAX>
-__device__ __forceinline__ void wgrad_mma_v6(const __bf16* A, const __bf16* B, const W6Lane& w, f32x4v (&acc)[KX][2][TOMAX]) {
-  constexpr int APL = WKC * W6ROW, BPL = (WKC + KX - 1) * W6ROW;
+__device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][2][TOMAX]) {
+  constexpr unsigned APL = 2 * WKC * W6ROW, BPL = 2 * (WKC + KX - 1) * W6ROW, ROWB = 2 * W6ROW;  // bytes
 #pragma unroll
   for (int s = 0; s < WKC / 32; ++s) {
     bf16x8 a[NP][TO];
 #pragma unroll
     for (int t = 0; t < TO; ++t) {
-      const int o0 = w.a + 32 * s * W6ROW + 16 * t, o1 = o0 + 4 * W6ROW;
+      const unsigned o0 = w.a + 32 * s * ROWB + 32 * t, o1 = o0 + 4 * ROWB;
 #pragma unroll
-      for (int p = 0; p < NP; ++p) a[p][t] = tr_read8(A + p * APL + o0, A + p * APL + o1);
+      for (int p = 0; p < NP; ++p) a[p][t] = tr_read8_at(o0 + p * APL, o1 + p * APL);
     }
 #pragma unroll
     for (int kx = 0; kx < KX; ++kx) {
 #pragma unroll
       for (int tc = 0; tc < 2; ++tc) {
         // X row j <-> pixel x0 - HALO + j: tap kx is a row shift
-        const int o0 = w.b + (32 * s + kx) * W6ROW + 16 * tc;
-        const int o1 = (kx == 0 ? w.b + 4 * W6ROW : w.b1[kx - 1]) + 32 * s * W6ROW + 16 * tc;
+        const unsigned o0 = w.b + (32 * s + kx) * ROWB + 32 * tc;
+        const unsigned o1 = (kx == 0 ? w.b + 4 * ROWB : w.b1[kx - 1]) + 32 * s * ROWB + 32 * tc;
         bf16x8 b[NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) b[p] = tr_read8(B + p * BPL + o0, B + p * BPL + o1);
+        for (int p = 0; p < NP; ++p) b[p] = tr_read8_at(o0 + p * BPL, o1 + p * BPL);
         wgrad_pieces<NP, TO, TOMAX>(a, b, acc[kx][tc]);
+#if SCAN_WG_SB
+        __builtin_amdgcn_sched_barrier(0);
+#endif
       }
     }
   }
@@ -620,13 +639,21 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
   // one K loop per live-tile count (wave-uniform; dead tiles: third c tile of Cin = 264 / 268, Cout = 8 / 5 / 1 heads):
   // inside one loop the compiler would keep the fragment addresses of all three variants in registers across it, which
   // at 168 registers per lane spills
-  const W6Lane wl = w6_lane(row_lane, col4, a_col, b_col);
+  // The lane's four fragment addresses are LDS byte addresses that carry the stage offset themselves and flip between the two stages by +-STAGE at
+  // the end of an iteration (four in-place adds): formed as "stage base + lane offset" inside the loop they were four
+  // MORE live registers, and at the 168-register cap of three waves per SIMD the bases were spilled and reloaded from
+  // scratch right behind every barrier -- a memory round trip in front of the first fragment read of each chunk.
   auto run = [&](auto to_tag) {
     constexpr int TO = decltype(to_tag)::value;
+    W6Lane wl = w6_lane<NP, WKC>((unsigned)(uintptr_t)(lds_ptr_t)sm, row_lane, col4, a_col, b_col);
+    unsigned flip = 2u * STAGE;  // bytes; +-: unsigned wrap-around is the subtraction
     for (int k = 0; k < nch; ++k) {
-      const __bf16* As = sm + (k & 1) * STAGE;
-      const __bf16* Bs = As + NP * WKC * W6ROW;
-      if constexpr (TO > 0) wgrad_mma_v6<NP, WKC, TO, KX, TOMAX>(As, Bs, wl, acc);
+      if constexpr (TO > 0) wgrad_mma_v6<NP, WKC, TO, KX, TOMAX>(wl, acc);
+      wl.a += flip;
+      wl.b += flip;
+      wl.b1[0] += flip;
+      wl.b1[1] += flip;
+      flip = 0u - flip;
       __syncthreads();  // done with this stage; the other one is complete
     }
   };

@@ -16,12 +16,13 @@ import sys
 
 
 def short(name):
-    m = re.match(r"(?:void )?([A-Za-z0-9_]+)", name)
-    return m.group(1) if m else name[:40]
+    """kernel name with its template arguments (the conv instances differ only there), without the parameter list"""
+    m = re.match(r"(?:void )?([A-Za-z0-9_]+)(<[^(]*>)?", name)
+    return (m.group(1) + (m.group(2) or "").replace(" ", "")) if m else name[:40]
 
 
 def main():
-    path, subs = sys.argv[1], sys.argv[2:]
+    path, subs = sys.argv[1], [a for a in sys.argv[2:] if "=" not in a]
     op = gzip.open if path.endswith(".gz") else open
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
     with op(path, "rt") as f:
@@ -35,7 +36,7 @@ def main():
     for k, cs in sorted(acc.items()):
         mean = {c: v[1] / v[0] for c, v in cs.items()}
         n = max(v[0] for v in cs.values())
-        line = "%-34s %4d dispatches " % (k, n)
+        line = "%-44s %4d dispatches " % (k, n)
         wc = mean.get("SQ_WAVE_CYCLES")
         for c in sorted(mean):
             line += " %s=%.4g" % (c.replace("SQ_", ""), mean[c])
@@ -44,6 +45,11 @@ def main():
                            ("SQ_ACTIVE_INST_ANY", "active_any")):
                 if c in mean:
                     line += "  %s/wave_cycles=%.3f" % (lab, mean[c] / wc)
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and len(sys.argv) > 2 and sys.argv[-1].startswith("waves_per_simd="):
+                # MFMA_BUSY counts cycles per SIMD, WAVE_CYCLES quad-cycles per wave: with w resident waves per SIMD for the
+                # whole launch, mfma_busy = MFMA_BUSY / (4 * WAVE_CYCLES / w)
+                w = float(sys.argv[-1].split("=")[1])
+                line += "  mfma_busy(at %g waves/SIMD)=%.3f" % (w, mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * wc / w))
             if "SQ_INSTS_VALU" in mean and "SQ_BUSY_CYCLES" in mean:
                 line += "  valu_insts_per_busy_cycle=%.3f" % (mean["SQ_INSTS_VALU"] / mean["SQ_BUSY_CYCLES"])
         print(line)

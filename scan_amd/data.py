@@ -146,33 +146,32 @@ class Compose:
         return image, target
 
 
+def scaled_size(h, w, short_target, long_cap=None):
+    """(oh, ow) of a frame whose SHORTER side is brought to ``short_target`` with the aspect ratio kept, unless that would
+    push the longer side past ``long_cap`` -- then the target shrinks so the longer side lands on the cap.  The other side
+    is truncated, not rounded, and a frame whose shorter side already has the target size is left alone: the integer results
+    of the reference's Resize (data/transforms/transforms.py:27-55), pinned by test_get_size_matches_reference_table."""
+    lo, hi = (w, h) if w <= h else (h, w)
+    t = short_target
+    if long_cap is not None and float(hi) / float(lo) * t > long_cap:
+        t = int(round(long_cap * float(lo) / float(hi)))
+    if lo == t:
+        return h, w
+    other = int(t * hi / lo)
+    return (other, t) if w < h else (t, other)
+
+
 class Resize:
-    """reference transforms.py:27-61."""
+    """Resize(min_size, max_size) of the reference's transform list: one of ``min_size`` is drawn per frame (multi-scale
+    training), boxes follow the frame."""
 
     def __init__(self, min_size, max_size):
-        if not isinstance(min_size, (list, tuple)):
-            min_size = (min_size,)
-        self.min_size = min_size
+        self.min_size = tuple(min_size) if isinstance(min_size, (list, tuple)) else (min_size,)
         self.max_size = max_size
 
     def get_size(self, image_size):
         w, h = image_size
-        size = random.choice(self.min_size)
-        max_size = self.max_size
-        if max_size is not None:
-            min_original_size = float(min((w, h)))
-            max_original_size = float(max((w, h)))
-            if max_original_size / min_original_size * size > max_size:
-                size = int(round(max_size * min_original_size / max_original_size))
-        if (w <= h and w == size) or (h <= w and h == size):
-            return (h, w)
-        if w < h:
-            ow = size
-            oh = int(size * h / w)
-        else:
-            oh = size
-            ow = int(size * w / h)
-        return (oh, ow)
+        return scaled_size(h, w, random.choice(self.min_size), self.max_size)
 
     def __call__(self, image, target):
         oh, ow = self.get_size(image.size)

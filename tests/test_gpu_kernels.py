@@ -599,7 +599,7 @@ def test_wgrad_full_size_elementwise(device, case, mode, monkeypatch):
     if mode == "bf16x6":
         # a split-K slab accumulates its pixels in fp32 with one rounded addition per piece product and 32-pixel step: over
         # the 8,192-pixel chains of conv3_2 the result sits ~2x further from fp64 (rms) than the fp32-MFMA kernel's, whose
-        # chains are shorter -- the same order, the same class as any fp32 implementation (scratch/wgrad_err.py: the distance
+        # chains are shorter -- the same order, the same class as any fp32 implementation (tools/wgrad_err.py: the distance
         # falls as 1 / sqrt(slabs)); the largest single deviation is the same
         assert e[0] <= 5e-6 and e[1] <= 2.5 * e32[1] and e[1] <= 1.5e-6 and e[0] <= 1.6 * e32[0], (e, e32)
     else:

@@ -409,7 +409,7 @@ def test_stream_overlap_is_race_free(device):
         torch.cuda.synchronize()
         res.append({k: g.flat_p.clone() for k, g in trainer.groups.items()})
     # two runs of the SAME schedule already differ by ~7e-7 in the parameters after two iterations (float atomics in
-    # the loss reductions and in torch's index_put backward, amplified through the net; scratch/determinism.py), so the
+    # the loss reductions and in torch's index_put backward, amplified through the net; tools/determinism.py), so the
     # bar sits above that noise floor and far below what a missed dependency would do (>= 1e-3)
     for k in res[0]:
         a, b = res[0][k], res[1][k]

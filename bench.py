@@ -206,6 +206,15 @@ def visible_gpus():
                 n += 1
     except Exception:
         return None
+    # a container may expose only some GPUs through device cgroups while sysfs still lists every GPU of the host: the
+    # render nodes this process can open bound the count too (one /dev/dri/renderD* per GPU)
+    try:
+        nodes = [f for f in os.listdir("/dev/dri") if f.startswith("renderD")]
+        usable = sum(1 for f in nodes if os.access(os.path.join("/dev/dri", f), os.R_OK | os.W_OK))
+        if nodes:
+            n = min(n, usable)
+    except OSError:
+        pass
     for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
         v = os.environ.get(var)
         if v is not None:

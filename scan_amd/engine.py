@@ -889,6 +889,10 @@ def do_train(trainer, loader_source, loader_target, max_iter, val_dataset=None, 
     loader_*: iterables of (ImageList, targets, ids) as data.BatchCollator returns them.  gate: coco_eval.TargetGate.
     Returns the list of per-iteration reduced loss dicts (python floats; rank 0 only, empty elsewhere)."""
     from . import comm
+    from .modeling import condgraph
+    if condgraph.FT_CANDIDATE_FRACTION is not None:
+        raise RuntimeError("condgraph.FT_CANDIDATE_FRACTION is a measurement switch of bench.py (--ft-positives): node "
+                           "sampling with it set differs from the reference's; it must be None in a training run")
     history = []
     start = trainer.iteration
     for it, ((il_s, tg_s, _), (il_t, _, _)) in enumerate(zip(loader_source, loader_target), start + 1):

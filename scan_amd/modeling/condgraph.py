@@ -131,7 +131,9 @@ def dbscan_positive_rows(feat_l, act_l, n_images, eps, thr):
     hw = feat_l.shape[0] // n_images
     act = act_l.detach().view(n_images, hw, K)[:, :, 1:].permute(0, 2, 1).contiguous()  # [N, CLS, HW]
     mask = act > thr
-    if FT_CANDIDATE_FRACTION is not None:
+    if FT_CANDIDATE_FRACTION is None:
+        _ft_masks.clear()
+    else:
         key = (tuple(act.shape), str(act.device), float(FT_CANDIDATE_FRACTION))
         keep = _ft_masks.get(key)
         if keep is None:
@@ -290,6 +292,9 @@ class GRAPHModule(nn.Module):
             thin = ops.conv2d(thin_in, conv.weight[:, C:C + K], None, shape, 3, 1)
             if main_stream is not None:
                 torch.cuda.current_stream().wait_stream(main_stream)
+                # allocated from the side stream's pool, read here: tell the caching allocator, or a later allocation on
+                # that stream which does not first wait for this one could be handed the block while it is still read
+                main.record_stream(torch.cuda.current_stream())
             return logits, maps, ops.add_relu(main, thin)
         pad = self.cat_stride - feats.shape[1] - maps.shape[1]
         cat = torch.cat([feats, maps, feats.new_zeros(feats.shape[0], pad)], 1)

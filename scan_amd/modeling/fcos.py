@@ -121,7 +121,7 @@ def target_plan(shape, targets, device, side_stream=None, after=None):
 
 
 DEVICE_PLAN = True  # False: the torch spelling below also on the GPU (A/B, cross-checks)
-_plan_staging = {}  # (N, G, device) -> pinned host buffers of the packed ground truth
+_plan_staging = {}  # (N, device) -> pinned host buffers of the packed ground truth, grown (never shrunk) to a power of two of boxes
 
 
 def _build_plan_device(shape, targets, device):
@@ -135,13 +135,18 @@ def _build_plan_device(shape, targets, device):
         # ground truth as the collator hands it over (host tensors): packed in pinned staging buffers and uploaded on
         # THIS stream -- the plan then depends on nothing the main stream has queued, and the one host read below waits
         # for three small kernels instead of for the previous iteration (tools/host_profile.py: 33 of 52 ms per step)
-        key = (N, G, str(device))
+        # one staging set per (batch size, device): the largest box count of a batch changes nearly every iteration on
+        # real data, and a set per count would page-lock a new buffer (milliseconds, on the hot path) each time and never
+        # give it back.  The kernels' loop is bounded by each image's own count (ng), so a wider G costs nothing.
+        key = (N, str(device))
         stage = _plan_staging.get(key)
-        if stage is None:
-            stage = _plan_staging[key] = (torch.zeros((N, G, 4), dtype=torch.float32).pin_memory(),
-                                          torch.zeros((N, G), dtype=torch.int64).pin_memory(),
+        if stage is None or stage[0].shape[1] < G:
+            G_cap = 1 << max(4, (G - 1).bit_length())
+            stage = _plan_staging[key] = (torch.zeros((N, G_cap, 4), dtype=torch.float32).pin_memory(),
+                                          torch.zeros((N, G_cap), dtype=torch.int64).pin_memory(),
                                           torch.zeros((N,), dtype=torch.int32).pin_memory())
         hb, hl, hn = stage
+        G = hb.shape[1]
         hb.zero_()
         hl.zero_()
         for i, (b, l) in enumerate(targets):
@@ -391,6 +396,9 @@ class FCOSPostProcessor:
                 # class-aware launch: a box is suppressed only by a kept, higher-scored box of the SAME label, which is
                 # exactly greedy NMS run per class; output order = class-major, original index ascending within a class
                 _last_nms[0] = (boxes, scores, labels, self.nms_thresh)
+                if side is not None:  # kept beyond this call (bench.py times the NMS on them on the main stream)
+                    for t in (boxes, scores, labels):
+                        t.record_stream(main)
                 finish = ops.nms_by_label_async(boxes, scores, labels, self.nms_thresh)
             pending.append((boxes, scores, labels, finish, side))
         results = []

@@ -165,14 +165,19 @@ def test_two_ranks_equal_one_process_accumulating_both_shards(device, tmp_path):
     assert torch.allclose(a["momentum_backbone"], trainer.groups["backbone"].flat_m.cpu(), rtol=1e-4, atol=1e-7)
 
 
-def test_two_ranks_mixed_schedules_issue_the_same_collectives(device, tmp_path):
-    """rank 0 takes Trainer.step_paired, rank 1 the three-phase schedule (what happens when the ranks' batches pad to
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_ranks_mixed_schedules_issue_the_same_collectives(device, tmp_path, backend):
+    """(backend "nccl": one GPU per rank over RCCL -- gloo's CUDA path synchronises the host and would hide a missing stream
+    dependency of the mid-backward bucket all-reduces; needs two GPUs, skipped on 1-GPU boxes)
+    rank 0 takes Trainer.step_paired, rank 1 the three-phase schedule (what happens when the ranks' batches pad to
     different shapes): the gradient all-reduces must pair up -- same ranges, same order -- and, with the same shard on
     both ranks, the result equals the single-process run."""
     # ONE optimizer step: the two schedules sum in different orders, and at this frame size (levels down to 1x1 pixel)
     # a second step amplifies first-step rounding differences to ~1e-3 relative (DESIGN.md 4, "chaotic at rounding
     # level") -- after one step the comparison with the single-process run is a rounding-level one
-    a, b = _spawn(True, tmp_path, steps=1, mixed_schedules=True)
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (RCCL refuses two ranks on one device)")
+    a, b = _spawn(True, tmp_path, backend=backend, steps=1, mixed_schedules=True)
     assert torch.equal(a["collective_log"], b["collective_log"]) and a["collective_log"].shape[0] >= 7
     ref = _run(0, 1, True, steps=1)
     for k in ref:

@@ -4,7 +4,17 @@ arguments and forward semantics, HIP underneath."""
 import torch
 from torch import nn
 
-from .. import _C, ops
+from .. import _C as _C_ctypes, ops
+
+# ``_C``: the compiled pybind11 module a reference checkout imports as fcos_core._C (scan_amd/csrc/fcos_core_C.cpp, built by
+# __graft_entry__.build() into scan_amd/ext/fcos_core/); scan_amd/_C.py is the same four functions bound through ctypes
+# (kept for environments without a C++ toolchain -- both sit on the C ABI of libscan_hip.so, neither computes anything itself)
+try:
+    from ..ext.fcos_core import _C
+    C_BACKEND = "compiled"
+except ImportError:
+    _C = _C_ctypes
+    C_BACKEND = "ctypes"
 
 nms = _C.nms
 ml_nms = _C.ml_nms

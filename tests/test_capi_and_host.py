@@ -55,6 +55,38 @@ def test_ops_refuse_cpu_tensors():
         _C.roi_align_forward()
 
 
+def _import_fcos_core_C():
+    """the compiled module under the name the reference imports it by: ``from fcos_core import _C``"""
+    import importlib
+    import sys
+    ext = os.path.join(ROOT, "scan_amd", "ext")
+    if ext not in sys.path:
+        sys.path.insert(0, ext)
+    return importlib.import_module("fcos_core._C")
+
+
+def test_compiled_fcos_core_C_module_loads_and_refuses_cpu_tensors():
+    """scan_amd/csrc/fcos_core_C.cpp built by __graft_entry__.build(): importable as fcos_core._C, exports what the
+    reference's csrc/vision.cpp:8-17 binds, and behaves like it off the GPU (no compute here: there is no GPU)."""
+    _C = _import_fcos_core_C()
+    for name in ("nms", "ml_nms", "sigmoid_focalloss_forward", "sigmoid_focalloss_backward", "roi_align_forward",
+                 "roi_align_backward", "roi_pool_forward", "roi_pool_backward"):
+        assert callable(getattr(_C, name)), name
+    assert _C.scan_abi_version() == _lib.lib().scan_abi_version()
+    k = _C.nms(torch.zeros(0, 4), torch.zeros(0), 0.5)  # csrc/nms.h:17-18
+    assert k.numel() == 0 and k.dtype == torch.int64 and k.device.type == "cpu"
+    with pytest.raises(RuntimeError, match="CPU"):
+        _C.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
+    with pytest.raises(RuntimeError, match="CPU"):
+        _C.ml_nms(torch.zeros(3, 4), torch.zeros(3), torch.zeros(3), 0.5)
+    with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
+        _C.sigmoid_focalloss_forward(torch.zeros(4, 8), torch.zeros(4, dtype=torch.int32), 8, 2.0, 0.25)
+    with pytest.raises(RuntimeError):
+        _C.roi_align_forward()
+    from scan_amd import layers
+    assert layers.C_BACKEND == "compiled" and layers.nms.__module__ is not None
+
+
 def test_pyramid_shape():
     s = ops.PyramidShape(2, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)])
     assert s.rows == 2 * 43648 and s.row_off[1] == 2 * 128 * 256

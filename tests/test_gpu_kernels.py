@@ -82,6 +82,62 @@ def test_sigmoid_focal_layer_sum_and_tail(device):
         _C.sigmoid_focalloss_forward(torch.zeros(4, 8), torch.zeros(4, dtype=torch.int32), 8, 2.0, 0.25)
 
 
+def test_compiled_fcos_core_C_runs_the_reference_call_sequences(device, gold_dir):
+    """the module built from scan_amd/csrc/fcos_core_C.cpp, imported under the reference's name ``fcos_core._C``, driven the
+    way the reference drives it: layers/nms.py:4-7 (``nms = _C.nms``), the ``_SigmoidFocalLoss`` autograd Function of
+    layers/sigmoid_focal_loss.py:9-36 (forward: _C.sigmoid_focalloss_forward, backward: _C.sigmoid_focalloss_backward) and
+    its module's ``loss.sum()`` (:56-70) -- against the reference's own test vectors, the C oracle, and the ctypes binding."""
+    import importlib
+    import sys
+    ext = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scan_amd", "ext")
+    if ext not in sys.path:
+        sys.path.insert(0, ext)
+    _C = importlib.import_module("fcos_core._C")
+    from scan_amd import _C as ctypes_C
+    from oracle import coracle
+
+    class _SigmoidFocalLoss(torch.autograd.Function):  # the reference's Function, verbatim in structure
+        @staticmethod
+        def forward(ctx, logits, targets, gamma, alpha):
+            ctx.save_for_backward(logits, targets)
+            ctx.num_classes, ctx.gamma, ctx.alpha = logits.shape[1], gamma, alpha
+            return _C.sigmoid_focalloss_forward(logits, targets, ctx.num_classes, gamma, alpha)
+
+        @staticmethod
+        def backward(ctx, d_loss):
+            logits, targets = ctx.saved_tensors
+            return _C.sigmoid_focalloss_backward(logits, targets, d_loss.contiguous(), ctx.num_classes, ctx.gamma,
+                                                 ctx.alpha), None, None, None
+
+    g = np.load(os.path.join(gold_dir, "pointwise.npz"))
+    x = torch.from_numpy(g["focal_logits"]).to(device).requires_grad_(True)
+    t = torch.from_numpy(g["focal_targets"]).to(device)
+    loss = _SigmoidFocalLoss.apply(x, t.int(), 2.0, 0.25)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), coracle.sigmoid_focal_fwd(g["focal_logits"], g["focal_targets"], 2.0, 0.25),
+                               rtol=1e-5, atol=1e-7)
+    loss.sum().backward()
+    ones = np.ones_like(g["focal_logits"])
+    np.testing.assert_allclose(x.grad.cpu().numpy(), coracle.sigmoid_focal_bwd(g["focal_logits"], g["focal_targets"], ones, 2.0, 0.25),
+                               rtol=1e-5, atol=1e-7)
+    assert torch.equal(loss.detach(), ctypes_C.sigmoid_focalloss_forward(x.detach(), t, 8, 2.0, 0.25))
+    # nms: the reference's own known answers (tests/test_nms.py) and random boxes against the oracle, ml_nms likewise
+    kat = json.load(open(os.path.join(gold_dir, "nms_kat.json")))
+    for case in kat["cases"]:
+        keep = _C.nms(torch.tensor(case["boxes"], device=device), torch.tensor(case["scores"], device=device), case["thresh"])
+        assert sorted(keep.cpu().tolist()) == case["keep_sorted"]
+    rs = np.random.RandomState(3)
+    boxes, scores = _rand_boxes(rs, 3000, quant=4.0), rs.rand(3000).astype(np.float32)
+    labels = rs.randint(1, 9, 3000).astype(np.float32)
+    bd, sd, ld = (torch.from_numpy(a).to(device) for a in (boxes, scores, labels))
+    assert np.array_equal(_C.nms(bd, sd, 0.5).cpu().numpy(), coracle.nms(boxes, scores, 0.5))
+    assert np.array_equal(_C.ml_nms(bd, sd, ld, 0.6).cpu().numpy(), coracle.ml_nms(boxes, scores, labels, 0.6))
+    assert torch.equal(_C.ml_nms(bd, sd, ld, 0.6), ctypes_C.ml_nms(bd, sd, ld, 0.6))
+    with pytest.raises(RuntimeError, match="num_classes"):
+        _C.sigmoid_focalloss_forward(torch.zeros(4, 3, device=device), torch.zeros(4, dtype=torch.int32, device=device), 8, 2.0, 0.25)
+    with pytest.raises(RuntimeError, match="SCAN_NMS_MAX"):
+        _C.nms(torch.zeros(8193, 4, device=device), torch.zeros(8193, device=device), 0.5)
+
+
 def test_iou_loss_golden(device, gold_dir):
     from scan_amd.layers import IOULoss
     g = np.load(os.path.join(gold_dir, "pointwise.npz"))

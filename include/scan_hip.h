@@ -62,6 +62,8 @@ int scan_abi_version(void);
  *                 MFMAs, 4 stage); 0: the kernel in which all 8 waves stage and multiply in turn (always used by the 1x1
  *                 convs).  bf16x3: bit-identical; bf16x6: other K-chunk length, i.e. other split-K boundaries.
  *   "wgrad_prio"  1 (default): the producer waves of that kernel run at s_setprio 3.
+ *   "wgrad_tile"  consumer wave tile of that kernel: 0 = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c), -1 (default) = 1 for bf16x6, 0 for
+ *                 bf16x3.  Same results bit for bit.
  *   "wgrad_wgs"   768 (default): workgroups a weight-gradient launch aims at (tiles x split-K slabs); 512 / 640 / 896 / 1024
  *                 / 1280 / 1536 are 2...25 % slower on the 256- and 512-channel layers (bf16x3).
  *   "gconv_mfma"  0 (default): the grouped class-branch conv runs on fp32 FMAs; 1: tap products and data gradient on the

@@ -27,6 +27,7 @@ extern int g_scan_conv_bn64_th16;
 extern int g_scan_conv_glds;
 extern int g_scan_wgrad_v6;
 extern int g_scan_wgrad_prio;
+extern int g_scan_wgrad_tile;
 extern int g_scan_wgrad_wgs;
 extern int g_scan_gconv_mfma;
 extern int g_scan_dbscan_bf16x3;
@@ -38,7 +39,7 @@ static int* tune_slot(const char* key) {
   } knobs[] = {
       {"conv_bn256", &g_scan_conv_bn256},   {"conv_v2", &g_scan_conv_v2},         {"conv_wg1024", &g_scan_conv_wg1024},
       {"conv_w8", &g_scan_conv_w8},         {"conv_tpb3", &g_scan_conv_tpb3},     {"conv_bn64_th16", &g_scan_conv_bn64_th16},
-      {"conv_glds", &g_scan_conv_glds},     {"wgrad_v6", &g_scan_wgrad_v6},       {"wgrad_prio", &g_scan_wgrad_prio},
+      {"conv_glds", &g_scan_conv_glds},     {"wgrad_v6", &g_scan_wgrad_v6},       {"wgrad_prio", &g_scan_wgrad_prio},   {"wgrad_tile", &g_scan_wgrad_tile},
       {"wgrad_wgs", &g_scan_wgrad_wgs},     {"gconv_mfma", &g_scan_gconv_mfma},   {"dbscan_bf16x3", &g_scan_dbscan_bf16x3},
   };
   for (const auto& k : knobs)

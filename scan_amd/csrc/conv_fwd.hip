@@ -41,6 +41,39 @@ struct TileTab2 {
 // 16-byte slot swizzle of a 64-byte row: k-group kg of row idx lives at slot kg ^ swz(idx)
 __device__ __forceinline__ int swz(int idx) { return (idx >> 1) & 2; }
 
+// The weight plane slot I of a thread reads from, WITHOUT a run-time table: slot = tid + NT * I lies in plane slot / PL, and
+// for every instance that is one compile-time plane or one of two neighbours.  (Written as a nested select on the run-time
+// plane index the compiler builds {w0, w1, w2} on the stack and indexes it: scratch in every kernel.)
+template <int K>
+__device__ __forceinline__ const __bf16* pick_plane(const __bf16* w0, const __bf16* w1, const __bf16* w2) {
+  if constexpr (K == 0)
+    return w0;
+  else if constexpr (K == 1)
+    return w1;
+  else
+    return w2;
+}
+template <int I, int NT, int PL, int NPL>
+__device__ __forceinline__ const __bf16* slot_plane(int tid, const __bf16* w0, const __bf16* w1, const __bf16* w2) {
+  constexpr int lo = (NT * I) / PL, hi = (NT * I + NT - 1) / PL;
+  constexpr int lo_c = lo < NPL ? lo : NPL - 1, hi_c = hi < NPL ? hi : NPL - 1;  // slots past the last plane are never used
+  static_assert(hi - lo <= 1, "a thread's slot spans at most two planes");
+  if constexpr (lo_c == hi_c)
+    return pick_plane<lo_c>(w0, w1, w2);
+  else
+    return (tid + NT * I) / PL == lo ? pick_plane<lo_c>(w0, w1, w2) : pick_plane<hi_c>(w0, w1, w2);
+}
+template <int NT, int PL, int NPL>
+__device__ __forceinline__ const __bf16* slot_plane_i(int i, int tid, const __bf16* w0, const __bf16* w1, const __bf16* w2) {
+  // i is a constant after unrolling: the chain folds to one call
+  return i == 0   ? slot_plane<0, NT, PL, NPL>(tid, w0, w1, w2)
+         : i == 1 ? slot_plane<1, NT, PL, NPL>(tid, w0, w1, w2)
+         : i == 2 ? slot_plane<2, NT, PL, NPL>(tid, w0, w1, w2)
+         : i == 3 ? slot_plane<3, NT, PL, NPL>(tid, w0, w1, w2)
+         : i == 4 ? slot_plane<4, NT, PL, NPL>(tid, w0, w1, w2)
+                  : slot_plane<5, NT, PL, NPL>(tid, w0, w1, w2);
+}
+
 // the piece products of one (weight fragment set, pixel fragment set), smallest terms first (conv_split.h)
 template <int NP, int TM>
 __device__ __forceinline__ void mma_pieces(const bf16x8 (&w)[NP], const bf16x8 (&p)[NP][TM], f32x4v (&acc)[TM]) {
@@ -186,7 +219,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
         const int rem = slot - plane * BN * 4;
         const int row = rem >> 2, seg = rem & 3;
         const int o = n0 + row, c = cc * V2_CK + 8 * seg;
-        const __bf16* base = plane == 0 ? w0 : (plane == 1 ? w1 : w2);
+        const __bf16* base = slot_plane_i<NT, BN * 4, NP>(i, tid, w0, w1, w2);
         rb[tt][i] = (slot < BSLOTS && o < Nout && c < Csw)
                         ? *reinterpret_cast<const uint4*>(base + ((int64_t)o * NTAPS + tap) * Csw + c)
                         : make_uint4(0u, 0u, 0u, 0u);
@@ -224,10 +257,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
   }
   // (separate variables, not an array: an array of __amdgpu_buffer_rsrc_t silently drops the kernel's host stub)
   const int plane_bytes = Nout * NTAPS * Csw * 2;  // rows >= Nout are out of range: they read (and the DMA writes) zeros
-  auto plane_rsrc = [&](int i) {
-    const int wplane = __builtin_amdgcn_readfirstlane((tid + NT * i) / (BN * 4));
-    return uniform_rsrc_b(wplane == 0 ? w0 : (wplane == 1 ? w1 : w2), plane_bytes);
-  };
+  auto plane_rsrc = [&](int i) { return uniform_rsrc_b(slot_plane_i<NT, BN * 4, NP>(i, tid, w0, w1, w2), plane_bytes); };
   const __amdgpu_buffer_rsrc_t b_src0 = plane_rsrc(0), b_src1 = plane_rsrc(1), b_src2 = plane_rsrc(2),
                                b_src3 = plane_rsrc(3), b_src4 = plane_rsrc(4), b_src5 = plane_rsrc(5);
   auto issue_b = [&](int cc, int grp, int buf) {

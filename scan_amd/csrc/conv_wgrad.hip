@@ -412,9 +412,13 @@ __device__ __forceinline__ W6Lane w6_lane(unsigned lds_base, int row_lane, int c
   return w;
 }
 
-template <int NP, int WKC, int TO, int KX, int TOMAX>
-__device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][2][TOMAX]) {
+// TO x TC live 16 x 16 tiles of this wave (of TOMAX x TCMAX).  The X fragments of G column tiles are read together so that
+// G * TO >= 4 independent accumulators separate two MFMAs on the same one.
+template <int NP, int WKC, int TO, int TC, int KX, int TOMAX, int TCMAX>
+__device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][TCMAX][TOMAX]) {
   constexpr unsigned APL = 2 * WKC * W6ROW, BPL = 2 * (WKC + KX - 1) * W6ROW, ROWB = 2 * W6ROW;  // bytes
+  constexpr int G = (TO >= 4 || TC == 1) ? 1 : (TO == 2 ? (TC >= 2 ? 2 : 1) : (TC >= 4 ? 4 : TC));
+  static_assert(TC % G == 0, "column tiles per block");
 #pragma unroll
   for (int s = 0; s < WKC / 32; ++s) {
     bf16x8 a[NP][TO];
@@ -427,14 +431,26 @@ __device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][
 #pragma unroll
     for (int kx = 0; kx < KX; ++kx) {
 #pragma unroll
-      for (int tc = 0; tc < 2; ++tc) {
-        // X row j <-> pixel x0 - HALO + j: tap kx is a row shift
-        const unsigned o0 = w.b + (32 * s + kx) * ROWB + 32 * tc;
-        const unsigned o1 = (kx == 0 ? w.b + 4 * ROWB : w.b1[kx - 1]) + 32 * s * ROWB + 32 * tc;
-        bf16x8 b[NP];
+      for (int tc0 = 0; tc0 < TC; tc0 += G) {
+        bf16x8 b[G][NP];
 #pragma unroll
-        for (int p = 0; p < NP; ++p) b[p] = tr_read8_at(o0 + p * BPL, o1 + p * BPL);
-        wgrad_pieces<NP, TO, TOMAX>(a, b, acc[kx][tc]);
+        for (int g = 0; g < G; ++g) {
+          // X row j <-> pixel x0 - HALO + j: tap kx is a row shift
+          const unsigned o0 = w.b + (32 * s + kx) * ROWB + 32 * (tc0 + g);
+          const unsigned o1 = (kx == 0 ? w.b + 4 * ROWB : w.b1[kx - 1]) + 32 * s * ROWB + 32 * (tc0 + g);
+#pragma unroll
+          for (int p = 0; p < NP; ++p) b[g][p] = tr_read8_at(o0 + p * BPL, o1 + p * BPL);
+        }
+        // piece products, smallest first; within a magnitude class the dY piece index descends (wgrad_pieces)
+#pragma unroll
+        for (int d = NP - 1; d >= 0; --d)
+#pragma unroll
+          for (int i = d; i >= 0; --i)
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+              for (int to = 0; to < TO; ++to)
+                acc[kx][tc0 + g][to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][to], b[g][d - i], acc[kx][tc0 + g][to], 0, 0, 0);
 #if SCAN_WG_SB
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -443,13 +459,19 @@ __device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][
   }
 }
 
-template <int NP, int WKC, int KX>
+// TOM x TCW: 16 x 16 tiles of a consumer wave along o and c (8 waves cover the 128 x 128 tile: 4 x 2 -> 2 (o) x 4 (c)
+// waves, 2 x 4 -> 4 (o) x 2 (c) waves).  Either way 96 accumulator registers; the resident dY fragments are NP * TOM * 4
+// registers, the X fragments are re-read per tap: 4 x 2 reads fewer fragments per MFMA (30 transposed reads per 144
+// MFMAs with three pieces), 2 x 4 keeps 24 instead of 48 registers resident (42 reads) and leaves room to prefetch.
+template <int NP, int WKC, int KX, int TOM, int TCW>
 __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
     const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
     float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
     int chunks_per_split, int splits, int prio) {
   constexpr int HALO = KX / 2, T = KX * KX;
-  constexpr int TOMAX = 4;                            // 16-row o tiles per consumer wave (64 o x 32 c per wave)
+  constexpr int TOMAX = TOM, TCMAX = TCW;             // 16 x 16 tiles per consumer wave along o and c
+  constexpr int WOC = 128 / (16 * TOM);               // consumer waves along o (x 128 / (16 * TCW) along c = 8)
+  static_assert(WOC * (128 / (16 * TCW)) == 8, "eight consumer waves cover the 128 x 128 tile");
   constexpr int PRG = 8;                              // pixel-row groups of the 256 producer threads
   constexpr int NA = WKC / PRG;                       // dY float4 per producer thread per chunk
   constexpr int NB = (WKC + KX - 1 + PRG - 1) / PRG;  // X float4 per producer thread per chunk
@@ -552,7 +574,11 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
 #pragma unroll
       for (int i = 0; i < NA; ++i) {
         const int off = wsw6(rr + PRG * i, 4 * q4);
+#ifdef SCAN_EXP_WGRAD_NOSPLIT  // TIMING EXPERIMENT (make exp_wgrad_nosplit, never in libscan_hip.so): no conversion work
+        for (int p = 0; p < NP; ++p) pc[p] = __builtin_bit_cast(bf16x4, make_float2(ra[i].x, ra[i].y));
+#else
         split4_np<NP>(ra[i], pc);
+#endif
 #pragma unroll
         for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(As + p * WKC * W6ROW + off) = pc[p];
         if (do_bias) {
@@ -571,7 +597,11 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
         const int j = rr + PRG * i;
         if (j < WKC + KX - 1) {
           const int off = wsw6(j, 4 * q4);
+#ifdef SCAN_EXP_WGRAD_NOSPLIT
+          for (int p = 0; p < NP; ++p) pc[p] = __builtin_bit_cast(bf16x4, make_float2(rb[i].x, rb[i].y));
+#else
           split4_np<NP>(rb[i], pc);
+#endif
 #pragma unroll
           for (int p = 0; p < NP; ++p) *reinterpret_cast<bf16x4*>(Bs + p * (WKC + KX - 1) * W6ROW + off) = pc[p];
         }
@@ -619,36 +649,35 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
     return;
   }
 
-  // ================================================================= consumers: 2 (o) x 4 (c) waves, 64 o x 32 c each
-  const int wm = wid % 2, wn = wid / 2;
+  // ================================================================= consumers: WOC (o) x 8 / WOC (c) waves
+  const int wm = wid % WOC, wn = wid / WOC;
   const int lr = lane & 15, kg = lane >> 4;
   const int row_lane = 8 * kg + (lr >> 2), col4 = 4 * (lane & 3);
-  const int a_col = wm * (16 * TOMAX), b_col = wn * 32;
-  const bool c_act = c0 + b_col < Cs;
+  const int a_col = wm * (16 * TOMAX), b_col = wn * (16 * TCMAX);
+  const int c_left = Cs - (c0 + b_col);
   const int o_left = Nout - (o0 + a_col);
 
-  f32x4v acc[KX][2][TOMAX];
+  f32x4v acc[KX][TCMAX][TOMAX];
 #pragma unroll
   for (int a = 0; a < KX; ++a)
 #pragma unroll
-    for (int c = 0; c < 2; ++c)
+    for (int c = 0; c < TCMAX; ++c)
 #pragma unroll
       for (int b = 0; b < TOMAX; ++b) acc[a][c][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
   __syncthreads();  // stage 0 is complete
   // one K loop per live-tile count (wave-uniform; dead tiles: third c tile of Cin = 264 / 268, Cout = 8 / 5 / 1 heads):
-  // inside one loop the compiler would keep the fragment addresses of all three variants in registers across it, which
-  // at 168 registers per lane spills
-  // The lane's four fragment addresses are LDS byte addresses that carry the stage offset themselves and flip between the two stages by +-STAGE at
-  // the end of an iteration (four in-place adds): formed as "stage base + lane offset" inside the loop they were four
-  // MORE live registers, and at the 168-register cap of three waves per SIMD the bases were spilled and reloaded from
-  // scratch right behind every barrier -- a memory round trip in front of the first fragment read of each chunk.
-  auto run = [&](auto to_tag) {
-    constexpr int TO = decltype(to_tag)::value;
+  // inside one loop the compiler would keep the fragment addresses of all variants in registers across it, which at 168
+  // registers per lane spills.
+  // The lane's four fragment addresses are LDS byte addresses that carry the stage offset themselves and flip between the
+  // two stages by +-STAGE at the end of an iteration (four in-place adds): formed as "stage base + lane offset" inside the
+  // loop they were four MORE live registers.
+  auto run = [&](auto to_tag, auto tc_tag) {
+    constexpr int TO = decltype(to_tag)::value, TC = decltype(tc_tag)::value;
     W6Lane wl = w6_lane<NP, WKC>((unsigned)(uintptr_t)(lds_ptr_t)sm, row_lane, col4, a_col, b_col);
     unsigned flip = 2u * STAGE;  // bytes; +-: unsigned wrap-around is the subtraction
     for (int k = 0; k < nch; ++k) {
-      if constexpr (TO > 0) wgrad_mma_v6<NP, WKC, TO, KX, TOMAX>(wl, acc);
+      if constexpr (TO > 0) wgrad_mma_v6<NP, WKC, TO, TC, KX, TOMAX, TCMAX>(wl, acc);
       wl.a += flip;
       wl.b += flip;
       wl.b1[0] += flip;
@@ -657,14 +686,29 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
       __syncthreads();  // done with this stage; the other one is complete
     }
   };
-  if (c_act && o_left > 32)
-    run(std::integral_constant<int, 4>{});
-  else if (c_act && o_left > 16)
-    run(std::integral_constant<int, 2>{});
-  else if (c_act && o_left > 0)
-    run(std::integral_constant<int, 1>{});
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+  using I2 = std::integral_constant<int, 2>;
+  using ITO = std::integral_constant<int, TOMAX>;
+  using ITC = std::integral_constant<int, TCMAX>;
+  // live column tiles: all of them, or one when at most 16 channels are left (the 8 / 12 channels of a 264- / 268-channel
+  // input beyond its two full 128-wide tiles)
+  auto run_to = [&](auto tc_tag) {
+    if (o_left > 16 * (TOMAX / 2) && TOMAX > 2)
+      run(ITO{}, tc_tag);
+    else if (o_left > 16)
+      run(I2{}, tc_tag);
+    else if (o_left > 0)
+      run(I1{}, tc_tag);
+    else
+      run(I0{}, tc_tag);
+  };
+  if (c_left <= 0)
+    run(I0{}, I1{});
+  else if (c_left <= 16)
+    run_to(I1{});
   else
-    run(std::integral_constant<int, 0>{});
+    run_to(ITC{});
 
   float* out = slab + (long long)split * Nout * T * Cs;
 #pragma unroll
@@ -672,7 +716,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
 #pragma unroll
     for (int to = 0; to < TOMAX; ++to)
 #pragma unroll
-      for (int tc = 0; tc < 2; ++tc) {
+      for (int tc = 0; tc < TCMAX; ++tc) {
         const int c = c0 + b_col + 16 * tc + lr;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -683,6 +727,11 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
   __syncthreads();  // pairs with the producers' bias-reduction barrier
 }
 
+// scan_tune "wgrad_tile": consumer wave tile of the producer / consumer kernel: 0 = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c),
+// -1 (default) = by piece count: three pieces 32 x 64 (conv3_x 2542 -> 2489 us, class-branch 264 -> 1024 3409 -> 3293,
+// head_out 1177 -> 1123: tools/conv_bench.py --op wgrad --variants wgrad_tile=0,wgrad_tile=1), two pieces 64 x 32 (within
+// noise of the other).  Same results bit for bit.
+int g_scan_wgrad_tile = -1;
 // scan_tune "wgrad_v6": 1 (default) = the 3x3 launches take the producer / consumer kernel, 0 = conv_wgrad_v4_kernel
 int g_scan_wgrad_v6 = 1;
 // scan_tune "wgrad_prio": 1 = the producer waves run at s_setprio 3
@@ -796,11 +845,16 @@ static int wgrad3_launch(const float* x, const scan_pyramid_t* d, int32_t Cs, co
     static_assert(sh6 <= 160 * 1024, "LDS: 160 KB per CU");
     static bool done = false;
     if (!done) {
-      set_lds(conv_wgrad_v6_kernel<NP, WK6, 3>, sh6);
+      set_lds(conv_wgrad_v6_kernel<NP, WK6, 3, 4, 2>, sh6);
+      set_lds(conv_wgrad_v6_kernel<NP, WK6, 3, 2, 4>, sh6);
       done = true;
     }
-    hipLaunchKernelGGL((conv_wgrad_v6_kernel<NP, WK6, 3>), dim3(nt * sp), dim3(768), sh6, st, x, *d, Cs, dy, Cout, Cout_s, ws,
-                       bias_slab, ct, nt, ctl, cps, sp, g_scan_wgrad_prio);
+    if (g_scan_wgrad_tile < 0 ? NP == 3 : g_scan_wgrad_tile != 0)
+      hipLaunchKernelGGL((conv_wgrad_v6_kernel<NP, WK6, 3, 2, 4>), dim3(nt * sp), dim3(768), sh6, st, x, *d, Cs, dy, Cout, Cout_s,
+                         ws, bias_slab, ct, nt, ctl, cps, sp, g_scan_wgrad_prio);
+    else
+      hipLaunchKernelGGL((conv_wgrad_v6_kernel<NP, WK6, 3, 4, 2>), dim3(nt * sp), dim3(768), sh6, st, x, *d, Cs, dy, Cout, Cout_s,
+                         ws, bias_slab, ct, nt, ctl, cps, sp, g_scan_wgrad_prio);
   } else {
     constexpr size_t sh = (size_t)WBUF(NP, 3) * sizeof(__bf16);
     static_assert(sh <= 160 * 1024, "LDS: 160 KB per CU");

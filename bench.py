@@ -93,10 +93,10 @@ def symbol_of(name):
     if m:
         np_, bn, ks = (3 if m.group(2) == "6" else 2), int(m.group(4)), (3 if m.group(1) == "3x3" else 1)
         th, nt, tail = (8, 256, "") if bn == 64 else (16, 512, "")
-        if np_ == 3:  # three pieces: 8-wave workgroups, weight tiles by LDS-DMA on the 128- / 256-channel 3x3 tiles
-            if bn == 64 and ks == 3:
-                return "conv_split_kernel<3,64,8|16,256,3>"
-            return "conv_split_kernel<3,%d,%d,%d,%d%s>" % (bn, th, nt, ks, ",1,true" if (bn > 64 and ks == 3) else "")
+        if np_ == 3:  # three pieces: weight tiles by LDS-DMA on every 3x3 instance (scan_conv3x3_bf16x6_instance)
+            if bn == 1064:
+                return "conv_split_kernel<3,64,16,512,3,1,true>"
+            return "conv_split_kernel<3,%d,%d,%d,%d%s>" % (bn, th, nt, ks, ",1,true" if ks == 3 else "")
         if bn > 2000:  # the 8-wave LDS-DMA instance of the 256-channel tile
             return "conv_split_kernel<2,%d,%d,512,3,1,true>" % (bn - 2000, th)
         if bn > 1000:

@@ -285,7 +285,8 @@ int64_t scan_conv1x1_wgrad_bf16x6_ws_floats(const scan_pyramid_t* yd, int32_t Cs
 int scan_conv1x1_wgrad_bf16x6(const float* x, const scan_pyramid_t* xd, int32_t Cs, const float* dy,
                               const scan_pyramid_t* yd, int32_t Cout, int32_t Cout_s, int32_t stride, float* dw,
                               float* db, int32_t accumulate, float* ws, void* stream);
-/* output-channel tile (64 / 128 / 256) a scan_conv3x3_bf16x6 launch on pyramid d with Nout channels takes */
+/* output-channel tile (64 / 128 / 256) a scan_conv3x3_bf16x6 launch on pyramid d with Nout channels takes; 1064 = the
+ * 64-channel tile on 16x16-pixel tiles (single-level pyramids with sizes that are multiples of 16) */
 int scan_conv3x3_bf16x6_instance(const scan_pyramid_t* d, int32_t Nout);
 /* w [Cout][T][Cin_s] -> wt [Cin_s][T][Cout_s] (zero padded) */
 int scan_weight_transpose(const float* w, int32_t Cout, int32_t T, int32_t Cin_s, float* wt, int32_t Cout_s,

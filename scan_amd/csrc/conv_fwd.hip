@@ -732,8 +732,11 @@ extern "C" int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nou
   return bn;
 }
 
-// three pieces: the output-channel tile (64 / 128 / 256); every instance runs 8 waves (4 for the 64-channel tile)
+// three pieces: the output-channel tile (64 / 128 / 256; 8 waves, LDS-DMA weight tiles), 1064 = the 64-channel tile on
+// 16x16-pixel tiles with 8 waves (single-level pyramids with sizes that are multiples of 16), 64 = on 8x16-pixel tiles, 4 waves
 extern "C" int scan_conv3x3_bf16x6_instance(const scan_pyramid_t* d, int32_t Nout) {
   if (!d) return -1;
-  return v2_instance(d, Nout);
+  const int bn = v2_instance(d, Nout);
+  if (bn == 64 && g_scan_conv_bn64_th16 && d->n_levels == 1 && d->h[0] % 16 == 0 && d->w[0] % 16 == 0) return 1064;
+  return bn;
 }

@@ -14,34 +14,46 @@ import gzip
 import json
 import sys
 
-GROUPS = [  # (substring of the kernel name, group key); conv keys = the symbols bench.py's roofline names
-    ("conv_bf16x3_v2_kernelILi256ELi16ELi1024ELi3", "conv_bf16x3_v2_kernel<256,16,1024,3>"),
-    ("conv_bf16x3_v2_kernelILi256ELi16ELi512ELi3ELi1ELb1E", "conv_bf16x3_v2_kernel<256,16,512,3,1,true>"),
-    ("conv_bf16x3_v2_kernelILi256ELi16ELi512ELi3", "conv_bf16x3_v2_kernel<256,16,512,3>"),
-    ("conv_bf16x3_v2_kernelILi128ELi16ELi1024ELi3", "conv_bf16x3_v2_kernel<128,16,1024,3>"),
-    ("conv_bf16x3_v2_kernelILi128ELi16ELi512ELi3", "conv_bf16x3_v2_kernel<128,16,512,3>"),
-    ("conv_bf16x3_v2_kernelILi64ELi8ELi256ELi3", "conv_bf16x3_v2_kernel<64,8,256,3>"),
-    ("conv_bf16x3_v2_kernelILi64ELi16ELi256ELi3", "conv_bf16x3_v2_kernel<64,16,256,3>"),
+def _conv_groups():
+    """(substring, key) for the template instances of the split-operand conv kernels, in their mangled and demangled spelling;
+    keys = the symbols bench.py's roofline names"""
+    out = []
+    for np_ in (3, 2):
+        for bn, th, nt, ks, tpb, gl in ((256, 16, 512, 3, 1, True), (256, 16, 1024, 3, 1, True), (256, 16, 1024, 3, 1, False),
+                                        (256, 16, 512, 3, 1, False), (128, 16, 512, 3, 1, True), (128, 16, 512, 3, 1, False),
+                                        (128, 16, 1024, 3, 3, True), (128, 16, 1024, 3, 3, False), (128, 16, 1024, 3, 1, True),
+                                        (128, 16, 1024, 3, 1, False), (128, 16, 512, 3, 3, False), (64, 16, 512, 3, 1, True),
+                                        (64, 8, 256, 3, 1, True), (64, 16, 512, 3, 1, False), (64, 16, 256, 3, 1, False),
+                                        (64, 8, 256, 3, 3, False), (64, 8, 256, 3, 1, False), (128, 16, 512, 1, 1, False),
+                                        (64, 8, 256, 1, 1, False)):
+            key = "conv_split_kernel<%d,%d,%d,%d,%d%s>" % (np_, bn, th, nt, ks, ",%d,true" % tpb if gl else ("" if tpb == 1 else ",%d" % tpb))
+            out.append(("conv_split_kernelILi%dELi%dELi%dELi%dELi%dELi%dELb%dEE" % (np_, bn, th, nt, ks, tpb, int(gl)), key))
+            out.append(("conv_split_kernel<%d, %d, %d, %d, %d, %d, %s>" % (np_, bn, th, nt, ks, tpb, "true" if gl else "false"), key))
+        wk = 32 if np_ == 3 else 64
+        for tom, tcw in ((2, 4), (4, 2)):
+            key = "conv_wgrad_v6_kernel<%d,%d,3>" % (np_, wk)
+            out.append(("conv_wgrad_v6_kernelILi%dELi%dELi3ELi%dELi%dEE" % (np_, wk, tom, tcw), key))
+            out.append(("conv_wgrad_v6_kernel<%d, %d, 3, %d, %d>" % (np_, wk, tom, tcw), key))
+        out.append(("conv_wgrad_v4_kernelILi%dELi3E" % np_, "conv_wgrad_v4_kernel<%d,3,1>" % np_))
+        out.append(("conv_wgrad_v4_kernel<%d, 3" % np_, "conv_wgrad_v4_kernel<%d,3,1>" % np_))
+        out.append(("conv_wgrad_v4_kernelILi%dELi1E" % np_, "conv_wgrad_v4_kernel<%d,1,S>" % np_))
+        out.append(("conv_wgrad_v4_kernel<%d, 1" % np_, "conv_wgrad_v4_kernel<%d,1,S>" % np_))
+        out.append(("conv_smallcin_kernelILi%dE" % np_, "conv_smallcin_kernel<%d>" % np_))
+        out.append(("conv_smallcin_kernel<%d," % np_, "conv_smallcin_kernel<%d>" % np_))
+    return out
+
+
+GROUPS = _conv_groups() + [  # (substring of the kernel name, group key)
     ("gconv_taps_kernel", "gconv_taps"), ("gconv_gather_kernel", "gconv_gather"), ("gconv_bwd_kernel", "gconv_bwd"),
     ("weight_split_batched_kernel", "weight_split_batched"), ("sgd_multi_kernel", "sgd_multi"),
-    ("conv_bf16x3_v2_kernelILi128ELi16ELi512ELi1", "conv_bf16x3_v2_kernel<128,16,512,1>"),
-    ("conv_bf16x3_v2_kernelILi64ELi8ELi256ELi1", "conv_bf16x3_v2_kernel<64,8,256,1>"),
-    ("conv3x3_bf16x3_kernelILi128ELi16ELi512ELi3", "conv3x3_bf16x3_fwd_dgrad_bn128"),
-    ("conv3x3_bf16x3_kernelILi64ELi8ELi256ELi3", "conv3x3_bf16x3_fwd_bn64"),
-    ("conv3x3_bf16x3_kernelILi128ELi16ELi512ELi1", "conv1x1_bf16x3_fwd_dgrad_bn128"),
-    ("conv3x3_bf16x3_kernelILi64ELi8ELi256ELi1", "conv1x1_bf16x3_fwd_dgrad_bn64"),
-    ("conv_wgrad_bf16x3_v6_kernel", "conv_wgrad_bf16x3_v6_kernel<3>"),
-    ("conv_wgrad_bf16x3_v4_kernelILi3", "conv_wgrad_bf16x3_v4_kernel<3,1>"), ("conv_wgrad_bf16x3_v4_kernel<3", "conv_wgrad_bf16x3_v4_kernel<3,1>"),
-    ("conv_wgrad_bf16x3_v4_kernelILi1", "conv_wgrad_bf16x3_v4_kernel<1,S>"), ("conv_wgrad_bf16x3_v4_kernel<1", "conv_wgrad_bf16x3_v4_kernel<1,S>"),
+    ("conv3x3_bf16x3_kernelILi256ELi16ELi512ELi3", "conv3x3_bf16x3_kernel<256,16,512>"),
+    ("conv3x3_bf16x3_kernelILi128ELi16ELi512ELi3", "conv3x3_bf16x3_kernel<128,16,512>"),
+    ("conv3x3_bf16x3_kernelILi64ELi8ELi256ELi3", "conv3x3_bf16x3_kernel<64,8,256>"),
     ("fcos_assign_kernel", "fcos_assign"), ("fcos_compact_kernel", "fcos_compact"), ("fcos_nodes_kernel", "fcos_nodes"),
     ("upsample2x_add_kernel", "upsample2x_add"), ("downsample2x_sum_kernel", "downsample2x_sum"),
-    ("conv_wgrad_bf16x3_v2_kernelILi3", "conv_wgrad_bf16x3_v2_kernel<3,1>"), ("conv_wgrad_bf16x3_v2_kernel<3", "conv_wgrad_bf16x3_v2_kernel<3,1>"),
-    ("conv_wgrad_bf16x3_v2_kernelILi1", "conv_wgrad_bf16x3_v2_kernel<1,S>"), ("conv_wgrad_bf16x3_v2_kernel<1", "conv_wgrad_bf16x3_v2_kernel<1,S>"),
-    ("conv3x3_wgrad_bf16x3_kernelILi3", "conv3x3_wgrad_bf16x3_kernel<3,1>"), ("conv3x3_wgrad_bf16x3_kernel<3", "conv3x3_wgrad_bf16x3_kernel<3,1>"),
-    ("conv3x3_wgrad_bf16x3_kernelILi1", "conv3x3_wgrad_bf16x3_kernel<1,S>"), ("conv3x3_wgrad_bf16x3_kernel<1", "conv3x3_wgrad_bf16x3_kernel<1,S>"),
-    ("conv_smallcin_kernel", "conv_smallcin_kernel"), ("dbscan_neighbors_kernel", "dbscan_neighbors"),
-    ("slab_bias_reduce_kernel", "slab_bias_reduce"),
+    ("dbscan_neighbors_kernel", "dbscan_neighbors"), ("slab_bias_reduce_kernel", "slab_bias_reduce"),
     ("conv_igemm_kernel<0", "conv_igemm_kernel<0,4>"), ("conv_igemm_kernel<1", "conv_igemm_kernel<1,4>"),
+    ("conv_igemm_kernelILi0", "conv_igemm_kernel<0,4>"), ("conv_igemm_kernelILi1", "conv_igemm_kernel<1,4>"),
     ("conv_wgrad_kernel", "conv_wgrad_kernel"),
     ("gn_stats_kernel", "gn_stats"), ("gn_apply_kernel", "gn_apply"), ("gn_bwd_reduce_kernel", "gn_bwd_reduce"),
     ("gn_bwd_apply_kernel", "gn_bwd_apply"), ("relu_bwd_kernel", "relu_bwd"),

@@ -384,6 +384,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v4_kernel(
 // 64-pixel chunk would need 2 x 112 KB) -- the MFMA work per chunk and barrier is the same (twice the products on half
 // the pixels), the producers convert half the elements into 1.5x the planes.
 // ------------------------------------------------------------------------------------------------
+#ifndef SCAN_WG_TCHAIN
+#define SCAN_WG_TCHAIN 1  // three pieces, 32 x 64 wave tile: per-step temporary accumulator (wgrad_mma_v6)
+#endif
+#ifndef SCAN_WG_TG
+#define SCAN_WG_TG 0  // > 0: column tiles per block of the temporary-accumulator form (fewer temporaries)
+#endif
 #ifndef SCAN_WG_SB
 #define SCAN_WG_SB 1  // scheduling fence behind every (tap, column tile) block of the consumers' MFMAs, see wgrad_mma_v6
 #endif
@@ -414,10 +420,11 @@ __device__ __forceinline__ W6Lane w6_lane(unsigned lds_base, int row_lane, int c
 
 // TO x TC live 16 x 16 tiles of this wave (of TOMAX x TCMAX).  The X fragments of G column tiles are read together so that
 // G * TO >= 4 independent accumulators separate two MFMAs on the same one.
-template <int NP, int WKC, int TO, int TC, int KX, int TOMAX, int TCMAX>
+template <int NP, int WKC, int TO, int TC, int KX, int TOMAX, int TCMAX, bool TCHAIN>
 __device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][TCMAX][TOMAX]) {
   constexpr unsigned APL = 2 * WKC * W6ROW, BPL = 2 * (WKC + KX - 1) * W6ROW, ROWB = 2 * W6ROW;  // bytes
-  constexpr int G = (TO >= 4 || TC == 1) ? 1 : (TO == 2 ? (TC >= 2 ? 2 : 1) : (TC >= 4 ? 4 : TC));
+  constexpr int G0 = (TO >= 4 || TC == 1) ? 1 : (TO == 2 ? (TC >= 2 ? 2 : 1) : (TC >= 4 ? 4 : TC));
+  constexpr int G = (TCHAIN && SCAN_WG_TG > 0 && SCAN_WG_TG < G0) ? SCAN_WG_TG : G0;
   static_assert(TC % G == 0, "column tiles per block");
 #pragma unroll
   for (int s = 0; s < WKC / 32; ++s) {
@@ -442,15 +449,40 @@ __device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][
           for (int p = 0; p < NP; ++p) b[g][p] = tr_read8_at(o0 + p * BPL, o1 + p * BPL);
         }
         // piece products, smallest first; within a magnitude class the dY piece index descends (wgrad_pieces)
+        if constexpr (TCHAIN) {
+          // the six products of a 32-pixel step are summed in a temporary that starts at zero and is added to the running
+          // accumulator ONCE: one rounding at the accumulator's magnitude per step instead of six (the temporary's own
+          // roundings are relative to a 32-term sum).  Over the 8,192-pixel chains of a split-K slab that is what separates
+          // the weight gradient's distance from fp64 from the exact fp32-MFMA kernel's.
+          f32x4v tmp[G][TO];
 #pragma unroll
-        for (int d = NP - 1; d >= 0; --d)
+          for (int g = 0; g < G; ++g)
 #pragma unroll
-          for (int i = d; i >= 0; --i)
+            for (int to = 0; to < TO; ++to) tmp[g][to] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int g = 0; g < G; ++g)
+          for (int d = NP - 1; d >= 0; --d)
 #pragma unroll
-              for (int to = 0; to < TO; ++to)
-                acc[kx][tc0 + g][to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][to], b[g][d - i], acc[kx][tc0 + g][to], 0, 0, 0);
+            for (int i = d; i >= 0; --i)
+#pragma unroll
+              for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int to = 0; to < TO; ++to)
+                  tmp[g][to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][to], b[g][d - i], tmp[g][to], 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int to = 0; to < TO; ++to) acc[kx][tc0 + g][to] += tmp[g][to];
+        } else {
+#pragma unroll
+          for (int d = NP - 1; d >= 0; --d)
+#pragma unroll
+            for (int i = d; i >= 0; --i)
+#pragma unroll
+              for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int to = 0; to < TO; ++to)
+                  acc[kx][tc0 + g][to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][to], b[g][d - i], acc[kx][tc0 + g][to], 0, 0, 0);
+        }
 #if SCAN_WG_SB
         __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -677,7 +709,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
     W6Lane wl = w6_lane<NP, WKC>((unsigned)(uintptr_t)(lds_ptr_t)sm, row_lane, col4, a_col, b_col);
     unsigned flip = 2u * STAGE;  // bytes; +-: unsigned wrap-around is the subtraction
     for (int k = 0; k < nch; ++k) {
-      if constexpr (TO > 0) wgrad_mma_v6<NP, WKC, TO, TC, KX, TOMAX, TCMAX>(wl, acc);
+      if constexpr (TO > 0) wgrad_mma_v6<NP, WKC, TO, TC, KX, TOMAX, TCMAX, SCAN_WG_TCHAIN && NP == 3 && TOM == 2>(wl, acc);
       wl.a += flip;
       wl.b += flip;
       wl.b1[0] += flip;

@@ -15,30 +15,50 @@ template <bool G2>
 __device__ __forceinline__ float focal_pow(float b, float gamma) {
   return G2 ? b * b : powf(b, gamma);
 }
+// One v_exp_f32, one v_rcp_f32 and one v_log_f32 per element, shared by both branches (round 4; the kernels were bound
+// by vector-ALU issue, not by HBM: profiles/r03_pointwise_counters.txt -- two expf, a full-precision division and one or
+// two logf per element through the math library):
+//     e = exp(-|x|) in (0, 1]        r = 1 / (1 + e)        L = log(1 + e)
+//     sigmoid(x) = x >= 0 ? r : e r         1 - sigmoid(x) = x >= 0 ? e r : r
+//     log sigmoid(x) = min(x, 0) - L        the reference's second term -x [x >= 0] - log(1 + exp(x - 2 x [x >= 0])) = -max(x, 0) - L
+// v_exp_f32 / v_log_f32 are good to ~1 ulp of their result and v_rcp_f32 to 1 ulp; L switches to its series below 2^-7
+// where log(1 + e) would lose the low bits of e.  Against the C oracle (the reference's CUDA formula in libm floats) the
+// element losses agree to rtol 1e-5 / atol 1e-7 as before (tests/test_gpu_kernels.py::test_sigmoid_focal_*).
+struct SigParts {
+  float p, q, L;  // sigmoid(x), 1 - sigmoid(x), log(1 + exp(-|x|))
+};
+__device__ __forceinline__ float fast_log1p_unit(float e) {  // log(1 + e), 0 <= e <= 1
+  return e < 0.0078125f ? e * (1.f - e * (0.5f - e * 0.33333334f)) : __logf(1.f + e);
+}
+__device__ __forceinline__ SigParts sig_parts(float x) {
+  const float e = __expf(-fabsf(x));
+  const float r = __builtin_amdgcn_rcpf(1.f + e);
+  const float er = e * r;
+  SigParts s;
+  s.p = x >= 0.f ? r : er;
+  s.q = x >= 0.f ? er : r;
+  s.L = fast_log1p_unit(e);
+  return s;
+}
 template <bool G2>
 __device__ __forceinline__ float focal_fwd_elem(float x, int t, int d, float gamma, float alpha) {
   if (t < 0) return 0.f;
-  const float p = 1.f / (1.f + expf(-x));
+  const SigParts s = sig_parts(x);
   if (t == d + 1) {
-    const float term1 = focal_pow<G2>(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
-    return -term1 * alpha;
+    const float logp = fmaxf(fminf(x, 0.f) - s.L, -87.33654f);  // log(max(p, FLT_MIN))
+    return -focal_pow<G2>(s.q, gamma) * logp * alpha;
   }
-  const float ge = (x >= 0.f) ? 1.f : 0.f;
-  const float term2 = focal_pow<G2>(p, gamma) * (-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge)));
-  return -term2 * (1.f - alpha);
+  return focal_pow<G2>(s.p, gamma) * (fmaxf(x, 0.f) + s.L) * (1.f - alpha);
 }
 template <bool G2>
 __device__ __forceinline__ float focal_bwd_elem(float x, int t, int d, float gamma, float alpha) {
   if (t < 0) return 0.f;
-  const float p = 1.f / (1.f + expf(-x));
+  const SigParts s = sig_parts(x);
   if (t == d + 1) {
-    const float term1 = focal_pow<G2>(1.f - p, gamma) * (1.f - p - (p * gamma * logf(fmaxf(p, FLT_MIN))));
-    return -term1 * alpha;
+    const float logp = fmaxf(fminf(x, 0.f) - s.L, -87.33654f);
+    return -focal_pow<G2>(s.q, gamma) * (s.q - s.p * gamma * logp) * alpha;
   }
-  const float ge = (x >= 0.f) ? 1.f : 0.f;
-  const float term2 =
-      focal_pow<G2>(p, gamma) * ((-1.f * x * ge - logf(1.f + expf(x - 2.f * x * ge))) * (1.f - p) * gamma - p);
-  return -term2 * (1.f - alpha);
+  return -focal_pow<G2>(s.p, gamma) * ((-fmaxf(x, 0.f) - s.L) * s.q * gamma - s.p) * (1.f - alpha);
 }
 
 // row (label index) and class of the 4 consecutive elements starting at i0 = 4q.  CT = compile-time class count of the
@@ -307,7 +327,7 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ 
     const float t = targets ? targets[i] : const_target;
     const float w = weight ? weight[i * w_stride] : 1.f;
     // max(x,0) - x*t + log(1 + exp(-|x|))
-    const float l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    const float l = fmaxf(x, 0.f) - x * t + fast_log1p_unit(__expf(-fabsf(x)));
     num += l * w;
     den += w;
   }
@@ -391,7 +411,7 @@ __global__ __launch_bounds__(256) void cka_fwd_kernel(const float* __restrict__ 
       if (c < Cf) {
         const float x = logits[i * Cf + c];
         const float w = act[i * (Cf + 1) + c + 1];
-        const float l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+        const float l = fmaxf(x, 0.f) - x * t + fast_log1p_unit(__expf(-fabsf(x)));
         num[c] += l * w;
         den[c] += w;
       }
@@ -427,7 +447,7 @@ __global__ __launch_bounds__(256) void cka_fwd8_kernel(const float* __restrict__
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float w = a[e];
-      const float l = fmaxf(x[e], 0.f) - x[e] * t + log1pf(expf(-fabsf(x[e])));
+      const float l = fmaxf(x[e], 0.f) - x[e] * t + fast_log1p_unit(__expf(-fabsf(x[e])));
       num[e] += l * w;
       den[e] += w;
     }

@@ -653,11 +653,11 @@ def test_wgrad_full_size_elementwise(device, case, mode, monkeypatch):
     e, e32 = sampled_err(dw), sampled_err(dw32)
     print("wgrad error vs fp64 (max, rms)", case, mode, e, "fp32-MFMA", e32)
     if mode == "bf16x6":
-        # a split-K slab accumulates its pixels in fp32 with one rounded addition per piece product and 32-pixel step: over
-        # the 8,192-pixel chains of conv3_2 the result sits ~2x further from fp64 (rms) than the fp32-MFMA kernel's, whose
-        # chains are shorter -- the same order, the same class as any fp32 implementation (tools/wgrad_err.py: the distance
-        # falls as 1 / sqrt(slabs)); the largest single deviation is the same
-        assert e[0] <= 5e-6 and e[1] <= 2.5 * e32[1] and e[1] <= 1.5e-6 and e[0] <= 1.6 * e32[0], (e, e32)
+        # no further from fp64 than the exact fp32-MFMA kernel: the six piece products of a 32-pixel step are summed in a
+        # temporary and added to the running accumulator once (csrc/conv_wgrad.hip: TCHAIN), so a split-K slab's 8,192-pixel
+        # chain rounds once per step at the accumulator's magnitude.  Measured 0.2-0.5x the fp32-MFMA kernel's rms
+        # (tools/wgrad_err.py); without the temporary it was 1.0-2.1x
+        assert e[0] <= 5e-6 and e[1] <= 1.1 * e32[1] and e[0] <= 1.5 * e32[0], (e, e32)
     else:
         assert e[0] <= 1e-4, e
     # adjoint identities (bias removed from y), fp64 accumulation on the device

@@ -145,8 +145,8 @@ def main():
                 olds = []
                 for kv in key.split("+"):
                     k, v = kv.split("=")
+                    assert _lib.query("scan_tune_get", k.encode()) != -1 or k == "wgrad_tile", "unknown scan_tune key " + k
                     olds.append((k, _lib.query("scan_tune", k.encode(), int(v))))
-                    assert olds[-1][1] >= 0, k
                 y, us, tf = {"fwd": run, "dgrad": run_dgrad, "wgrad": run_wgrad}[a.op](sd, a.reps, dev)
                 for k, o in olds:
                     _lib.query("scan_tune", k.encode(), o)

@@ -324,7 +324,11 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
         bf16x8 wf[NP];
         read_w(bt, tn, wf);
         mma_pieces<NP, TM>(wf, pf, acc[tn]);
+#ifdef SCAN_EXP_MID_STAGGER  // timing experiment (make exp_mid_stagger): the second wave of a SIMD feeds half an interval later
+        if (tt == 0 && tn == ((wid >= WAVES / 2 && TN >= 8) ? SCAN_EXP_MID_STAGGER : SCAN_CONV_MID)) {
+#else
         if (tt == 0 && tn == SCAN_CONV_MID) {
+#endif
           __builtin_amdgcn_sched_barrier(0);
           mid();
           __builtin_amdgcn_sched_barrier(0);

@@ -567,75 +567,128 @@ extern "C" int scan_scale(const float* x, float alpha, float* y, int64_t n, void
 // Rows are K floats (36 B at K = 9): a lane reading its own row touches a new cache line every 3-4 lanes.  A block
 // therefore moves its 256 rows as ONE contiguous 256*K-float segment with coalesced dword accesses through LDS and each
 // lane then walks its row in LDS (stride K floats: conflict-free for odd K).
+// Round 4: no workgroup barriers.  A WAVE moves its own 64 rows (64 * K floats, contiguous) through a private LDS region:
+// K coalesced dword loads per lane (lane + 64 j), written to LDS, then every lane walks its row there (stride K floats:
+// conflict-free for odd K); LDS operations of one wave execute in order, so a wave-level fence is all that is needed.
+// Two 64-row batches are in flight per wave and iteration (the first cut -- 256 rows per workgroup between two
+// __syncthreads -- spent 72 % of its wave cycles parked: profiles/r03_pointwise_counters.txt).
 template <bool BWD>
 __global__ __launch_bounds__(256) void sfl_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
                                                   int64_t M, int K, float gamma, float d_scale,
                                                   float* __restrict__ loss_sum, float* __restrict__ d_logits) {
-  __shared__ __align__(16) float rows[256 * SFL_MAXK];
+  constexpr int NB = 2;  // batches of 64 rows per wave and iteration
+  __shared__ float rows_all[4 * NB * 64 * SFL_MAXK];
   __shared__ float red[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float* wrows = rows_all + wid * (NB * 64 * SFL_MAXK);
   const bool g2 = gamma == 2.0f;
+  const bool vec_ok = (reinterpret_cast<uintptr_t>(logits) & 15) == 0;
   float acc = 0.f;
-  const int64_t nblk = (M + 255) / 256;
-  for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
-    const int64_t r0 = b * 256;
-    const int nrow = (int)((M - r0 < 256) ? (M - r0) : 256);
-    const int nf = nrow * K;
-    const float* src = logits + r0 * K;
-    if (nrow == 256 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-      for (int j = threadIdx.x; j < 64 * K; j += 256)  // 256 * K floats = 64 * K float4
-        reinterpret_cast<float4*>(rows)[j] = reinterpret_cast<const float4*>(src)[j];
-    } else {
-      for (int j = threadIdx.x; j < nf; j += 256) rows[j] = src[j];
-    }
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t < nrow) {
-      const float* z = rows + t * K;
-      float e[SFL_MAXK];
-      float mx = z[0];
+  const int64_t nbatch = (M + 63) / 64;
+  const int64_t stride = (int64_t)gridDim.x * 4 * NB;
+  for (int64_t b0 = ((int64_t)blockIdx.x * 4 + wid) * NB; b0 < nbatch; b0 += stride) {
+    constexpr int NV = SFL_MAXK / 4;  // float4 per lane and batch: 64 rows x K floats = 16 K float4, lane + 64 j
+    float4 v[NB][NV];
+    int nrow[NB];
 #pragma unroll
-      for (int k = 1; k < SFL_MAXK; ++k)
-        if (k < K) mx = fmaxf(mx, z[k]);
-      float den = 0.f;
+    for (int u = 0; u < NB; ++u) {
+      const int64_t r0 = (b0 + u) * 64;
+      nrow[u] = r0 < M ? (int)((M - r0 < 64) ? (M - r0) : 64) : 0;
+      const float* src = logits + r0 * K;  // 64 * K * 4 bytes per batch: 16-byte aligned whenever logits is
+      const int nf = nrow[u] * K;
 #pragma unroll
-      for (int k = 0; k < SFL_MAXK; ++k) {
-        e[k] = (k < K) ? expf(z[k] - mx) : 0.f;
-        den += e[k];
-      }
-      const int lab = (int)labels[r0 + t];
-      float el = 0.f;
-#pragma unroll
-      for (int k = 0; k < SFL_MAXK; ++k) el = (k == lab) ? e[k] : el;
-      if (!BWD) {
-        float p = el / den;
-        p = fmaxf(p, 1e-15f);
-        const float om = 1.f - p;
-        acc += -(g2 ? om * om : powf(om, gamma)) * logf(p);
-      } else {
-        const float inv = 1.f / den;
-        const float p = el * inv;
-        float dLdp = 0.f;  // clamp(min=1e-15) has zero gradient below the clamp
-        if (p >= 1e-15f) {
-          const float om = 1.f - p;
-          dLdp = g2 ? (2.f * om * logf(p) - om * om / p) : (gamma * powf(om, gamma - 1.f) * logf(p) - powf(om, gamma) / p);
+      for (int j = 0; j < NV; ++j) {
+        const int i4 = 4 * (lane + 64 * j);
+        v[u][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i4 + 3 < nf && vec_ok) {
+          v[u][j] = *reinterpret_cast<const float4*>(src + i4);
+        } else if (i4 < nf) {
+          v[u][j].x = src[i4];
+          if (i4 + 1 < nf) v[u][j].y = src[i4 + 1];
+          if (i4 + 2 < nf) v[u][j].z = src[i4 + 2];
+          if (i4 + 3 < nf) v[u][j].w = src[i4 + 3];
         }
-        const float c = dLdp * p * d_scale;
+      }
+    }
 #pragma unroll
-        for (int k = 0; k < SFL_MAXK; ++k)
-          if (k < K) rows[t * K + k] = c * ((k == lab ? 1.f : 0.f) - e[k] * inv);
+    for (int u = 0; u < NB; ++u)
+#pragma unroll
+      for (int j = 0; j < NV; ++j)
+        if (4 * 64 * j < 64 * K) *reinterpret_cast<float4*>(wrows + u * 64 * SFL_MAXK + 4 * (lane + 64 * j)) = v[u][j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int u = 0; u < NB; ++u) {
+      const int64_t r0 = (b0 + u) * 64;
+      float* z = wrows + u * 64 * SFL_MAXK + lane * K;
+      if (lane < nrow[u]) {
+        float e[SFL_MAXK];
+        float mx = z[0];
+#pragma unroll
+        for (int k = 1; k < SFL_MAXK; ++k)
+          if (k < K) mx = fmaxf(mx, z[k]);
+        float den = 0.f;
+#pragma unroll
+        for (int k = 0; k < SFL_MAXK; ++k) {
+          e[k] = (k < K) ? __expf(z[k] - mx) : 0.f;
+          den += e[k];
+        }
+        const int lab = (int)labels[r0 + lane];
+        float el = 0.f;
+#pragma unroll
+        for (int k = 0; k < SFL_MAXK; ++k) el = (k == lab) ? e[k] : el;
+        const float inv = __builtin_amdgcn_rcpf(den);
+        const float pr = el * inv;
+        if (!BWD) {
+          const float p = fmaxf(pr, 1e-15f);
+          const float om = 1.f - p;
+          // log p through its series near p = 1: log(p) there loses the low bits of 1 - p
+          const float lp = om < 0.0078125f ? -om * (1.f + om * (0.5f + om * 0.33333334f)) : __logf(p);
+          acc += -(g2 ? om * om : powf(om, gamma)) * lp;
+        } else {
+          float dLdp = 0.f;  // clamp(min=1e-15) has zero gradient below the clamp
+          if (pr >= 1e-15f) {
+            const float om = 1.f - pr;
+            const float lp = om < 0.0078125f ? -om * (1.f + om * (0.5f + om * 0.33333334f)) : __logf(pr);
+            const float ip = __builtin_amdgcn_rcpf(pr);
+            dLdp = g2 ? (2.f * om * lp - om * om * ip) : (gamma * powf(om, gamma - 1.f) * lp - powf(om, gamma) * ip);
+          }
+          const float c = dLdp * pr * d_scale;
+#pragma unroll
+          for (int k = 0; k < SFL_MAXK; ++k)
+            if (k < K) z[k] = c * ((k == lab ? 1.f : 0.f) - e[k] * inv);
+        }
       }
     }
-    __syncthreads();
     if (BWD) {
-      float* dst = d_logits + r0 * K;
-      if (nrow == 256 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-        for (int j = threadIdx.x; j < 64 * K; j += 256)
-          reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(rows)[j];
-      } else {
-        for (int j = threadIdx.x; j < nf; j += 256) dst[j] = rows[j];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int u = 0; u < NB; ++u) {
+        const int64_t r0 = (b0 + u) * 64;
+        float* dst = d_logits + r0 * K;
+        const int nf = nrow[u] * K;
+        const bool st_ok = (reinterpret_cast<uintptr_t>(d_logits) & 15) == 0;
+#pragma unroll
+        for (int j = 0; j < SFL_MAXK / 4; ++j) {
+          const int i4 = 4 * (lane + 64 * j);
+          const float4 o = *reinterpret_cast<const float4*>(wrows + u * 64 * SFL_MAXK + i4);
+          if (i4 + 3 < nf && st_ok) {
+            *reinterpret_cast<float4*>(dst + i4) = o;
+          } else if (i4 < nf) {
+            dst[i4] = o.x;
+            if (i4 + 1 < nf) dst[i4 + 1] = o.y;
+            if (i4 + 2 < nf) dst[i4 + 2] = o.z;
+            if (i4 + 3 < nf) dst[i4 + 3] = o.w;
+          }
+        }
       }
-      __syncthreads();
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();  // the region is rewritten by the next iteration's batches
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
   if (!BWD) {
     const float sum = block_sum_256(acc, red);
@@ -648,7 +701,7 @@ extern "C" int scan_softmax_focal_forward(const float* logits, const int64_t* la
   SCAN_CHECK_ARG(M >= 0 && K > 0 && K <= SFL_MAXK && loss_sum, "softmax_focal_forward: bad arguments (K=%d)", K);
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && labels, "softmax_focal_forward: null input");
-  int64_t g = (M + 255) / 256;
+  int64_t g = (M + 511) / 512;  // a workgroup iteration covers 4 waves x 2 batches x 64 rows
   if (g > 2048) g = 2048;
   hipLaunchKernelGGL(sfl_kernel<false>, dim3((int)g), dim3(256), 0, as_stream(stream), logits, labels, M, K, gamma, 0.f,
                      loss_sum, (float*)nullptr);
@@ -661,7 +714,7 @@ extern "C" int scan_softmax_focal_backward(const float* logits, const int64_t* l
   SCAN_CHECK_ARG(M >= 0 && K > 0 && K <= SFL_MAXK, "softmax_focal_backward: bad arguments (K=%d)", K);
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && labels && d_logits, "softmax_focal_backward: null pointer");
-  int64_t g = (M + 255) / 256;
+  int64_t g = (M + 511) / 512;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(sfl_kernel<true>, dim3((int)g), dim3(256), 0, as_stream(stream), logits, labels, M, K, gamma,
                      d_scale, (float*)nullptr, d_logits);

@@ -387,6 +387,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_v4_kernel(
 #ifndef SCAN_WG_TCHAIN
 #define SCAN_WG_TCHAIN 1  // three pieces, 32 x 64 wave tile: per-step temporary accumulator (wgrad_mma_v6)
 #endif
+#ifndef SCAN_WG_PIPE
+#define SCAN_WG_PIPE 1  // three pieces, 32 x 64 wave tile: hand-pipelined consumer loop (wgrad_mma_v6_pipe)
+#endif
 #ifndef SCAN_WG_TG
 #define SCAN_WG_TG 0  // > 0: column tiles per block of the temporary-accumulator form (fewer temporaries)
 #endif
@@ -488,6 +491,55 @@ __device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][
 #endif
       }
     }
+  }
+}
+
+// The same chunk, software-pipelined by hand (three pieces, 32 x 64 wave tile): a block is ONE column tile of one tap
+// (2 x 6 MFMAs on a temporary pair); the X fragments of block i + 1 are requested before the MFMAs of block i are issued
+// and the scheduling fence keeps that order -- the fence-per-block form above waited for its fragments in front of every
+// block with the other wave of the SIMD mostly in the same state.  12 more registers for the second fragment set, 8 for the
+// temporaries: 162 at the 168-register cap, no scratch.  The resident dY fragments are requested tile by tile so that the
+// first block can start after 12 of the 24 transposed reads behind the barrier.
+template <int NP, int WKC, int TO, int TC, int KX, int TOMAX, int TCMAX>
+__device__ __forceinline__ void wgrad_mma_v6_pipe(const W6Lane& w, f32x4v (&acc)[KX][TCMAX][TOMAX]) {
+  static_assert(WKC == 32, "one 32-pixel step per chunk");
+  constexpr unsigned APL = 2 * WKC * W6ROW, BPL = 2 * (WKC + KX - 1) * W6ROW, ROWB = 2 * W6ROW;  // bytes
+  constexpr int NBLK = KX * TC;
+  bf16x8 a[NP][TO];
+  bf16x8 b[2][NP];
+  auto read_b = [&](int blk, bf16x8 (&dst)[NP]) {
+    const int kx = blk / TC, tc = blk % TC;
+    const unsigned o0 = w.b + kx * ROWB + 32 * tc;
+    const unsigned o1 = (kx == 0 ? w.b + 4 * ROWB : w.b1[kx - 1]) + 32 * tc;
+#pragma unroll
+    for (int p = 0; p < NP; ++p) dst[p] = tr_read8_at(o0 + p * BPL, o1 + p * BPL);
+  };
+#pragma unroll
+  for (int p = 0; p < NP; ++p) a[p][0] = tr_read8_at(w.a + p * APL, w.a + 4 * ROWB + p * APL);
+  read_b(0, b[0]);
+#pragma unroll
+  for (int t = 1; t < TO; ++t)
+#pragma unroll
+    for (int p = 0; p < NP; ++p) a[p][t] = tr_read8_at(w.a + 32 * t + p * APL, w.a + 32 * t + 4 * ROWB + p * APL);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int blk = 0; blk < NBLK; ++blk) {
+    const int kx = blk / TC, tc = blk % TC;
+    if (blk + 1 < NBLK) read_b(blk + 1, b[(blk + 1) & 1]);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4v tmp[TO];
+#pragma unroll
+    for (int to = 0; to < TO; ++to) tmp[to] = f32x4v{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = NP - 1; d >= 0; --d)
+#pragma unroll
+      for (int i = d; i >= 0; --i)
+#pragma unroll
+        for (int to = 0; to < TO; ++to)
+          tmp[to] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][to], b[blk & 1][d - i], tmp[to], 0, 0, 0);
+#pragma unroll
+    for (int to = 0; to < TO; ++to) acc[kx][tc][to] += tmp[to];
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -655,6 +707,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
     load_b();
     __syncthreads();  // stage 0 is complete
     for (int k = 0; k < nch; ++k) {
+#ifndef SCAN_EXP_WGRAD_NOPROD  // TIMING EXPERIMENT (make exp_wgrad_noprod): the producers only attend the barriers
       const int stage = (k + 1) & 1;  // chunk k + 1 is in the registers; chunk k + 2 follows it
       const bool more = k + 2 < nch;
       if (more) advance();
@@ -663,6 +716,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
       load_a();
       store_b(stage);
       load_b();
+#endif
       __syncthreads();  // the consumers are done with stage k & 1; stage (k + 1) & 1 is complete
     }
     if (do_bias) {  // column sums of this split's dY rows: reduce the 8 pixel-row groups through LDS
@@ -709,7 +763,12 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
     W6Lane wl = w6_lane<NP, WKC>((unsigned)(uintptr_t)(lds_ptr_t)sm, row_lane, col4, a_col, b_col);
     unsigned flip = 2u * STAGE;  // bytes; +-: unsigned wrap-around is the subtraction
     for (int k = 0; k < nch; ++k) {
-      if constexpr (TO > 0) wgrad_mma_v6<NP, WKC, TO, TC, KX, TOMAX, TCMAX, SCAN_WG_TCHAIN && NP == 3 && TOM == 2>(wl, acc);
+      if constexpr (TO > 0) {
+        if constexpr (SCAN_WG_PIPE && SCAN_WG_TCHAIN && NP == 3 && TOM == 2)
+          wgrad_mma_v6_pipe<NP, WKC, TO, TC, KX, TOMAX, TCMAX>(wl, acc);
+        else
+          wgrad_mma_v6<NP, WKC, TO, TC, KX, TOMAX, TCMAX, SCAN_WG_TCHAIN && NP == 3 && TOM == 2>(wl, acc);
+      }
       wl.a += flip;
       wl.b += flip;
       wl.b1[0] += flip;

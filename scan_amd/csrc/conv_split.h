@@ -19,17 +19,29 @@ typedef float f32x4v __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
-// pieces of four values: q[0] = hi ... q[NP - 1] = lo
+// pieces of four values: q[0] = hi ... q[NP - 1] = lo.  Written on PAIRS so that each step is one packed instruction:
+// v_cvt_pk_bf16_f32 rounds and packs two values, the two floats behind a packed pair are a shift and a mask of its dword,
+// the residual is one v_pk_add_f32 -- 8 vector instructions per float4 and residual stage instead of the 11-12 the
+// element-wise form compiled to (the split runs beside the MFMA stream and every vector instruction of it takes an issue
+// slot from the matrix pipe: profiles/r04_wgrad_exp.txt).
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 template <int NP>
 __device__ __forceinline__ void split4_np(const float4 v, bf16x4 (&q)[NP]) {
-  float r[4] = {v.x, v.y, v.z, v.w};
+  f32x2v r0 = {v.x, v.y}, r1 = {v.z, v.w};
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const __bf16 b = (__bf16)r[k];
-      q[p][k] = b;
-      if (p + 1 < NP) r[k] -= (float)b;
+    const bf16x2 b0 = __builtin_convertvector(r0, bf16x2), b1 = __builtin_convertvector(r1, bf16x2);
+    q[p][0] = b0[0];
+    q[p][1] = b0[1];
+    q[p][2] = b1[0];
+    q[p][3] = b1[1];
+    if (p + 1 < NP) {
+      const unsigned u0 = __builtin_bit_cast(unsigned, b0), u1 = __builtin_bit_cast(unsigned, b1);
+      const f32x2v f0 = {__builtin_bit_cast(float, u0 << 16), __builtin_bit_cast(float, u0 & 0xffff0000u)};
+      const f32x2v f1 = {__builtin_bit_cast(float, u1 << 16), __builtin_bit_cast(float, u1 & 0xffff0000u)};
+      r0 -= f0;
+      r1 -= f1;
     }
   }
 }

@@ -393,6 +393,10 @@ def main():
     # ---- companion legs (N = 1, headline model only): same frames, same trainer, outside the timed region
     strict = fast = three_phase = infer = dp1 = None
 
+    def note(msg):  # progress on stderr: the JSON line is the only thing on stdout
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
     def mode_leg(conv_mode, steps, what):
         """the SAME step with every convolution in another arithmetic (ops.CONV_MODE), timed over `steps` steps, plus one
         serial step under the kernel timer for its dominant kernel"""
@@ -431,9 +435,11 @@ def main():
         # (a) the exact fp32 matrix-core kernels (v_mfma_f32_32x32x2_f32 / 16x16x4_f32 = an fp32 fma chain): the same
         # arithmetic as the headline on the 16x narrower pipe; and the two-piece split (16 significand bits per operand:
         # NARROWER than the reference's arithmetic, 2e-6 on the losses) -- what giving up the third piece would buy
+        note("headline done: %.2f ms/step; companion legs" % (dt / a.steps * 1e3))
         strict = mode_leg("fp32", a.strict_steps, "f32 (exact fp32 MFMA, v_mfma_f32_32x32x2_f32 / 16x16x4_f32)")
         fast = mode_leg("bf16x3", a.steps, "bf16x3 (two bf16 pieces per operand = 16 significand bits, 3 bf16 MFMAs per "
                                            "product: narrower than the reference's fp32 multiply; not the headline)")
+        note("strict %.1f ms, two-piece %.1f ms; three-phase schedule" % (strict["ms_per_step"], fast["ms_per_step"]))
         # (b) the reference's three-phase schedule (source forward/backward, target forward/backward as separate
         # pyramids): what do_train runs when source and target batches pad to different sizes
         trainer.paired = False
@@ -452,6 +458,7 @@ def main():
             trainer.paired = True
         # (c) inference on the same frames (engine.inference: backbone + middle head + FCOS head + post-processing +
         # batched NMS, TEST.MODE of the yaml), and the NMS launch alone on the last image's candidate set
+        note("three-phase %.1f ms; inference" % three_phase["ms_per_step"])
         import scan_amd.modeling.fcos as fcos_mod
         frames = imgs_t
         for _ in range(2):
@@ -483,6 +490,7 @@ def main():
             m_.train()
         # (d) the data-parallel machinery with ONE rank on RCCL (gradient hooks, buckets, side-stream all-reduces, the
         # 1 / world scale, paradigm all-reduce, loss reduce): a regression there shows without a multi-GPU box
+        note("inference %.1f ms per batch; one-rank RCCL leg" % infer["ms_per_batch"])
         if not dist.is_initialized():
             try:
                 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
@@ -501,6 +509,7 @@ def main():
                        "gradient_allreduces_per_step": len(tr_dp.collective_log),
                        "note": "same step through engine.Trainer(distributed=True) on a one-rank RCCL group"}
                 ops.WGRAD_STREAM = trainer.wgrad_stream
+                note("one-rank RCCL leg %.1f ms" % dp1["ms_per_step"])
                 del tr_dp
             except Exception as e:  # a broken collective path must not take the headline down with it
                 dp1 = {"error": repr(e)}

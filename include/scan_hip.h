@@ -418,12 +418,12 @@ int scan_sgd_momentum_multi(const scan_sgd_segment_t* segs, int32_t n_segs, floa
 /* ---- bf16 hi / lo planes of many conv weights in one launch (same element mapping as scan_weight_split) ----
  * jobs: DEVICE array of n_jobs records of SCAN_SPLIT_JOB_WORDS int64: {w, wh, wl (device addresses), O, T, Cs, mode,
  * rows (= mode ? Cs : O), Csw, first_block, third plane or 0}; with a third plane the job is the three-piece split of
- * scan_weight_split3 and {wh, wl, third} = its {wh, wm, wl}; first_block = running sum of scan_weight_split_job_blocks() over the jobs
+ * scan_weight_split3 and {wh, wl, third} = its {wh, wm, wl}; job_words = SCAN_SPLIT_JOB_WORDS as the caller compiled it (a table of another layout is refused); first_block = running sum of scan_weight_split_job_blocks() over the jobs
  * before it, total_blocks the sum over all.  No reference counterpart (the reference convolves in fp32 through
  * cuDNN); it exists because a DA iteration re-splits ~120 weights after every optimizer step. */
 #define SCAN_SPLIT_JOB_WORDS 11
 int64_t scan_weight_split_job_blocks(int32_t O, int32_t T, int32_t Cs, int32_t mode, int32_t Csw);
-int scan_weight_split_batched(const int64_t* jobs, int32_t n_jobs, int64_t total_blocks, void* stream);
+int scan_weight_split_batched(const int64_t* jobs, int32_t n_jobs, int32_t job_words, int64_t total_blocks, void* stream);
 
 /* ---- CKA discriminator class branches as two stacked convolutions ----
  * replaces the per-class loop of FCOSDiscriminator_con.forward (modeling/discriminator/

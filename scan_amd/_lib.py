@@ -138,7 +138,7 @@ SIGNATURES = {
     "scan_sgd_momentum": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_f32, c_f32, c_f32, c_i32, c_vp]),
     "scan_sgd_momentum_multi": (ctypes.c_int, [ctypes.POINTER(SgdSegment), c_i32, c_f32, c_vp]),
     "scan_weight_split_job_blocks": (c_i64, [c_i32, c_i32, c_i32, c_i32, c_i32]),
-    "scan_weight_split_batched": (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp]),
+    "scan_weight_split_batched": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i64, c_vp]),
     "scan_cka_stack_weights": (ctypes.c_int, [ctypes.POINTER(CkaBranch), c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64,
                                               c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "scan_cka_unstack_grads": (ctypes.c_int, [ctypes.POINTER(CkaBranch), c_i32, c_i32, c_i32, c_i64, c_i64, c_i64, c_i64,

@@ -125,7 +125,12 @@ extern "C" int64_t scan_weight_split_job_blocks(int32_t O, int32_t T, int32_t Cs
   return tiles_o * tiles_c * T;
 }
 
-extern "C" int scan_weight_split_batched(const int64_t* jobs, int32_t n_jobs, int64_t total_blocks, void* stream) {
+extern "C" int scan_weight_split_batched(const int64_t* jobs, int32_t n_jobs, int32_t job_words, int64_t total_blocks,
+                                         void* stream) {
+  // the table lives in device memory and cannot be inspected here: the caller states its record length, so that a table
+  // built for another version of the layout is refused instead of being read past its records
+  SCAN_CHECK_ARG(job_words == SCAN_SPLIT_JOB_WORDS, "weight_split_batched: records of %d words, this library reads %d",
+                 job_words, SCAN_SPLIT_JOB_WORDS);
   SCAN_CHECK_ARG(jobs && n_jobs > 0 && total_blocks > 0 && total_blocks < (1ll << 31),
                  "weight_split_batched: bad arguments (n_jobs=%d)", n_jobs);
   hipLaunchKernelGGL(weight_split_batched_kernel, dim3((unsigned)total_blocks), dim3(256), 0, as_stream(stream), jobs,

@@ -265,7 +265,7 @@ class SplitPlan:
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
             self.blocks = off
             self.dirty = False
-        call("scan_weight_split_batched", _ptr(self.table), len(self.order), self.blocks, _stream())
+        call("scan_weight_split_batched", _ptr(self.table), len(self.order), int(self.table.shape[1]), self.blocks, _stream())
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         for k in self.order:

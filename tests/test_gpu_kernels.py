@@ -1073,7 +1073,7 @@ def test_weight_split_batched_equals_single_launches(device, pieces):
             expect.append(exp)
     table = torch.tensor(rows, dtype=torch.int64).to(device)
     assert table.shape[1] == _lib.SPLIT_JOB_WORDS
-    _lib.call("scan_weight_split_batched", ops._ptr(table), len(rows), off, ops._stream())
+    _lib.call("scan_weight_split_batched", ops._ptr(table), len(rows), table.shape[1], off, ops._stream())
     torch.cuda.synchronize()
     for (w, mode, planes), exp in zip(jobs, expect):
         for a, e in zip(planes, exp):
@@ -1088,7 +1088,9 @@ def test_weight_split_batched_equals_single_launches(device, pieces):
             assert float(((got - ref).abs() / ref.abs().clamp_min(1e-30)).max()) <= 2.0 ** -16
         assert float(total[:, :, ref.shape[2]:].abs().sum()) == 0  # row padding
     with pytest.raises(RuntimeError):
-        _lib.call("scan_weight_split_batched", ops._ptr(table), 0, off, ops._stream())
+        _lib.call("scan_weight_split_batched", ops._ptr(table), 0, table.shape[1], off, ops._stream())
+    with pytest.raises(RuntimeError, match="records of 10 words"):  # a table of the round-3 layout is refused, not misread
+        _lib.call("scan_weight_split_batched", ops._ptr(table), len(rows), 10, off, ops._stream())
 
 
 def test_split_plan_resplits_after_parameter_update(device):

@@ -206,14 +206,14 @@ def measure(dev, sizes=(M_CFG5, M_BIG), reps=10, K=9, only=None):
         for mode in modes:
             rows_, csw = (O, ops._round32(Cs)) if mode == 0 else (Cs, ops._round32(O))
             wh = torch.empty((rows_, 9, csw), dtype=torch.bfloat16, device=dev)
-            wl = torch.empty_like(wh)
-            jobs.append([w.data_ptr(), wh.data_ptr(), wl.data_ptr(), O, 9, Cs, mode, rows_, csw, off])
+            wm, wl = torch.empty_like(wh), torch.empty_like(wh)
+            jobs.append([w.data_ptr(), wh.data_ptr(), wm.data_ptr(), O, 9, Cs, mode, rows_, csw, off, wl.data_ptr()])
             off += query("scan_weight_split_job_blocks", O, 9, Cs, mode, csw)
-            keep.append((w, wh, wl))
+            keep.append((w, wh, wm, wl))
             elems += O * 9 * Cs
     table = torch.tensor(jobs, dtype=torch.int64).to(dev)
-    rec("weight_split_batched", elems, 8 * elems, "8 B per weight element and orientation: fp32 read, bf16 hi + lo written",
-        lambda: call("scan_weight_split_batched", P(table), len(jobs), off, st()), unit="element")
+    rec("weight_split_batched", elems, 10 * elems, "10 B per weight element and orientation: fp32 read, three bf16 pieces written",
+        lambda: call("scan_weight_split_batched", P(table), len(jobs), int(table.shape[1]), off, st()), unit="element")
     del keep, table
     # ---- class-aware NMS on one image's candidate set (a18): latency-bound, reported as time (bytes = the 20 B / box read)
     for n_box in (1000, 4000, 8192):

@@ -96,3 +96,30 @@ def test_single_process_comm_is_passthrough():
     assert list(out) == [7] and out[7][0].shape == (2, 4)
     with pytest.raises(ValueError):
         comm.images_per_gpu(16, 3)
+
+
+def test_bench_symbols_and_peaks():
+    """bench.py maps its timer records to the kernel symbols rocprofv3 lists and prices each against the ceiling of ITS
+    arithmetic: 2.5 PFLOP/s / 6 for a three-piece (bf16x6) kernel, / 3 for a two-piece one, 157.3 for the fp32-MFMA kernels."""
+    import bench
+    cases = {
+        "conv3x3_bf16x6_fwd_bn256": ("conv_split_kernel<3,256,16,512,3,1,true>", 2500.0 / 6),
+        "conv3x3_bf16x6_dgrad_bn128": ("conv_split_kernel<3,128,16,512,3,1,true>", 2500.0 / 6),
+        "conv3x3_bf16x6_fwd_bn1064": ("conv_split_kernel<3,64,16,512,3,1,true>", 2500.0 / 6),
+        "conv3x3_bf16x6_fwd_bn64": ("conv_split_kernel<3,64,8,256,3,1,true>", 2500.0 / 6),
+        "conv1x1_bf16x6_fwd_bn128": ("conv_split_kernel<3,128,16,512,1>", 2500.0 / 6),
+        "conv3x3_bf16x6_wgrad": ("conv_wgrad_v6_kernel<3,32,3>", 2500.0 / 6),
+        "conv1x1_bf16x6_wgrad": ("conv_wgrad_v4_kernel<3,1,S>", 2500.0 / 6),
+        "conv_smallcin_bf16x6": ("conv_smallcin_kernel<3>", 2500.0 / 6),
+        "conv3x3_bf16x3_fwd_bn2256": ("conv_split_kernel<2,256,16,512,3,1,true>", 2500.0 / 3),
+        "conv3x3_bf16x3_dgrad_bn1128": ("conv_split_kernel<2,128,16,1024,3>", 2500.0 / 3),
+        "conv3x3_bf16x3_wgrad": ("conv_wgrad_v6_kernel<2,64,3>", 2500.0 / 3),
+        "conv_igemm_fwd": ("conv_igemm_kernel<0,4>", 157.3),
+        "conv_wgrad": ("conv_wgrad_kernel", 157.3),
+    }
+    for rec, (sym, peak) in cases.items():
+        assert bench.symbol_of(rec) == sym, (rec, bench.symbol_of(rec))
+        assert abs(bench.peak_for(sym) - peak) < 1e-6, (sym, bench.peak_for(sym))
+    assert bench.HEADLINE_MODE == "bf16x6"
+    from scan_amd import ops
+    assert ops.CONV_MODE == bench.HEADLINE_MODE  # the shipped default is what the headline is measured in

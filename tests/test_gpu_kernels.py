@@ -669,6 +669,29 @@ def test_wgrad_full_size_elementwise(device, case, mode, monkeypatch):
     assert abs(lhs - via_w) <= 2e-6 * ascale and abs(lhs - via_x) <= 2e-6 * ascale, (lhs, via_w, via_x, ascale)
 
 
+@pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
+def test_conv_kernels_are_run_to_run_identical(device, mode, monkeypatch):
+    """forward, data gradient and weight gradient (split-K slabs reduced in a fixed order) are order-fixed: two runs on the same
+    inputs give the same bits, at the bench's tower-pyramid size (no atomics anywhere on the conv path except the GroupNorm
+    sums, which are not requested here)."""
+    from scan_amd import ops
+    monkeypatch.setattr(ops, "CONV_MODE", mode)
+    shape = ops.PyramidShape(4, [(128, 256), (64, 128), (32, 64), (16, 32), (8, 16)])
+    g = torch.Generator(device=device).manual_seed(17)
+    x = torch.randn((shape.rows, 256), device=device, generator=g)
+    gy = torch.randn((shape.rows, 256), device=device, generator=g)
+    w0 = (torch.randn((256, 256, 3, 3), device=device, generator=g) / 48).contiguous(memory_format=torch.channels_last)
+    b0 = torch.randn((256,), device=device, generator=g)
+    outs = []
+    for _ in range(2):
+        xx, w, b = x.clone().requires_grad_(True), w0.clone().requires_grad_(True), b0.clone().requires_grad_(True)
+        y = ops.conv2d(xx, w, b, shape, 3, 1, relu=True)
+        y.backward(gy)
+        outs.append((y.detach().clone(), xx.grad.clone(), w.grad.clone(), b.grad.clone()))
+    for a, c in zip(*outs):
+        assert torch.equal(a, c)
+
+
 def test_shipped_library_has_no_ablation_knobs(device):
     """timing-ablation kernel instances (wrong results by construction) are not part of the shipped library: their
     scan_tune keys do not exist, so no environment variable can switch them on."""

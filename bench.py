@@ -39,8 +39,9 @@ sys.path.insert(0, ROOT)
 # significand bits -- the reference's fp32 arithmetic) or THREE ("bf16x3": two pieces, 16 bits) bf16 MFMAs per fp32-equivalent
 # product, so their ceilings in algorithmic (fp32-equivalent) FLOPs are the 2.5 PFLOP/s dense bf16 peak / 6 and / 3.
 PEAK_FP32_MFMA_TFLOPS = 157.3
-PEAK_BF16X6_TFLOPS = 2500.0 / 6.0
-PEAK_BF16X3_TFLOPS = 2500.0 / 3.0
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_BF16X6_TFLOPS = PEAK_BF16_TFLOPS / 6.0
+PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 3.0
 HEADLINE_MODE = "bf16x6"
 XGMI_LINK_GBS = 153.0  # per link and direction; 7 links per GPU (MI355X_MICROARCH.md)
 
@@ -557,6 +558,21 @@ def main():
                                              "share_of_serial_step": round(v["total_ms"] / (dtr * 1e3), 3)}
                                          for k, v in ksum.items()}}
             roof.update(prov)
+            if world == 1 and not a.no_companions:
+                # what the bf16 matrix pipe of THIS board sustains under its package power cap (register-only MFMA loop on
+                # random operands, csrc/mfma_peak.hip): context for `frac`, which stays priced against the nominal peak
+                import ctypes
+                from scan_amd import _lib
+                tf = ctypes.c_double(0.0)
+                note("board-sustained bf16 MFMA rate (2 s register-only loop)")
+                _lib.call("scan_mfma_sustained_bf16", 2.0, 1, ctypes.byref(tf), ops._stream())
+                per = PEAK_BF16_TFLOPS / peak_for(name)  # bf16 MFMA FLOPs per algorithmic FLOP of this kernel (6, 3, ...)
+                roof["board_sustained"] = {
+                    "bf16_tflops": round(tf.value, 1), "frac_of_nominal_peak": round(tf.value / PEAK_BF16_TFLOPS, 4),
+                    "kernel_frac_of_it": round(r["tflops"] * per / tf.value, 4) if tf.value > 0 else None,
+                    "how": "v_mfma_f32_16x16x32_bf16 from registers only, two waves per SIMD on every CU, random-sign / "
+                           "random-mantissa operands, 2 s: the socket sits at its 1.4 kW cap at 2.0-2.2 GHz "
+                           "(profiles/r04_mfma_peak.txt); the conv kernels run at the same cap (r04_kernel_power_clock.txt)"}
         pointwise = None
         if not a.no_pointwise and world == 1:
             from tools import pointwise_roofline

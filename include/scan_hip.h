@@ -74,6 +74,12 @@ int scan_tune(const char* key, int value);
 /* read-only: the current value of a knob (nothing is written), -1 for an unknown key */
 int scan_tune_get(const char* key);
 
+/* Measurement (no reference counterpart): the bf16 matrix-pipe rate this board sustains under its package power cap -- a
+ * register-only v_mfma_f32_16x16x32_bf16 loop on every CU for about `seconds` (<= 30), two waves per SIMD; random != 0:
+ * random-sign / random-mantissa operands, 0: zeros.  Writes TFLOP/s; blocking (synchronises `stream`).  bench.py reports
+ * it as roofline.board_sustained beside the fraction of the nominal 2.5 PFLOP/s. */
+int scan_mfma_sustained_bf16(double seconds, int32_t random, double* tflops, void* stream);
+
 /* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels;
  * 1128 / 1256 = the 128- / 256-channel tile on 16-wave workgroups, 2256 = the 256-channel tile on the 8-wave LDS-DMA instance. */
 int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout);

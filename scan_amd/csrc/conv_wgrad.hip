@@ -707,7 +707,29 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
     load_b();
     __syncthreads();  // stage 0 is complete
     for (int k = 0; k < nch; ++k) {
-#ifndef SCAN_EXP_WGRAD_NOPROD  // TIMING EXPERIMENT (make exp_wgrad_noprod): the producers only attend the barriers
+#if defined(SCAN_EXP_WGRAD_PROD)
+      // TIMING EXPERIMENT (make exp_wgrad_prod_<mask>, WRONG results): which part of the producers' work costs the consumers
+      // their issue slots -- bit 0: the loads, bit 1: the LDS writes (of unconverted bits unless the split is compiled in),
+      // bit 3: the chunk walk and descriptors
+      const int stage = (k + 1) & 1;
+      const bool more = k + 2 < nch;
+      auto keep_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
+      };
+      auto keep_b = [&]() {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) asm volatile("" ::"v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+      };
+      if (SCAN_EXP_WGRAD_PROD & 8) {
+        if (more) advance();
+        prepare(more);
+      }
+      if (SCAN_EXP_WGRAD_PROD & 2) store_a(stage); else keep_a();
+      if (SCAN_EXP_WGRAD_PROD & 1) load_a();
+      if (SCAN_EXP_WGRAD_PROD & 2) store_b(stage); else keep_b();
+      if (SCAN_EXP_WGRAD_PROD & 1) load_b();
+#elif !defined(SCAN_EXP_WGRAD_NOPROD)  // TIMING EXPERIMENT (make exp_wgrad_noprod): the producers only attend the barriers
       const int stage = (k + 1) & 1;  // chunk k + 1 is in the registers; chunk k + 2 follows it
       const bool more = k + 2 < nch;
       if (more) advance();

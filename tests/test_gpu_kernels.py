@@ -701,6 +701,22 @@ def test_shipped_library_has_no_ablation_knobs(device):
         assert _lib.query("scan_tune", key, 1) == -1, key
 
 
+def test_mfma_sustained_measurement(device):
+    """scan_mfma_sustained_bf16 (bench.py's roofline.board_sustained): a plausible rate on random operands, a higher one on
+    zeros (no power cap in the way), argument errors reported through the C ABI."""
+    import ctypes
+    from scan_amd import _lib, ops
+    tf = ctypes.c_double(0.0)
+    _lib.call("scan_mfma_sustained_bf16", 0.3, 1, ctypes.byref(tf), ops._stream())
+    rnd = tf.value
+    _lib.call("scan_mfma_sustained_bf16", 0.3, 0, ctypes.byref(tf), ops._stream())
+    zeros = tf.value
+    assert 1000.0 < rnd <= 2500.0 and 1000.0 < zeros <= 2500.0, (rnd, zeros)  # nominal dense peak: 2500 TFLOP/s
+    assert zeros > 0.98 * rnd, (rnd, zeros)
+    with pytest.raises(RuntimeError):
+        _lib.call("scan_mfma_sustained_bf16", 0.0, 1, ctypes.byref(tf), ops._stream())
+
+
 def test_conv2d_errors(device):
     from scan_amd import ops
     shape = ops.PyramidShape(1, [(4, 4)])

@@ -565,7 +565,10 @@ def main():
                 from scan_amd import _lib
                 tf = ctypes.c_double(0.0)
                 note("board-sustained bf16 MFMA rate (2 s register-only loop)")
-                _lib.call("scan_mfma_sustained_bf16", 2.0, 1, ctypes.byref(tf), ops._stream())
+                try:
+                    _lib.call("scan_mfma_sustained_bf16", 2.0, 1, ctypes.byref(tf), ops._stream())
+                except RuntimeError as e:  # context only: never costs the run its line
+                    note("board-sustained measurement failed: %s" % e)
                 per = PEAK_BF16_TFLOPS / peak_for(name)  # bf16 MFMA FLOPs per algorithmic FLOP of this kernel (6, 3, ...)
                 roof["board_sustained"] = {
                     "bf16_tflops": round(tf.value, 1), "frac_of_nominal_peak": round(tf.value / PEAK_BF16_TFLOPS, 4),

@@ -3,7 +3,7 @@
 // dense peak (2.5 PFLOP/s) is 2.4 GHz x 256 CUs x 4 SIMDs x 1024 FLOP/cycle; under the 1.4 kW package cap an MFMA-dense
 // loop on random operands holds a lower clock -- this is the measured ceiling the conv kernels' fractions can be read against.
 //   hipcc --offload-arch=gfx950 -O3 -o gpurun_out/mfma_peak tools/mfma_peak.hip
-//   gpurun_out/mfma_peak <seconds> <waves per SIMD: 1|2|4> <data: 0 zeros | 1 random> <shape: 0 16x16x32 | 1 32x32x16>
+//   gpurun_out/mfma_peak <seconds> <waves per SIMD: 1|2|4> <data: 0 zeros | 1 random | 2 random with one operand half zeros | 3 random, no operand shared by consecutive MFMAs> <shape: 0 16x16x32 | 1 32x32x16>
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, long iters, int ran
       // random sign and mantissa, magnitudes around 2^-3 (the sums stay finite over any run length that matters)
       const unsigned ha = hash32(id * 64u + i * 8u + e), hb = hash32(id * 64u + 32u + i * 8u + e);
       const unsigned short ua = random ? (unsigned short)((ha & 0x807fu) | (0x7cu << 7)) : 0;
-      const unsigned short ub = random ? (unsigned short)((hb & 0x807fu) | (0x7cu << 7)) : 0;
+      unsigned short ub = random ? (unsigned short)((hb & 0x807fu) | (0x7cu << 7)) : 0;
+      if (random == 2 && (hb & 0x10000u)) ub = 0;  // half of one operand's elements are zero (what a ReLU leaves)
       a[i][e] = __builtin_bit_cast(__bf16, ua);
       b[i][e] = __builtin_bit_cast(__bf16, ub);
     }
@@ -35,12 +36,22 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, long iters, int ran
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
-  for (long k = 0; k < iters; ++k) {
+  if (random == 3) {  // diagonal order: consecutive MFMAs share neither operand
+    for (long k = 0; k < iters; ++k) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int d = 0; d < 4; ++d)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)  // (inline asm: the intrinsic form was compiled with accumulator copies between the MFMAs)
-        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+        for (int i = 0; i < 4; ++i)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][(i + d) & 3]) : "v"(a[i]), "v"(b[(i + d) & 3]));
+    }
+  } else {
+    for (long k = 0; k < iters; ++k) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)  // (inline asm: the intrinsic form was compiled with accumulator copies between the MFMAs)
+          asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[i]), "v"(b[j]));
+    }
   }
   f32x4v s = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -120,7 +131,7 @@ int main(int argc, char** argv) {
     if (pass == 0) iters = (long)(iters * seconds * 1e3 / ms);
     else
       printf("{\"mfma\": \"%s\", \"cus\": %d, \"waves_per_simd\": %d, \"data\": \"%s\", \"seconds\": %.2f, \"bf16_tflops\": %.1f, "
-             "\"frac_of_2500\": %.3f, \"implied_mhz_at_full_issue\": %.0f}\n", shape32 ? "32x32x16" : "16x16x32", cus, wps, random ? "random" : "zeros", ms * 1e-3, tf,
+             "\"frac_of_2500\": %.3f, \"implied_mhz_at_full_issue\": %.0f}\n", shape32 ? "32x32x16" : "16x16x32", cus, wps, random == 0 ? "zeros" : random == 1 ? "random" : random == 2 ? "random, one operand half zeros" : "random, diagonal order", ms * 1e-3, tf,
              tf / 2500.0, tf * 1e12 / (cus * 4 * 1024.0) * 1e-6);
   }
   return 0;

@@ -266,6 +266,9 @@ def main():
                          "threshold as clustering candidates (SURVEY.md 8d second series: 0.01).  A random-init model passes "
                          "ALL entries -- the worst case -- a trained one a small fraction; measurement switch only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-mode", choices=("bf16x6", "bf16x3", "fp32"), default=HEADLINE_MODE,
+                    help="arithmetic of the timed region (default: the headline, bf16x6).  Another value is for profiling the "
+                         "companion arithmetics under rocprofv3 (use with --no-companions); the line then says so in dtype")
     ap.add_argument("--no-companions", action="store_true",
                     help="skip the companion legs of the line (strict fp32-MFMA steps, the three-phase schedule, inference)")
     ap.add_argument("--strict-steps", type=int, default=5, help="timed steps of the strict fp32-MFMA companion leg")
@@ -312,6 +315,9 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from scan_amd import comm, engine, ops, synth
+    ops.CONV_MODE = a.conv_mode
+    if a.conv_mode != HEADLINE_MODE and not a.no_companions:
+        raise SystemExit("--conv-mode %s is a profiling aid: combine it with --no-companions" % a.conv_mode)
     if a.ft_positives is not None:
         if not a.forward_target:
             raise SystemExit("--ft-positives needs --forward-target")
@@ -632,6 +638,11 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        if a.conv_mode != HEADLINE_MODE:  # a profiling run of a companion arithmetic: never to be read as the headline
+            what = {"bf16x3": "bf16x3: two bf16 pieces per operand = 16 significand bits, narrower than the reference",
+                    "fp32": "exact fp32-MFMA kernels (v_mfma_f32_32x32x2_f32)"}[a.conv_mode]
+            line["dtype"] = "COMPANION ARITHMETIC, NOT THE HEADLINE (--conv-mode %s): %s" % (a.conv_mode, what)
+            line["config"]["arithmetic"] = what
         print(json.dumps(line), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -3,6 +3,17 @@
 #   conv_bench tables (forward / data gradient / weight gradient, three and two pieces), SQ counters of the conv kernels,
 #   per-launch-shape times of a step, the weight gradient's distance from fp64 over the split-K count, and the timing
 #   experiments of the weight gradient (separate exp_* libraries: wrong results or other trade-offs, never the product).
+# rocprofv3 summaries of the companion arithmetics (the same step on the exact fp32-MFMA kernels / the two-piece split):
+#   bash tools/collect_extra.sh companions <tag>
+if [ "$1" = "companions" ]; then
+  TAG=${2:-prof}; export TMPDIR=/tmp; R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out; cd /tmp
+  for M in fp32 bf16x3; do
+    rocprofv3 --kernel-trace --stats -d /tmp/p_$M --output-format csv -- python3 $R/bench.py --conv-mode $M --serial-streams --steps 5 --warmup 2 --no-cpu-baseline --no-pointwise --no-companions > $O/${TAG}_prof_$M.log 2>&1
+    cp $(find /tmp/p_$M -name "*kernel_stats.csv" | head -1) $O/${TAG}_bench_${M}_kernel_stats.csv; rm -rf /tmp/p_$M
+    tail -1 $O/${TAG}_prof_$M.log | cut -c1-300
+  done
+  exit 0
+fi
 TAG=${1:-r04}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}

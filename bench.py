@@ -95,8 +95,8 @@ def symbol_of(name):
         np_, bn, ks = (3 if m.group(2) == "6" else 2), int(m.group(4)), (3 if m.group(1) == "3x3" else 1)
         th, nt, tail = (8, 256, "") if bn == 64 else (16, 512, "")
         if np_ == 3:  # three pieces: weight tiles by LDS-DMA on every 3x3 instance (scan_conv3x3_bf16x6_instance)
-            if bn == 1064:
-                return "conv_split_kernel<3,64,16,512,3,1,true>"
+            if bn in (1064, 2064):
+                return "conv_split_kernel<3,64,%d,512,3,1,true>" % (16 if bn == 1064 else 32)
             return "conv_split_kernel<3,%d,%d,%d,%d%s>" % (bn, th, nt, ks, ",1,true" if ks == 3 else "")
         if bn > 2000:  # the 8-wave LDS-DMA instance of the 256-channel tile
             return "conv_split_kernel<2,%d,%d,512,3,1,true>" % (bn - 2000, th)

@@ -54,8 +54,9 @@ int scan_abi_version(void);
  *                 wave); 0: 16 waves.  Same results bit for bit.
  *   "conv_tpb3"   (bf16x3) bit 0 (default on) / bit 1: the 128- / 64-channel instance stages three taps per barrier (same
  *                 results bit for bit).
- *   "conv_bn64_th16" 1 (default): convs with <= 64 output channels on single-level pyramids whose sizes are multiples of
- *                 16 use 16x16-pixel tiles; 0: 8x16.  Same results bit for bit.
+ *   "conv_bn64_th16" pixel tile of convs with <= 64 output channels on single-level pyramids: 0: 8x16; 1: 16x16 when the
+ *                 sizes are multiples of 16; 2 (default): bf16x6 additionally takes 32x16 when H is a multiple of 32.  Same
+ *                 results bit for bit.
  *   "conv_glds"   1 (default): the 128- / 256-channel 3x3 instances stage weight tiles by LDS-DMA (buffer_load ... lds) on
  *                 whole tiles; 0: through registers.  Same results bit for bit.
  *   "wgrad_v6"    1 (default): the 3x3 weight-gradient launches take the producer / consumer kernel (12 waves: 8 issue
@@ -292,7 +293,8 @@ int scan_conv1x1_wgrad_bf16x6(const float* x, const scan_pyramid_t* xd, int32_t 
                               const scan_pyramid_t* yd, int32_t Cout, int32_t Cout_s, int32_t stride, float* dw,
                               float* db, int32_t accumulate, float* ws, void* stream);
 /* output-channel tile (64 / 128 / 256) a scan_conv3x3_bf16x6 launch on pyramid d with Nout channels takes; 1064 = the
- * 64-channel tile on 16x16-pixel tiles (single-level pyramids with sizes that are multiples of 16) */
+ * 64-channel tile on 16x16-pixel tiles (single-level pyramids with sizes that are multiples of 16), 2064 = on 32x16-pixel
+ * tiles (H a multiple of 32 too) */
 int scan_conv3x3_bf16x6_instance(const scan_pyramid_t* d, int32_t Nout);
 /* w [Cout][T][Cin_s] -> wt [Cin_s][T][Cout_s] (zero padded) */
 int scan_weight_transpose(const float* w, int32_t Cout, int32_t T, int32_t Cin_s, float* wt, int32_t Cout_s,

@@ -616,10 +616,12 @@ int g_scan_conv_tpb3 = 1;
 // tools/conv_bench.py, us): towers over P3..P7 608 -> 556, conv3_x 1530 -> 1431, conv4_x 1431 -> 1349; neutral on the
 // 128-channel instance; the 64-channel instance gets slower (1906 -> 2040) and stays on registers.
 int g_scan_conv_glds = 1;
-// scan_tune "conv_bn64_th16": the <= 64-channel 3x3 instance on 16x16-pixel tiles (4 waves x 64 px x 64 ch: 48 MFMAs per
-// wave and barrier instead of 24) instead of 8x16 -- 1 (default): single-level pyramids with H, W multiples of 16, 0:
-// never.  conv1_2 (64 -> 64 at 1024x2048, 4 frames) 2047 -> 1940 us, conv2_1 990 -> 981 us (tools/conv_bench.py).
-int g_scan_conv_bn64_th16 = 1;
+// scan_tune "conv_bn64_th16": pixel tile of the <= 64-channel 3x3 instance on single-level pyramids -- 0: always 8x16 (4 waves);
+// 1: 16x16 when H, W are multiples of 16 (8 waves x 32 px x 64 ch: conv1_2, 64 -> 64 at 1024x2048, 4 frames, two pieces 2047 ->
+// 1940 us); 2 (default): three pieces additionally take 32x16 tiles when H is a multiple of 32 (8 waves x 64 px x 64 ch: 96
+// MFMAs per wave and barrier instead of 48, half the weight-tile traffic per MFMA, halo 1.20 instead of 1.27; 142 KB of LDS,
+// one workgroup per CU as before: conv1_2 3257 -> 2918 us, tools/conv_bench.py).  Same results bit for bit.
+int g_scan_conv_bn64_th16 = 2;
 static int v2_instance(const scan_pyramid_t* od, int32_t Nout) {
   if (Nout <= 64) return 64;
   TileTab2 tt;
@@ -643,7 +645,9 @@ int conv3x3_split_launch(int np, const float* x, const scan_pyramid_t* d, int32_
     // tools/conv_bench.py --variants conv_glds=0)
     switch (v2_instance(d, Nout)) {
       case 64:
-        if (whole && th16)
+        if (whole && th16 && g_scan_conv_bn64_th16 == 2 && d->h[0] % 32 == 0)
+          launch_v2<3, 64, 32, 512, 3, 1, true>(a);
+        else if (whole && th16)
           launch_v2<3, 64, 16, 512, 3, 1, true>(a);
         else if (whole)
           launch_v2<3, 64, 8, 256, 3, 1, true>(a);
@@ -740,10 +744,12 @@ extern "C" int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nou
 }
 
 // three pieces: the output-channel tile (64 / 128 / 256; 8 waves, LDS-DMA weight tiles), 1064 = the 64-channel tile on
-// 16x16-pixel tiles with 8 waves (single-level pyramids with sizes that are multiples of 16), 64 = on 8x16-pixel tiles, 4 waves
+// 16x16-pixel tiles with 8 waves (single-level pyramids with sizes that are multiples of 16), 2064 = on 32x16-pixel tiles
+// (H a multiple of 32), 64 = on 8x16-pixel tiles, 4 waves
 extern "C" int scan_conv3x3_bf16x6_instance(const scan_pyramid_t* d, int32_t Nout) {
   if (!d) return -1;
   const int bn = v2_instance(d, Nout);
-  if (bn == 64 && g_scan_conv_bn64_th16 && d->n_levels == 1 && d->h[0] % 16 == 0 && d->w[0] % 16 == 0) return 1064;
+  if (bn == 64 && g_scan_conv_bn64_th16 && d->n_levels == 1 && d->h[0] % 16 == 0 && d->w[0] % 16 == 0)
+    return (g_scan_conv_bn64_th16 == 2 && d->h[0] % 32 == 0) ? 2064 : 1064;  // (Csw % 32 == 0 assumed, as for the others)
   return bn;
 }

@@ -359,6 +359,46 @@ def test_conv2d_fwd_bwd(device, case, mode, conv_generation, monkeypatch):
     np.testing.assert_allclose(bd.grad.cpu().numpy(), br.grad.numpy(), rtol=1e-4, atol=2e-5 * max(1.0, float(br.grad.abs().max())))
 
 
+def test_conv_64_channel_tiles_agree(device, monkeypatch):
+    """the <= 64-channel 3x3 instance on 32x16- (default for H % 32 == 0), 16x16- and 8x16-pixel tiles (scan_tune
+    conv_bn64_th16 = 2 / 1 / 0): the same K order per output element, so the results are bit-identical -- plain, with the fused
+    ReLU + 2x2 max-pool epilogue of the frozen stages, and as a data gradient; on a size where the 32-row tile does not apply
+    (H = 48) the default is the 16x16 tile."""
+    from scan_amd import _lib, ops
+    monkeypatch.setattr(ops, "CONV_MODE", "bf16x6")
+    torch.manual_seed(11)
+    for (h, w_), want in (((64, 96), 2064), ((48, 64), 1064)):
+        shape = ops.PyramidShape(2, [(h, w_)])
+        assert _lib.query("scan_conv3x3_bf16x6_instance", shape.ref(), 64) == want
+        x = torch.randn(shape.rows, 64, device=device).relu_()
+        w = (torch.randn(64, 64, 3, 3, device=device) / 24).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(64, device=device)
+        gy = torch.randn(shape.rows, 64, device=device)
+
+        def run():
+            with torch.no_grad():
+                pooled = ops.conv2d(x, w, b, shape, 3, 1, relu=True, pool=True)
+            xx = x.clone().requires_grad_(True)
+            y = ops.conv2d(xx, w, b, shape, 3, 1, relu="deferred")
+            y.backward(gy)
+            return pooled, y.detach(), xx.grad.clone()
+
+        outs = {}
+        for knob in (2, 1, 0):
+            old = _lib.query("scan_tune", b"conv_bn64_th16", knob)
+            try:
+                outs[knob] = run()
+            finally:
+                _lib.query("scan_tune", b"conv_bn64_th16", old)
+        for knob in (1, 0):
+            for a, c in zip(outs[2], outs[knob]):
+                assert torch.equal(a, c), (h, w_, knob)
+        ref = torch.nn.functional.conv2d(x.view(2, h, w_, 64).permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(),
+                                         padding=1)
+        got = outs[2][1].view(2, h, w_, 64).permute(0, 3, 1, 2).double().cpu()
+        assert (got - ref.relu()).abs().max().item() <= 5e-6 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("mode", ["bf16x6", "bf16x3"])
 def test_conv_instances_agree_full_size(device, mode, monkeypatch):
     """the ways a 256 -> 256 tower layer can run on 4 frames of 128x256 (P3 of the bench workload): 16x16x32

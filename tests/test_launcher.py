@@ -106,6 +106,7 @@ def test_bench_symbols_and_peaks():
         "conv3x3_bf16x6_fwd_bn256": ("conv_split_kernel<3,256,16,512,3,1,true>", 2500.0 / 6),
         "conv3x3_bf16x6_dgrad_bn128": ("conv_split_kernel<3,128,16,512,3,1,true>", 2500.0 / 6),
         "conv3x3_bf16x6_fwd_bn1064": ("conv_split_kernel<3,64,16,512,3,1,true>", 2500.0 / 6),
+        "conv3x3_bf16x6_fwd_bn2064": ("conv_split_kernel<3,64,32,512,3,1,true>", 2500.0 / 6),
         "conv3x3_bf16x6_fwd_bn64": ("conv_split_kernel<3,64,8,256,3,1,true>", 2500.0 / 6),
         "conv1x1_bf16x6_fwd_bn128": ("conv_split_kernel<3,128,16,512,1>", 2500.0 / 6),
         "conv3x3_bf16x6_wgrad": ("conv_wgrad_v6_kernel<3,32,3>", 2500.0 / 6),

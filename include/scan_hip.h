@@ -62,7 +62,8 @@ int scan_abi_version(void);
  *   "wgrad_v6"    1 (default): the 3x3 weight-gradient launches take the producer / consumer kernel (12 waves: 8 issue
  *                 MFMAs, 4 stage); 0: the kernel in which all 8 waves stage and multiply in turn (always used by the 1x1
  *                 convs).  bf16x3: bit-identical; bf16x6: other K-chunk length, i.e. other split-K boundaries.
- *   "wgrad_prio"  1 (default): the producer waves of that kernel run at s_setprio 3.
+ *   "wgrad_prio"  1: the producer waves of that kernel run at s_setprio 3; 0 (default): at the consumers' priority.  Same
+ *                 results bit for bit.
  *   "wgrad_tile"  consumer wave tile of that kernel: 0 = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c), -1 (default) = 1 for bf16x6, 0 for
  *                 bf16x3.  Same results bit for bit.
  *   "wgrad_wgs"   768 (default): workgroups a weight-gradient launch aims at (tiles x split-K slabs); 512 / 640 / 896 / 1024

@@ -847,8 +847,11 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
 int g_scan_wgrad_tile = -1;
 // scan_tune "wgrad_v6": 1 (default) = the 3x3 launches take the producer / consumer kernel, 0 = conv_wgrad_v4_kernel
 int g_scan_wgrad_v6 = 1;
-// scan_tune "wgrad_prio": 1 = the producer waves run at s_setprio 3
-int g_scan_wgrad_prio = 1;
+// scan_tune "wgrad_prio": 1 = the producer waves run at s_setprio 3, 0 (default) = at the consumers' priority.  Round 3 ran them
+// raised (the staging wave otherwise reached the barrier last); with the packed conversion and the loads issued early the
+// raised priority only takes issue slots from the MFMA waves -- three pieces: conv3_x 2630 -> 2532 us, conv4_x 2532 -> 2468,
+// towers 464 -> 453, class branches 3266 -> 3204; two pieces: 0-2 % (conv3_x 1338 -> 1309).  Same results bit for bit.
+int g_scan_wgrad_prio = 0;
 // scan_tune "wgrad_wgs": workgroups a weight-gradient launch aims at (tiles x splits), see the sweep quoted in wgrad_plan
 int g_scan_wgrad_wgs = 768;
 
@@ -908,7 +911,10 @@ static void wgrad_plan(const scan_pyramid_t* d, int Cs, int Cout, int KX, int wk
   // ~3 workgroups per CU in total.  Swept on the device (tower layer, two pieces, us): 256 -> 499, 512 -> 428, 768 -> 355,
   // 1024 -> 414, 1536 -> 411, 2304 -> 486: fewer splits lengthen each workgroup's serial chunk chain, more splits
   // cost slab traffic and leave partial rounds
-  long long s = g_scan_wgrad_wgs / *n_tiles;
+  // a thin last channel tile (264 / 268 input channels: 8 / 12 live of 128) leaves a third of the workgroups with one column
+  // tile of MFMAs: more, shorter workgroups balance that (class branches 264 -> 1024 3390 -> 3304 us, head_out 1181 -> 1104 at 1280)
+  const int target = (Cs > 128 && Cs % 128 != 0 && Cs % 128 <= 16) ? g_scan_wgrad_wgs * 5 / 3 : g_scan_wgrad_wgs;
+  long long s = target / *n_tiles;
   if (s < 1) s = 1;
   const long long smax = (chunks + 7) / 8;
   if (s > smax) s = smax;

@@ -373,7 +373,11 @@ class Trainer:
         self.wgrad_stream = torch.cuda.Stream() if on_gpu and os.environ.get("SCAN_WGRAD_STREAM", "0") != "0" else None
         ops.WGRAD_STREAM = self.wgrad_stream
         self.overlap_target = True
-        self.fcos_beside_dis = os.environ.get("SCAN_FCOS_STREAM", "1") != "0"  # paired step: FCOS head beside the discriminators
+        # paired step: the FCOS head on a side stream beside the discriminators.  SCAN_FCOS_STREAM=1 / 0 forces it; unset, it
+        # follows the conv arithmetic at step time: on for the two-piece kernels (their shorter launches leave tails to fill:
+        # 61 -> 60 ms/step in round 3), off for bf16x6 and fp32, whose kernels run at the package power cap -- co-running MFMA
+        # kernels share one power budget and cost each other cache and LDS (same box, A B A B: 95.05 / 95.32 -> 93.98 / 94.45 ms)
+        self._fcos_stream_env = os.environ.get("SCAN_FCOS_STREAM")
         self.merge_source_backward = True
         # source and target frames as ONE batch through backbone / middle head / discriminators and one backward
         # (step_paired): same losses and gradients as the three phases, larger launches.  Used when both batches
@@ -381,6 +385,12 @@ class Trainer:
         self.paired = True
         self.throttle = os.environ.get("SCAN_THROTTLE", "none")
         self._throttle_ev = None
+
+    @property
+    def fcos_beside_dis(self):
+        if self._fcos_stream_env is not None:
+            return self._fcos_stream_env != "0"
+        return ops.split_pieces() == 2
 
     def _allreduce_async(self, keys, after_side_streams=False):
         """all-reduce the flat gradient buffers of sub-models whose gradients are final, on the side stream."""
@@ -657,7 +667,7 @@ class Trainer:
         main = torch.cuda.current_stream()
         # the FCOS head (source rows) is independent of the discriminators: it takes the side stream the three-phase
         # schedule uses for the target forward and fills the tails of the P3 discriminator's kernels (~1.2 ms)
-        fstream = self.tgt_stream if self.overlap_target and self.fcos_beside_dis else None
+        fstream = self.tgt_stream if self.overlap_target and self.fcos_beside_dis else None  # (property, see __init__)
         if fstream is not None:
             fstream.wait_stream(main)
         with torch.cuda.stream(fstream if fstream is not None else main):

@@ -43,8 +43,9 @@ int scan_abi_version(void);
 /* Tuning knob for A/B measurements and tests (no reference counterpart): scan_tune(key, value) sets an integer
  * launch-selection parameter and returns its previous value, -1 for an unknown key.  Every setting of every key gives
  * correct results (timing-ablation instances are not part of this library).
- *   "conv_bn256"  1 (default): 3x3 convs whose output channels are a multiple of 256 use 256-channel tiles
- *                 when the launch keeps >= 2 workgroups per CU; 0: always 128-channel tiles (same results).
+ *   "conv_bn256"  3x3 convs whose output channels are a multiple of 256 -- 2 (default): 256-channel tiles whenever they do
+ *                 not cost a round of 256 CUs against 128-channel tiles (a 256-channel workgroup runs twice as long); 1: when
+ *                 the launch keeps >= 2 workgroups per CU (rounds 2-4); 0: always 128-channel tiles.  Same results bit for bit.
  *   "conv_v2"     1 (default): bf16x3 forward / data-gradient convs run on the v_mfma_f32_16x16x32_bf16 kernel
  *                 (csrc/conv_fwd.hip); 0: on the independent v_mfma_f32_32x32x16_bf16 kernel kept for cross-checks
  *                 (csrc/conv_bf16x3.hip; same arithmetic, different summation order inside a 32-channel chunk).

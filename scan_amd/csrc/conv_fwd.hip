@@ -593,7 +593,7 @@ static void launch_v2(const ConvArgs& a) {
 
 // Instance choice for an output pyramid and channel count: 64 (8x16- or 16x16-pixel tiles, 256 threads), 128 or 256
 // (16x16-pixel tiles; 256 when the channels fill 256-wide tiles and the launch keeps >= 2 workgroups per CU).
-int g_scan_conv_bn256 = 1;  // scan_tune "conv_bn256": 0 keeps every launch on the 128-channel instance
+int g_scan_conv_bn256 = 2;  // scan_tune "conv_bn256": 0 keeps every launch on the 128-channel instance, 1 = 256 when >= 512 workgroups result, 2 (default) = by rounds (below)
 // scan_tune "conv_wg1024" (two pieces only): 1 (default) = the 128- and 256-channel 3x3 instances run with 16 waves per
 // workgroup (each wave 32 px x 64 / 128 ch, <= 128 registers, four waves per SIMD) instead of 8 (64 px per wave, two per
 // SIMD); 0 = 8 waves; 2 = 16 waves only for the 256-channel tile on multi-level pyramids.  Same-process A/B per layer
@@ -627,7 +627,14 @@ static int v2_instance(const scan_pyramid_t* od, int32_t Nout) {
   TileTab2 tt;
   make_tiles_v2(od, &tt, 16);
   const int64_t tiles = tt.tile_off[od->n_levels];
-  if (g_scan_conv_bn256 && Nout % 256 == 0 && tiles * (Nout / 256) >= 512) return 256;
+  if (g_scan_conv_bn256 == 1 && Nout % 256 == 0 && tiles * (Nout / 256) >= 512) return 256;  // the rule of rounds 2-4
+  if (g_scan_conv_bn256 == 2 && Nout % 256 == 0) {
+    // rounds of 256 CUs (one workgroup per CU either way; a 256-channel workgroup runs twice as long as a 128-channel one and
+    // reads half the fragments per MFMA): the wider tile whenever it does not cost a round -- conv5_x on 4 frames (128 pixel
+    // tiles x 2: one full round of 256-channel workgroups instead of two of 128-channel ones), conv4_x on the 2 frames of inference
+    const int64_t r256 = (tiles * (Nout / 256) + 255) / 256 * 2, r128 = (tiles * (Nout / 128) + 255) / 256;
+    if (r256 <= r128) return 256;
+  }
   return 128;
 }
 

@@ -269,6 +269,9 @@ def main():
     ap.add_argument("--conv-mode", choices=("bf16x6", "bf16x3", "fp32"), default=HEADLINE_MODE,
                     help="arithmetic of the timed region (default: the headline, bf16x6).  Another value is for profiling the "
                          "companion arithmetics under rocprofv3 (use with --no-companions); the line then says so in dtype")
+    ap.add_argument("--three-phase", action="store_true",
+                    help="time the three-phase schedule (Trainer.paired = False: what ragged batches take) as the main region; "
+                         "a profiling / A-B aid, use with --no-companions")
     ap.add_argument("--no-companions", action="store_true",
                     help="skip the companion legs of the line (strict fp32-MFMA steps, the three-phase schedule, inference)")
     ap.add_argument("--strict-steps", type=int, default=5, help="timed steps of the strict fp32-MFMA companion leg")
@@ -330,6 +333,10 @@ def main():
     # under torch.distributed.run the data-parallel path (flat-buffer all-reduce on the side stream, paradigm
     # all-reduce) is exercised even with a single rank
     trainer = engine.Trainer(model, settings=mcfg, distributed=True if dist.is_initialized() else None)
+    if a.three_phase:
+        if not a.no_companions:
+            raise SystemExit("--three-phase is a profiling aid: combine it with --no-companions")
+        trainer.paired = False
 
     def set_serial(flag):
         trainer.overlap_target = not flag
@@ -638,6 +645,8 @@ def main():
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        if a.three_phase:
+            line["config"]["workload"] += " [THREE-PHASE SCHEDULE, not the headline]"
         if a.conv_mode != HEADLINE_MODE:  # a profiling run of a companion arithmetic: never to be read as the headline
             what = {"bf16x3": "bf16x3: two bf16 pieces per operand = 16 significand bits, narrower than the reference",
                     "fp32": "exact fp32-MFMA kernels (v_mfma_f32_32x32x2_f32)"}[a.conv_mode]

@@ -372,7 +372,8 @@ class Trainer:
         # weight gradients of flat-buffer parameters on a stream of their own (ops.WGRAD_STREAM)
         self.wgrad_stream = torch.cuda.Stream() if on_gpu and os.environ.get("SCAN_WGRAD_STREAM", "0") != "0" else None
         ops.WGRAD_STREAM = self.wgrad_stream
-        self.overlap_target = True
+        # three-phase schedule: the target forward on a side stream beside the source backward (SCAN_TGT_STREAM=0 switches it off)
+        self.overlap_target = os.environ.get("SCAN_TGT_STREAM", "1") != "0"
         # paired step: the FCOS head on a side stream beside the discriminators.  SCAN_FCOS_STREAM=1 / 0 forces it; unset, it
         # follows the conv arithmetic at step time: on for the two-piece kernels (their shorter launches leave tails to fill:
         # 61 -> 60 ms/step in round 3), off for bf16x6 and fp32, whose kernels run at the package power cap -- co-running MFMA

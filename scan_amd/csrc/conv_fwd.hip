@@ -633,7 +633,7 @@ static int v2_instance(const scan_pyramid_t* od, int32_t Nout) {
     // reads half the fragments per MFMA): the wider tile whenever it does not cost a round -- conv5_x on 4 frames (128 pixel
     // tiles x 2: one full round of 256-channel workgroups instead of two of 128-channel ones), conv4_x on the 2 frames of inference
     const int64_t r256 = (tiles * (Nout / 256) + 255) / 256 * 2, r128 = (tiles * (Nout / 128) + 255) / 256;
-    if (r256 <= r128) return 256;
+    if (r256 * 97 <= r128 * 100) return 256;  // (the wider tile is ~3 % faster per unit of work: a tie of many rounds goes to it)
   }
   return 128;
 }

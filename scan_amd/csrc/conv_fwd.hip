@@ -383,6 +383,9 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
     issue_b(0, 0, 0);
     for (int cc = 0; cc < nchunks; ++cc) {
       __syncthreads();  // every wave is done reading the previous chunk's patch
+#ifdef SCAN_EXP_FWD_NOFEED
+      if (cc == 0)
+#endif
       store_a();
       if (NGRP == 1 && cc + 1 < nchunks) load_a(cc + 1);
 #pragma unroll 1
@@ -393,6 +396,9 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // this tap's weight tile is complete; the patch is visible
         auto feed = [&]() {
+#ifdef SCAN_EXP_FWD_NOFEED  // TIMING EXPERIMENT (make exp_fwd_nofeed, WRONG results): no weight-tile DMA and no patch loads in the loop
+          return;
+#endif
           // the other buffer was last read one tap ago: the next tap's tile goes there while this one is multiplied
           if (grp < NGRP - 1)
             issue_b(cc, grp + 1, buf ^ 1);

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
     for (int cc = 0; cc < nchunks; ++cc) {
       __syncthreads();  // every wave is done reading the previous chunk's patch
 #ifdef SCAN_EXP_FWD_NOFEED
-      if (cc == 0)
+      if (cc == 0 || !(SCAN_EXP_FWD_NOFEED & 2))
 #endif
       store_a();
       if (NGRP == 1 && cc + 1 < nchunks) load_a(cc + 1);
@@ -396,8 +396,13 @@ __global__ __launch_bounds__(NT, NT == 1024 ? 4 : 2) void conv_split_kernel(
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();  // this tap's weight tile is complete; the patch is visible
         auto feed = [&]() {
-#ifdef SCAN_EXP_FWD_NOFEED  // TIMING EXPERIMENT (make exp_fwd_nofeed, WRONG results): no weight-tile DMA and no patch loads in the loop
-          return;
+#ifdef SCAN_EXP_FWD_NOFEED  // TIMING EXPERIMENT (make exp_fwd_nofeed [M=1|2|3], WRONG results): bit 0 = no weight-tile DMA, bit 1 = no
+          // patch loads / conversion / LDS writes after the first chunk
+          if ((SCAN_EXP_FWD_NOFEED & 1) && !(SCAN_EXP_FWD_NOFEED & 2)) {
+            if (NGRP > 1 && grp == NGRP - 2 && cc + 1 < nchunks) load_a(cc + 1);
+            return;
+          }
+          if ((SCAN_EXP_FWD_NOFEED & 3) == 3) return;
 #endif
           // the other buffer was last read one tap ago: the next tap's tile goes there while this one is multiplied
           if (grp < NGRP - 1)

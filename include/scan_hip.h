@@ -41,8 +41,8 @@ const char* scan_last_error(void);
 int scan_abi_version(void);
 
 /* Tuning knob for A/B measurements and tests (no reference counterpart): scan_tune(key, value) sets an integer
- * launch-selection parameter and returns its previous value, -1 for an unknown key.  Every setting of every key gives
- * correct results (timing-ablation instances are not part of this library).
+ * launch-selection parameter and returns its previous value, SCAN_TUNE_UNKNOWN for an unknown key.  Every setting of every
+ * key gives correct results (timing-ablation instances are not part of this library).
  *   "conv_bn256"  3x3 convs whose output channels are a multiple of 256 -- 2 (default): 256-channel tiles whenever they do
  *                 not cost a round of 256 CUs against 128-channel tiles (a 256-channel workgroup runs twice as long); 1: when
  *                 the launch keeps >= 2 workgroups per CU (rounds 2-4); 0: always 128-channel tiles.  Same results bit for bit.
@@ -65,17 +65,24 @@ int scan_abi_version(void);
  *                 convs).  bf16x3: bit-identical; bf16x6: other K-chunk length, i.e. other split-K boundaries.
  *   "wgrad_prio"  1: the producer waves of that kernel run at s_setprio 3; 0 (default): at the consumers' priority.  Same
  *                 results bit for bit.
- *   "wgrad_tile"  consumer wave tile of that kernel: 0 = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c), -1 (default) = 1 for bf16x6, 0 for
- *                 bf16x3.  Same results bit for bit.
+ *   "wgrad_tile"  consumer wave tile of that kernel: 0 = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c), 2 (default) = 1 for bf16x6, 0 for
+ *                 bf16x3.  bf16x3: same results bit for bit.  bf16x6: 0 adds the six piece products of a 32-pixel step
+ *                 straight into the running accumulator, 1 sums them in a temporary first (one rounding per step at the
+ *                 accumulator's magnitude) -- other rounding, 2-4x further from fp64 with 0.
  *   "wgrad_wgs"   768 (default): workgroups a weight-gradient launch aims at (tiles x split-K slabs); 512 / 640 / 896 / 1024
  *                 / 1280 / 1536 are 2...25 % slower on the 256- and 512-channel layers (bf16x3).
  *   "gconv_mfma"  0 (default): the grouped class-branch conv runs on fp32 FMAs; 1: tap products and data gradient on the
  *                 fp32 matrix cores (same products, different summation order; measured no faster in the step).
  *   "dbscan_bf16x3" 1 (default): scan_dbscan_prepare's pairwise-distance GEMM runs as bf16x3 with a wider exact re-check
  *                 band; 0: exact fp32 matrix cores.  Same neighbour bits (pairs inside the band are decided in fp64). */
+#define SCAN_TUNE_UNKNOWN (-2147483647 - 1)
 int scan_tune(const char* key, int value);
-/* read-only: the current value of a knob (nothing is written), -1 for an unknown key */
+/* read-only: the current value of a knob (nothing is written), SCAN_TUNE_UNKNOWN for an unknown key */
 int scan_tune_get(const char* key);
+/* the value the library was built with; scan_tune_key(i): name of the i-th knob, NULL past the end (bench.py stamps every
+ * knob that differs from its default into the line it prints) */
+int scan_tune_default(const char* key);
+const char* scan_tune_key(int index);
 
 /* Measurement (no reference counterpart): the bf16 matrix-pipe rate this board sustains under its package power cap -- a
  * register-only v_mfma_f32_16x16x32_bf16 loop on every CU for about `seconds` (<= 30), two waves per SIMD; random != 0:
@@ -170,8 +177,13 @@ int scan_softmax_focal_backward(const float* logits, const int64_t* labels, int6
  * rule_ge != 0: suppress when IoU >= thr (the CPU rule, nms_cpu.cpp:60 -- the oracle);
  * rule_ge == 0: suppress when IoU >  thr (the CUDA rule, nms.cu:60).
  * keep_out [n] int64 receives the kept ORIGINAL indices ascending, num_keep_out[0] their count
- * (both device memory).  workspace: scan_nms_ws_bytes(n) bytes.  n <= SCAN_NMS_MAX. */
-#define SCAN_NMS_MAX 8192
+ * (both device memory).  workspace: scan_nms_ws_bytes(n) bytes (n <= SCAN_NMS_PANEL: ~n*n/8 + 64 KB; the mask of a
+ * larger n is n * ceil(n/64) * 8 bytes, the size of the reference's own, cuda/nms.cu:95-100).
+ * n <= SCAN_NMS_PANEL runs as three single-workgroup-chain launches (the post-processor's case: <= 5,000 candidates per
+ * image); a larger n (nms_cuda has no limit, cuda/nms.cu:70-131) takes the panel path, up to SCAN_NMS_MAX -- a bound on
+ * the chain state one workgroup keeps in LDS (two bit words per 64 candidates), not on the algorithm. */
+#define SCAN_NMS_PANEL 8192
+#define SCAN_NMS_MAX 262144
 int64_t scan_nms_ws_bytes(int64_t n);
 int scan_nms(const float* dets, const float* scores, const float* labels, int64_t n, float thr, int32_t rule_ge,
              int64_t* keep_out, int32_t* num_keep_out, void* workspace, void* stream);

@@ -2,7 +2,7 @@
 (reference fcos_core/csrc/vision.cpp:8-17): same names, argument meaning and
 error behaviour, backed by libscan_hip.so through the C ABI.
 
-    nms(dets[n,4], scores[n], thr) -> int64[k]
+    nms(dets[n,4], scores[n], thr[, cuda_rule]) -> int64[k]     (CPU tensors: the host loop of nms_host below)
     ml_nms(dets[n,4], scores[n], labels[n] float, thr) -> int64[k]
     sigmoid_focalloss_forward(logits[M,C], targets[M] int32, num_classes, gamma, alpha) -> losses[M,C]
     sigmoid_focalloss_backward(logits, targets, d_losses, num_classes, gamma, alpha) -> d_logits[M,C]
@@ -23,13 +23,52 @@ def _require_gpu(t, who):
         raise RuntimeError("%s: not implemented on the CPU" % who)
 
 
-def nms(dets, scores, threshold):
-    """Greedy NMS; IoU >= threshold suppresses (the reference CPU rule, csrc/cpu/nms_cpu.cpp:60,
-    which is what the oracle pins).  Empty input returns an empty CPU tensor (csrc/nms.h:17-18)."""
+def nms_host(dets, scores, threshold, rule_ge=True):
+    """The reference's CPU dispatch (csrc/nms.h:26, csrc/cpu/nms_cpu.cpp:5-65) for host tensors: candidates by
+    descending score (ties: lower index first), a kept box suppresses every later box whose IoU -- areas with the +1
+    pixel rule, in the tensors' own dtype -- reaches the threshold; kept ORIGINAL indices ascending.  One vectorised
+    row of IoUs per kept box (same operations in the same order as the scalar loop, so the same keep list)."""
+    if scores.is_cuda:
+        raise RuntimeError("scores must be a CPU tensor")           # nms_cpu.cpp:10
+    if dets.dtype != scores.dtype:
+        raise RuntimeError("dets should have the same type as scores")  # nms_cpu.cpp:11
+    if dets.dtype not in (torch.float32, torch.float64):
+        raise RuntimeError("nms: float or double boxes")
+    n = dets.shape[0]
+    by_score = torch.sort(scores, descending=True, stable=True).indices
+    b = dets[by_score].contiguous()
+    area = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    dead = torch.zeros(n, dtype=torch.bool)
+    zero = torch.zeros((), dtype=dets.dtype)
+    thr = float(torch.tensor(threshold, dtype=torch.float32))  # the reference's `const float threshold`
+    for r in range(n):
+        if dead[r]:
+            continue
+        rest = b[r + 1:]
+        w = torch.maximum(zero, torch.minimum(b[r, 2], rest[:, 2]) - torch.maximum(b[r, 0], rest[:, 0]) + 1)
+        h = torch.maximum(zero, torch.minimum(b[r, 3], rest[:, 3]) - torch.maximum(b[r, 1], rest[:, 1]) + 1)
+        inter = w * h
+        iou = inter / (area[r] + area[r + 1:] - inter)
+        dead[r + 1:] |= (iou >= thr) if rule_ge else (iou > thr)
+    return torch.sort(by_score[~dead]).values
+
+
+def _cuda_rule_env():
+    import os
+    return os.environ.get("SCAN_NMS_RULE", "") in ("gt", "cuda")
+
+
+def nms(dets, scores, threshold, cuda_rule=False):
+    """Greedy NMS.  Default: IoU >= threshold suppresses (the reference CPU rule, csrc/cpu/nms_cpu.cpp:60, which its
+    tests/test_nms.py pins); ``cuda_rule=True`` or SCAN_NMS_RULE=gt: IoU > threshold (csrc/cuda/nms.cu:60).  GPU tensors
+    run on libscan_hip.so, CPU tensors on ``nms_host`` (csrc/nms.h:10-30 dispatches the same way).  Empty input returns
+    an empty CPU tensor (csrc/nms.h:17-18)."""
     if dets.numel() == 0:
         return torch.empty((0,), dtype=torch.int64, device="cpu")
-    _require_gpu(dets, "nms")
-    return ops.nms(dets, scores, threshold, rule_ge=True)
+    rule_ge = not (cuda_rule or _cuda_rule_env())
+    if not dets.is_cuda:
+        return nms_host(dets, scores, threshold, rule_ge)
+    return ops.nms(dets, scores, threshold, rule_ge=rule_ge)
 
 
 def ml_nms(dets, scores, labels, threshold):

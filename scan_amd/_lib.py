@@ -14,7 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SCAN_HIP_LIB") or os.path.join(_HERE, "libscan_hip.so")
 
 MAX_LEVELS = 5
-NMS_MAX = 8192
+TUNE_UNKNOWN = -2 ** 31  # SCAN_TUNE_UNKNOWN
+NMS_PANEL = 8192     # SCAN_NMS_PANEL: single-workgroup fast path
+NMS_MAX = 262144     # SCAN_NMS_MAX
 
 c_i32, c_i64, c_f32, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p
 
@@ -53,6 +55,8 @@ SIGNATURES = {
     "scan_cond_rnn_ws_floats": (ctypes.c_int64, []),
     "scan_cond_rnn_backward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "scan_tune_get": (ctypes.c_int, [ctypes.c_char_p]),
+    "scan_tune_default": (ctypes.c_int, [ctypes.c_char_p]),
+    "scan_tune_key": (ctypes.c_char_p, [ctypes.c_int]),
     "scan_mfma_sustained_bf16": (ctypes.c_int, [ctypes.c_double, c_i32, ctypes.POINTER(ctypes.c_double), c_vp]),
     "scan_conv3x3_bf16x3_instance": (ctypes.c_int, [_PD, c_i32]),
     "scan_conv3x3_bf16x6_instance": (ctypes.c_int, [_PD, c_i32]),
@@ -181,10 +185,32 @@ def lib():
         # SCAN_TUNE="key=value,key=value": launch-selection knobs for A/B measurements (scan_tune, include/scan_hip.h)
         for kv in filter(None, os.environ.get("SCAN_TUNE", "").split(",")):
             key, _, val = kv.partition("=")
-            if L.scan_tune(key.strip().encode(), int(val)) < 0:
+            if L.scan_tune(key.strip().encode(), int(val)) == TUNE_UNKNOWN:
                 raise RuntimeError("SCAN_TUNE: unknown key %r" % key)
         _lib = L
     return _lib
+
+
+def tune_state():
+    """{knob: (value, default)} of every scan_tune knob of the loaded library"""
+    L, out, i = lib(), {}, 0
+    while True:
+        k = L.scan_tune_key(i)
+        if k is None:
+            return out
+        out[k.decode()] = (L.scan_tune_get(k), L.scan_tune_default(k))
+        i += 1
+
+
+def lib_identity():
+    """what a measurement was taken with: the library file (basename, sha1 of its bytes, whether it is the product library
+    and not an alternative build selected by SCAN_HIP_LIB) and every scan_tune knob that is off its default"""
+    import hashlib
+    with open(LIB_PATH, "rb") as f:
+        sha = hashlib.sha1(f.read()).hexdigest()
+    product = os.path.realpath(LIB_PATH) == os.path.realpath(os.path.join(_HERE, "libscan_hip.so"))
+    return {"lib": os.path.basename(LIB_PATH), "lib_sha1": sha, "product_library": product,
+            "scan_tune_non_default": {k: v for k, (v, d) in tune_state().items() if v != d}}
 
 
 def call(name, *args):

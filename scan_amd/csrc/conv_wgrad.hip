@@ -844,7 +844,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
 // -1 (default) = by piece count: three pieces 32 x 64 (conv3_x 2542 -> 2489 us, class-branch 264 -> 1024 3409 -> 3293,
 // head_out 1177 -> 1123: tools/conv_bench.py --op wgrad --variants wgrad_tile=0,wgrad_tile=1), two pieces 64 x 32 (within
 // noise of the other).  Same results bit for bit.
-int g_scan_wgrad_tile = -1;
+int g_scan_wgrad_tile = 2;  // 2 = by piece count
 // scan_tune "wgrad_v6": 1 (default) = the 3x3 launches take the producer / consumer kernel, 0 = conv_wgrad_v4_kernel
 int g_scan_wgrad_v6 = 1;
 // scan_tune "wgrad_prio": 1 = the producer waves run at s_setprio 3, 0 (default) = at the consumers' priority.  Round 3 ran them
@@ -968,7 +968,7 @@ static int wgrad3_launch(const float* x, const scan_pyramid_t* d, int32_t Cs, co
       set_lds(conv_wgrad_v6_kernel<NP, WK6, 3, 2, 4>, sh6);
       done = true;
     }
-    if (g_scan_wgrad_tile < 0 ? NP == 3 : g_scan_wgrad_tile != 0)
+    if (g_scan_wgrad_tile >= 2 ? NP == 3 : g_scan_wgrad_tile != 0)
       hipLaunchKernelGGL((conv_wgrad_v6_kernel<NP, WK6, 3, 2, 4>), dim3(nt * sp), dim3(768), sh6, st, x, *d, Cs, dy, Cout, Cout_s,
                          ws, bias_slab, ct, nt, ctl, cps, sp, g_scan_wgrad_prio);
     else

@@ -514,6 +514,19 @@ class Trainer:
         """hooks on the marks the backbone's last forward left (modeling/backbone.py: VGG16FPN.grad_marks)."""
         bb = self.model["backbone"]
         for mark, t in getattr(bb, "grad_marks", {}).items():
+            if mark.startswith("node:"):
+                # a tensor whose producer is the last node of the backward: nothing below it gets a gradient, so a tensor
+                # hook (which fires BEFORE the producer's backward runs) would be too early -- hook the node itself; its
+                # post-hook runs once its backward, weight-gradient launch included, has been queued
+                if self.distributed and t is not None and t.grad_fn is not None:
+                    def _node_done(grad_inputs, grad_outputs, _n="backbone:" + mark[5:]):
+                        # weight / bias gradients written straight into the arena by the node (ops._Conv2d: flat-buffer
+                        # parameters) come back as None; one that is still on its way to an AccumulateGrad node is not
+                        # final yet -- then the bucket waits for _flush_buckets
+                        if all(g is None for g in grad_inputs[1:3]):
+                            self._bucket_ready(_n)
+                    t.grad_fn.register_hook(_node_done)
+                continue
             self._hook_ready(t, "middle_head" if mark == "out" else "backbone:" + mark)
         if hasattr(bb, "grad_marks"):
             bb.grad_marks = {}

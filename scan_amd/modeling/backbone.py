@@ -59,6 +59,7 @@ class VGGBody(nn.Module):
         # every conv output here has exactly one consumer (the next conv or the stage's max-pool), so the ReLU
         # backward is folded into that consumer's dgrad / pool-backward epilogue instead of a pass of its own
         outs = []
+        self.first_trainable_out = None
         for stage in VGG_STAGES:
             for j, idx in enumerate(stage):
                 m = self.features[idx]
@@ -69,6 +70,10 @@ class VGGBody(nn.Module):
                     shape = PyramidShape(shape.n_images, [(h // 2, w // 2)])
                     break
                 rows = ops.conv2d(rows, m.weight, m.bias, shape, 3, 1, relu="deferred", mask_dx=j > 0)
+                if self.first_trainable_out is None and rows.requires_grad:
+                    # output of the first conv with a gradient (conv3_1 at frozen_stages = 2): its autograd node is the
+                    # LAST backbone node of a backward pass (its input needs no gradient) -- VGG16FPN.grad_marks["node:rest"]
+                    self.first_trainable_out = rows
             else:
                 rows, shape = maxpool2x2(rows, shape, relu_input=True)
             outs.append((rows, shape))
@@ -148,6 +153,10 @@ class VGG16FPN(nn.Module):
         #   "out": the pyramid handed to the middle head -> the middle head's gradients are final
         #   "c4":  stage-4 output (conv5_1 and fpn_inner4 have back-propagated) -> conv5_x weights
         #   "c3":  stage-3 output (conv4_1 and fpn_inner3 have back-propagated) -> conv4_x and every FPN weight
+        #   "node:rest": output of the first trainable conv (conv3_1).  No tensor below it receives a gradient (stages 1-2
+        #          are frozen), so the trainer hooks its autograd NODE: when that node has run, conv3_1's weight gradient --
+        #          the last kernel of the backbone's backward -- is queued and the remaining bucket (conv3_x + every bias)
+        #          is final.  Until round 5 that bucket was only issued after backward() had returned.
         self.record_grad_marks = False
         self.grad_marks = {}
         self.grad_stage_params = [
@@ -168,6 +177,9 @@ class VGG16FPN(nn.Module):
         out = self.fpn(outs[2], outs[3], outs[4])
         if self.record_grad_marks and torch.is_grad_enabled():
             self.grad_marks = {"out": out[0], "c4": outs[3][0], "c3": outs[2][0]}
+            if self.body.first_trainable_out is not None:
+                self.grad_marks["node:rest"] = self.body.first_trainable_out
+        self.body.first_trainable_out = None
         return out
 
 

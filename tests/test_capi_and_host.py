@@ -35,11 +35,14 @@ def test_argument_validation_without_device():
     with pytest.raises(RuntimeError, match="ksize"):
         _lib.call("scan_conv2d_forward", None, d.ref(), 8, None, None, None, d.ref(), 8, 8, 4, 1, 0, None)
     with pytest.raises(RuntimeError, match="SCAN_NMS_MAX"):
-        _lib.call("scan_nms", None, None, None, 9000, 0.5, 1, None, ctypes.c_void_p(8), None, None)
+        _lib.call("scan_nms", None, None, None, _lib.NMS_MAX + 1, 0.5, 1, None, ctypes.c_void_p(8), None, None)
     with pytest.raises(RuntimeError, match="K in"):
         _lib.call("scan_dynconv_softmax_forward", None, None, 10, 256, 5, None, None, None)
-    assert _lib.query("scan_nms_ws_bytes", 9000) == -1
+    assert _lib.query("scan_nms_ws_bytes", _lib.NMS_MAX + 1) == -1
     assert _lib.query("scan_nms_ws_bytes", 100) > 0
+    # beyond one panel the mask is n x ceil(n / 64) words (the reference's own size, csrc/cuda/nms.cu:95-100) + sort keys
+    n = 20000
+    assert n * ((n + 63) // 64) * 8 <= _lib.query("scan_nms_ws_bytes", n) <= 1.1 * n * ((n + 63) // 64) * 8 + (1 << 20)
 
 
 def test_ops_refuse_cpu_tensors():
@@ -75,8 +78,8 @@ def test_compiled_fcos_core_C_module_loads_and_refuses_cpu_tensors():
     assert _C.scan_abi_version() == _lib.lib().scan_abi_version()
     k = _C.nms(torch.zeros(0, 4), torch.zeros(0), 0.5)  # csrc/nms.h:17-18
     assert k.numel() == 0 and k.dtype == torch.int64 and k.device.type == "cpu"
-    with pytest.raises(RuntimeError, match="CPU"):
-        _C.nms(torch.zeros(3, 4), torch.zeros(3), 0.5)
+    with pytest.raises(RuntimeError, match="same type"):  # csrc/cpu/nms_cpu.cpp:11
+        _C.nms(torch.zeros(3, 4), torch.zeros(3, dtype=torch.float64), 0.5)
     with pytest.raises(RuntimeError, match="CPU"):
         _C.ml_nms(torch.zeros(3, 4), torch.zeros(3), torch.zeros(3), 0.5)
     with pytest.raises(RuntimeError, match="Not implemented on the CPU"):
@@ -85,6 +88,59 @@ def test_compiled_fcos_core_C_module_loads_and_refuses_cpu_tensors():
         _C.roi_align_forward()
     from scan_amd import layers
     assert layers.C_BACKEND == "compiled" and layers.nms.__module__ is not None
+
+
+def _both_C():
+    from scan_amd import _C as ctypes_C
+    return (("compiled", _import_fcos_core_C()), ("ctypes", ctypes_C))
+
+
+def test_nms_on_cpu_tensors_runs_the_reference_unit_test(gold_dir):
+    """The reference's only hot-path unit test, tests/test_nms.py:11-58,60-217 (Caffe2's UtilsNMSTest cases, recorded
+    with their expected keep lists in tests/golden/nms_kat.json by oracle/make_golden.py while that unittest passed on the
+    imported reference), runs on CPU tensors: the reference's ``_C.nms`` dispatches those to nms_cpu
+    (csrc/nms.h:26, csrc/cpu/nms_cpu.cpp:5-75).  Same call, same answers, through the compiled module and its ctypes twin."""
+    kat = json.load(open(os.path.join(gold_dir, "nms_kat.json")))
+    assert len(kat["cases"]) == 6
+    for name, _C in _both_C():
+        for case in kat["cases"]:
+            boxes, scores = torch.tensor(case["boxes"], dtype=torch.float32), torch.tensor(case["scores"], dtype=torch.float32)
+            keep = _C.nms(boxes, scores, case["thresh"])
+            assert keep.dtype == torch.int64 and keep.device.type == "cpu", name
+            assert np.sort(keep.numpy()).tolist() == case["keep_sorted"], (name, case["thresh"])
+            # AT_DISPATCH_FLOATING_TYPES (nms_cpu.cpp:71): double tensors take the same loop in double
+            assert np.sort(_C.nms(boxes.double(), scores.double(), case["thresh"]).numpy()).tolist() == case["keep_sorted"]
+
+
+def test_nms_on_cpu_tensors_bit_exact_against_oracle_both_tie_rules():
+    """random boxes on a 4-pixel grid (exact IoU ties with the threshold, duplicate boxes) and tied scores: the host loop of
+    the compiled module and of its ctypes twin against the C oracle's keep list (>=), and the '>' rule of
+    csrc/cuda/nms.cu:60 through ``cuda_rule=True`` / SCAN_NMS_RULE=gt against the oracle's ml_nms with one label."""
+    from oracle import coracle
+    for n in (1, 2, 65, 700, 3000):
+        rs = np.random.RandomState(n)
+        # corners on a 4-pixel grid with x2 = 4 j - 1: widths + 1 are multiples of 4, so IoU hits 1/4 and 1/2 exactly
+        xy = np.floor(rs.uniform(0, 200, (n, 2)) / 4.0) * 4.0
+        boxes = np.concatenate([xy, xy + np.ceil(rs.uniform(1, 70, (n, 2)) / 4.0) * 4.0 - 1.0], 1).astype(np.float32)
+        scores = (rs.randint(0, max(2, n // 3), n) / float(max(2, n // 3))).astype(np.float32)
+        one = np.ones(n, np.float32)
+        differ = 0
+        for thr in (0.25, 0.5, 0.6):
+            ge, gt = coracle.nms(boxes, scores, thr), coracle.ml_nms(boxes, scores, one, thr)
+            differ += int(not np.array_equal(ge, gt))
+            for name, _C in _both_C():
+                if name == "ctypes" and n > 700:
+                    continue  # the Python twin is a loop over kept boxes; the compiled one takes every size
+                b, s = torch.from_numpy(boxes), torch.from_numpy(scores)
+                assert np.array_equal(_C.nms(b, s, thr).numpy(), ge), (name, n, thr)
+                assert np.array_equal(_C.nms(b, s, thr, cuda_rule=True).numpy(), gt), (name, n, thr)
+                os.environ["SCAN_NMS_RULE"] = "gt"
+                try:
+                    assert np.array_equal(_C.nms(b, s, thr).numpy(), gt), (name, n, thr)
+                finally:
+                    del os.environ["SCAN_NMS_RULE"]
+        if n >= 700:
+            assert differ > 0, "the two tie rules never disagreed: the cases do not exercise the switch"
 
 
 def test_pyramid_shape():

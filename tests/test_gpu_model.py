@@ -17,6 +17,12 @@ DEFAULT_MODE = "bf16x6"   # ops.CONV_MODE as shipped: three bf16 pieces per oper
 ALL_MODES = ("fp32", "bf16x6", "bf16x3")
 
 
+# sampled gradient elements of the mid-size / cfg1 / cfg2 / cfg5 fixtures, fp32 and bf16x6 modes: |mine - ref| <= SAMPLED_BAR x
+# (|ref| + mean |grad|).  Round 4 held 5e-2; the bar is what bf16x6 measures on those fixtures + 50 % (the printed
+# "worst sampled element" lines)
+SAMPLED_BAR = 5e-2
+
+
 def _digest(g):
     flat = g.detach().double().reshape(-1).cpu()
     idx = torch.linspace(0, flat.numel() - 1, 8).long()
@@ -27,7 +33,7 @@ def _check_all_gradient_digests(gold, model, mode, rt, tag):
     """EVERY parameter-gradient digest the fixture holds (sum and abs-sum, error relative to the abs-sum) within
     ``rt``; the two smallest discriminator levels get twice the bar in bf16x3 mode (a handful of rows: one ReLU
     decision flipped by the operand split moves their digests by ~1e-3).  Prints the six worst entries."""
-    worst, errs = (0.0, None), []
+    worst, errs, samp = (0.0, None), [], (0.0, None)
     for mk, m in model.items():
         for name, p in m.named_parameters():
             ref = gold["grad_digest"][mk].get(name)
@@ -46,12 +52,14 @@ def _check_all_gradient_digests(gold, model, mode, rt, tag):
             # barely move when a small part of it is dropped -- single elements are not.  An element of a deep gradient
             # is a sum of thousands of cancelling terms, so the bar is relative to the element AND to the mean magnitude
             mean_abs = ref[1] / max(1, p.numel())
-            st = 5e-2 if mode != "bf16x3" else (0.5 if small else 0.2)  # fp32 and bf16x6: 5e-2 everywhere
+            st = SAMPLED_BAR if mode != "bf16x3" else (0.5 if small else 0.2)  # fp32 and bf16x6: one bar everywhere
             for a, b in zip(mine[2:], ref[2:]):
+                samp = max(samp, (abs(a - b) / (abs(b) + mean_abs + 1e-30), mk + "/" + name))
                 assert abs(a - b) <= st * abs(b) + st * mean_abs + 1e-7, (tag, mode, mk, name, a, b)
     errs.sort(reverse=True)
     print("%s %s: %d gradient digests, worst errors (sum / abs-sum, relative to abs-sum): %s" % (
         tag, mode, len(errs), ", ".join("%.2e %s" % e for e in errs[:6])))
+    print("%s %s: worst sampled element, |mine - ref| / (|ref| + mean |grad|): %.2e %s" % (tag, mode, samp[0], samp[1]))
     assert worst[0] <= rt, (tag, mode, worst)
 
 
@@ -127,11 +135,22 @@ def test_step_gradients_match_reference(step_result):
     report.sort(reverse=True)
     print("step_128x256 %s: %d digests; closest to their bar (error / bar, error, parameter): %s" % (
         mode, len(report), ", ".join("%.2f %.1e %s" % r for r in report[:6])))
-    # One ReLU decision of a pre-activation within fp32 rounding of zero falls on the other side whenever the summation
-    # order differs from the reference's (any two fp32 implementations: DESIGN.md section 4); on the 4x8-pixel and smaller
-    # discriminator levels of this 128x256 fixture that is 1 of 128 rows and moves a bias digest by ~1e-3.  Whatever the
-    # mode, at most ONE of the 347 digests may sit between its bar and twice its bar, and only on a discriminator.
-    assert len(fails) <= 1 and all(f[0].startswith("dis_") and f[2] <= 2 * f[3] for f in fails), fails
+    # The exact fp32-MFMA mode pins the reference with NO allowance: every one of the 347 digests within its bar.
+    # bf16x6: one NAMED digest may sit between its bar and twice its bar -- KNOWN_RELU_FLIP below; any other digest over its
+    # bar fails.  bf16x3 (16 significand bits, documented allowances): at most one discriminator digest up to twice its bar.
+    if mode == "fp32":
+        assert not fails, fails
+    elif mode == "bf16x6":
+        assert all((f[0], f[1]) in KNOWN_RELU_FLIP and f[2] <= 2 * f[3] for f in fails), fails
+    else:
+        assert len(fails) <= 1 and all(f[0].startswith("dis_") and f[2] <= 2 * f[3] for f in fails), fails
+
+
+# step_128x256, bf16x6 only: the bias gradient of a discriminator layer on a 4x8-pixel (or smaller) level is a sum over <= 128
+# rows; ONE of those rows has a pre-activation within fp32 rounding of zero in the reference's own run, and the six-product
+# summation order of the split kernels puts its ReLU decision on the other side (1 row of 128 moves the digest by ~1.5e-3
+# against a 1e-3 bar).  Named here instead of allowing "any one discriminator digest"; the exact fp32 mode has no allowance.
+KNOWN_RELU_FLIP = set()
 
 
 def test_prototype_and_kernels_match_reference(step_result, gold_dir):
@@ -290,7 +309,9 @@ def test_trajectory_matches_reference(device, gold_dir, conv_mode):
         # summation order of the kernels in use: fp32-MFMA 1.01e-4 at iteration 6, bf16x6 1.04e-4 / 1.19e-4 / 1.00e-4 at
         # iterations 4 / 5 / 6; the same trajectory run by the REFERENCE and by its CPU restatement already differs by 2e-5
         # there -- so they get 2e-4)
-        if conv_mode != "bf16x3":
+        if conv_mode == "fp32":    # the exact path pins the reference: 1e-4 through iteration 5 (measured 5.7e-5 / 7.0e-5 at
+            bar = LOSS_RTOL if it < 6 else 2e-4  # iterations 4 / 5), 1.01e-4 at iteration 6
+        elif conv_mode == "bf16x6":
             bar = LOSS_RTOL if it < 4 else 2e-4
         else:
             bar = LOSS_RTOL if it < 3 else 5e-4
@@ -309,6 +330,54 @@ def test_trajectory_matches_reference(device, gold_dir, conv_mode):
                 tol = 1e-2 if not (conv_mode == "bf16x3" and mk in ("dis_P6_CON", "dis_P7_CON")) else 3e-2
                 assert abs(mine - ref[1]) <= tol * ref[1], (conv_mode, mk, n, mine, ref[1])
     assert trainer.groups["middle_head"].skipped == ["cond_2.weight", "cond_2.bias"]
+
+
+@pytest.mark.parametrize("conv_mode", ["fp32", "bf16x6"])
+@pytest.mark.parametrize("fixture", ["traj_yaml_128x256", "traj_yaml_full_lr_128x256"])
+def test_trajectory_at_yaml_solver_values_is_drift_bounded(device, gold_dir, fixture, conv_mode):
+    """Training pinned at the hyper-parameters the reference actually trains with (engine/trainer.py:266-424,
+    solver/build.py:7-43): 5 DA iterations with the yaml's SOLVER section untouched (``traj_yaml``: BASE_LR 0.0025 behind the
+    constant 1/3 warm-up of the first 1000 iterations) and past the warm-up (``traj_yaml_full_lr``: the full 0.0025 / 0.005).
+    At these rates the dynamics amplify rounding differences -- the fixture holds, per iteration, the losses of the imported
+    reference AND of its CPU restatement (same fp32 operations in another summation order), which part by 2e-7 -> 4e-4 / 8e-4
+    over the five iterations -- so the bar is relative to that: |gpu - reference| <= 3 x |restatement - reference| per loss and
+    iteration, with a floor of 1e-4 (the north-star tolerance) -- i.e. this implementation may drift from the reference no
+    faster than the reference's own arithmetic re-ordered does.  Both fp32 arithmetics (exact fp32-MFMA, bf16x6)."""
+    from scan_amd import config, engine, ops, synth
+    gold = json.load(open(os.path.join(gold_dir, fixture + ".json")))
+    H, W, N, K = gold["H"], gold["W"], gold["N"], gold["num_classes"]
+    opts = [tuple(x) if isinstance(x, list) else x for x in gold["opts"]]
+    settings = config.settings(config.load("c2f", opts))
+    ops.CONV_MODE = conv_mode
+    rows, bad = [], []
+    try:
+        model = engine.build_model(device=device, attn_dropout=0.0, settings=settings)
+        engine.load_procedural_weights(model)
+        trainer = engine.Trainer(model, settings=settings)
+        for it in range(gold["iters"]):
+            for k, (lw, lb) in gold["lr"][it].items():  # the yaml's schedule, as the reference's own scheduler stepped it
+                assert abs(trainer.lr_of(k) - lw) <= 1e-9 * lw and abs(trainer.lr_of(k, bias=True) - lb) <= 1e-9 * lb
+            imgs_s, tg, imgs_t = synth.traj_batch(it, H, W, N, K)
+            losses = trainer.step(imgs_s.to(device), tg, imgs_t.to(device))
+            ref, rst = gold["losses_reference"][it], gold["losses_restatement"][it]
+            worst_g, worst_r = (0.0, ""), (0.0, "")
+            for k, r in ref.items():
+                v = float(losses[k])
+                if r == 0.0:
+                    assert v == 0.0, (it, k, v)
+                    continue
+                eg, er = abs(v - r) / abs(r), abs(rst[k] - r) / abs(r)
+                worst_g, worst_r = max(worst_g, (eg, k)), max(worst_r, (er, k))
+                if eg > max(LOSS_RTOL, 3.0 * er):
+                    bad.append((it, k, eg, er))
+            rows.append((it, gold["lr"][it]["backbone"][0], worst_g[0], worst_g[1], worst_r[0], worst_r[1]))
+        torch.cuda.synchronize()
+    finally:
+        ops.CONV_MODE = DEFAULT_MODE
+    print("%s %s: iteration, backbone lr, worst |gpu - ref| (loss), worst |restatement - ref| (loss)" % (fixture, conv_mode))
+    for r in rows:
+        print("   it %d  lr %.6f  gpu %.2e %-22s restatement %.2e %s" % r)
+    assert not bad, (fixture, conv_mode, bad)
 
 
 def test_step_mid_size_all_gradients_match_reference(device, gold_dir):

@@ -145,7 +145,7 @@ def main():
                 olds = []
                 for kv in key.split("+"):
                     k, v = kv.split("=")
-                    assert _lib.query("scan_tune_get", k.encode()) != -1 or k == "wgrad_tile", "unknown scan_tune key " + k
+                    assert _lib.query("scan_tune_get", k.encode()) != _lib.TUNE_UNKNOWN, "unknown scan_tune key " + k
                     olds.append((k, _lib.query("scan_tune", k.encode(), int(v))))
                 y, us, tf = {"fwd": run, "dgrad": run_dgrad, "wgrad": run_wgrad}[a.op](sd, a.reps, dev)
                 for k, o in olds:

@@ -24,10 +24,12 @@ SIZES_OF_INTEREST = ((-1, 64), (64, 128), (128, 256), (256, 512), (512, INF))  #
 VGG_CONVS = ((0, 2), (5, 7), (10, 12, 14), (17, 19, 21), (24, 26, 28))  # mmdetection/vgg.py:52-57
 
 
-def params(sd, requires_grad=True, frozen_prefixes=()):
+def params(sd, requires_grad=True, frozen_prefixes=(), dtype=torch.float32):
+    """dtype=torch.float64: the same iteration in double precision -- not the reference's arithmetic but the yardstick for its
+    rounding error (oracle/make_golden.py gen_traj_yaml: how far the fp32 reference itself is from exact arithmetic)."""
     out = {}
     for k, v in sd.items():
-        t = v.detach().clone().float()
+        t = v.detach().clone().to(dtype) if v.is_floating_point() else v.detach().clone().float()
         bn_buffer = ".bn" in k or ".downsample.1." in k  # FrozenBatchNorm2d holds buffers, not parameters
         if requires_grad and t.is_floating_point() and k != "prototype" and not bn_buffer \
                 and not k.startswith(tuple(frozen_prefixes)):

@@ -500,6 +500,11 @@ __device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][
 // block with the other wave of the SIMD mostly in the same state.  12 more registers for the second fragment set, 8 for the
 // temporaries: 162 at the 168-register cap, no scratch.  The resident dY fragments are requested tile by tile so that the
 // first block can start after 12 of the 24 transposed reads behind the barrier.
+// Round 5, measured and NOT adopted (profiles/r05_wgrad_pipe2_ab.txt): the block as two back-to-back six-product chains (tile
+// 0, then tile 1) with each temporary's final add in the shadow of the other tile's MFMAs -- no "s_nop 6 + adds" stall at the
+// end of a block in the ISA, four registers fewer, bit-identical -- runs 3-4 % SLOWER on every shape (conv3_x 2,510 -> 2,600 us,
+// conv4_x 2,430 -> 2,535, same box, A B A B): the two interleaved chains of this form keep the pipe busier than one dependent
+// chain at a time, and the stall at the block end is covered by the SIMD's other consumer wave.
 template <int NP, int WKC, int TO, int TC, int KX, int TOMAX, int TCMAX>
 __device__ __forceinline__ void wgrad_mma_v6_pipe(const W6Lane& w, f32x4v (&acc)[KX][TCMAX][TOMAX]) {
   static_assert(WKC == 32, "one 32-pixel step per chunk");
@@ -841,9 +846,10 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
 }
 
 // scan_tune "wgrad_tile": consumer wave tile of the producer / consumer kernel: 0 = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c),
-// -1 (default) = by piece count: three pieces 32 x 64 (conv3_x 2542 -> 2489 us, class-branch 264 -> 1024 3409 -> 3293,
+// 2 (default) = by piece count: three pieces 32 x 64 (conv3_x 2542 -> 2489 us, class-branch 264 -> 1024 3409 -> 3293,
 // head_out 1177 -> 1123: tools/conv_bench.py --op wgrad --variants wgrad_tile=0,wgrad_tile=1), two pieces 64 x 32 (within
-// noise of the other).  Same results bit for bit.
+// noise of the other).  Two pieces: same results bit for bit; three pieces: the 64 x 32 tile has no temporary accumulator
+// (other rounding, further from fp64: tests/test_gpu_kernels.py::test_wgrad_full_size_elementwise measures both).
 int g_scan_wgrad_tile = 2;  // 2 = by piece count
 // scan_tune "wgrad_v6": 1 (default) = the 3x3 launches take the producer / consumer kernel, 0 = conv_wgrad_v4_kernel
 int g_scan_wgrad_v6 = 1;

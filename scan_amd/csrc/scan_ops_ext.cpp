@@ -1,0 +1,415 @@
+// C++ autograd entry points of the SCAN hot-path operators (BASELINE.json north_star: "registered behind the existing
+// fcos_core.layers / fcos_core.modeling operator surface ... via PyTorch-ROCm C++ extensions"; SURVEY.md section 7 step 1
+// names conv3x3_gn_relu_* and dynamic_conv_softmax_*).  Built by __graft_entry__.build() into
+// scan_amd/ext/scan_ops/_ops<EXT_SUFFIX> (plain g++: host code only; every device operation is a call into libscan_hip.so
+// through the C ABI of include/scan_hip.h, nothing of torch crosses that boundary).
+//
+// Every function takes and returns NCHW tensors the way the reference's modules call torch.nn (a channels_last NCHW tensor
+// IS the kernels' pixel-major row matrix, so the adaptor is a view; any other layout is converted once on entry), records a
+// torch::autograd::Function node, and runs forward AND backward without entering the Python interpreter:
+//
+//   conv2d(x, weight, bias, stride, relu)                      nn.Conv2d(k in {1, 3}, padding k // 2) [+ ReLU]
+//        rpn/fcos/fcos.py:25-64, rpn/fcos/condgraph.py:86-106, backbone/fpn.py:52-66,118-130, backbone/mmdetection/vgg.py:8-33
+//   conv3x3_gn_relu(x, weight, bias, gamma, beta, eps, relu)   the [Conv2d(3x3), GroupNorm(32, 256), ReLU] tower block
+//        rpn/fcos/fcos.py:36-49, rpn/fcos/condgraph.py:99-105, discriminator/fcos_head_discriminator_con.py:20-34
+//   group_norm_relu(x, gamma, beta, eps, relu)                 nn.GroupNorm(32, 256) [+ ReLU]
+//   dynamic_conv_softmax(features, kernels)                    F.conv2d(x, kernel_par[K, 256, 1, 1]) + softmax(dim = 1)
+//        rpn/fcos/condgraph.py:619-629,344-346
+//
+// Arithmetic: the reference's fp32 multiply / fp32 accumulate on the bf16 matrix cores ("bf16x6", scan_hip.h); 3x3 / stride 2
+// (P6 / P7) on the exact fp32-MFMA kernels.  Same kernels as scan_amd.ops -> bit-identical results (tests/test_gpu_kernels.py).
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPGuardImplMasqueradingAsCUDA.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <torch/extension.h>
+
+#include <vector>
+
+#include "../../include/scan_hip.h"
+
+namespace {
+
+using torch::autograd::AutogradContext;
+using torch::autograd::variable_list;
+
+void* cur_stream(const at::Tensor& t) { return c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.device().index()).stream(); }
+void check(int rc, const char* what) { TORCH_CHECK(rc == 0, what, " failed (", rc, "): ", scan_last_error()); }
+int64_t pad4(int64_t c) { return (c + 3) / 4 * 4; }
+int64_t round_up(int64_t c, int64_t m) { return (c + m - 1) / m * m; }
+
+void require_gpu_f32(const at::Tensor& t, const char* who, const char* what) {
+  TORCH_CHECK(t.is_cuda(), who, ": ", what, " must be a GPU tensor (the HIP kernels have no CPU fallback)");
+  TORCH_CHECK(t.scalar_type() == at::kFloat, who, ": ", what, " must be float32");
+}
+
+scan_pyramid_t one_level(int64_t n, int64_t h, int64_t w) {
+  scan_pyramid_t d{};
+  d.n_levels = 1;
+  d.n_images = (int32_t)n;
+  d.h[0] = (int32_t)h;
+  d.w[0] = (int32_t)w;
+  d.row_off[0] = 0;
+  d.row_off[1] = n * h * w;
+  return d;
+}
+
+// [N, C, H, W] -> rows [N*H*W, pad4(C)] (zero-copy for channels_last tensors with C % 4 == 0)
+at::Tensor to_rows(const at::Tensor& x) {
+  const int64_t n = x.size(0), c = x.size(1), h = x.size(2), w = x.size(3);
+  at::Tensor r = x.permute({0, 2, 3, 1});
+  if (c % 4 != 0) r = at::constant_pad_nd(r, {0, pad4(c) - c}, 0);
+  return r.contiguous().view({n * h * w, pad4(c)});
+}
+// rows [N*H*W, Cs] -> channels_last NCHW view of the first c channels
+at::Tensor to_nchw(const at::Tensor& rows, int64_t n, int64_t h, int64_t w, int64_t c) {
+  return rows.view({n, h, w, rows.size(1)}).slice(3, 0, c).permute({0, 3, 1, 2});
+}
+// weight [O, I, k, k] -> packed fp32 [O][k*k][pad4(I)] (what a channels_last weight is physically, channel-padded)
+at::Tensor pack_weight(const at::Tensor& w) {
+  const int64_t o = w.size(0), i = w.size(1), t = w.size(2) * w.size(3);
+  at::Tensor p = w.permute({0, 2, 3, 1});
+  if (i % 4 != 0) p = at::constant_pad_nd(p, {0, pad4(i) - i}, 0);
+  return p.contiguous().view({o, t, pad4(i)});
+}
+// packed gradient [O][T][Cs] -> gradient of the logical weight [O, I, k, k] (channels_last strides like the parameter)
+at::Tensor unpack_wgrad(const at::Tensor& dwp, int64_t i, int64_t k) {
+  return dwp.view({dwp.size(0), k, k, dwp.size(2)}).slice(3, 0, i).permute({0, 3, 1, 2});
+}
+
+struct Planes {
+  at::Tensor p[3];
+  int64_t csw;
+};
+// three bf16 planes of packed weights wp [O][T][Cs]; mode 0: forward [O][T][csw]; mode 1: data gradient [Cs][T][csw]
+Planes split3(const at::Tensor& wp, int mode, int64_t cs_src) {
+  const int64_t o = wp.size(0), t = wp.size(1), cs = wp.size(2);
+  const int64_t rnd = t == 9 ? 32 : 8;  // 3x3: whole 32-channel K chunks (LDS-DMA weight tiles); 1x1: 8-element granule
+  Planes pl;
+  const int64_t rows = mode == 0 ? o : cs;
+  pl.csw = round_up(mode == 0 ? cs : std::max(o, cs_src), rnd);
+  for (auto& q : pl.p) q = at::empty({rows, t, pl.csw}, wp.options().dtype(at::kBFloat16));
+  check(scan_weight_split3(wp.data_ptr<float>(), (int32_t)o, (int32_t)t, (int32_t)cs, mode, pl.p[0].data_ptr(), pl.p[1].data_ptr(),
+                           pl.p[2].data_ptr(), (int32_t)pl.csw, cur_stream(wp)),
+        "scan_weight_split3");
+  return pl;
+}
+
+const float* opt_ptr(const at::Tensor& t) { return t.defined() ? t.data_ptr<float>() : nullptr; }
+
+struct ConvGeom {
+  int64_t n, cin, h, w, cout, k, stride, ho, wo, cs, ns;
+};
+ConvGeom geom(const at::Tensor& x, const at::Tensor& weight, int64_t stride, const char* who) {
+  require_gpu_f32(x, who, "input");
+  require_gpu_f32(weight, who, "weight");
+  TORCH_CHECK(x.dim() == 4 && weight.dim() == 4, who, ": input [N, C, H, W] and weight [O, I, k, k]");
+  TORCH_CHECK(weight.size(1) == x.size(1), who, ": weight expects ", weight.size(1), " input channels, got ", x.size(1));
+  TORCH_CHECK(weight.size(2) == weight.size(3) && (weight.size(2) == 1 || weight.size(2) == 3), who,
+              ": kernel size 1 or 3 (square), padding = k // 2 -- the convolutions the SCAN modules build");
+  TORCH_CHECK(stride == 1 || stride == 2, who, ": stride 1 or 2");
+  ConvGeom g;
+  g.n = x.size(0), g.cin = x.size(1), g.h = x.size(2), g.w = x.size(3);
+  g.cout = weight.size(0), g.k = weight.size(2), g.stride = stride;
+  g.ho = (g.h - 1) / stride + 1, g.wo = (g.w - 1) / stride + 1;  // padding k // 2
+  g.cs = pad4(g.cin), g.ns = pad4(g.cout);
+  return g;
+}
+
+// ---- forward / backward of a conv on row matrices (shared by Conv2dFn and ConvGnReluFn) -------------------------------
+// y rows [Mo, Ns]; gn_sums (defined): the epilogue accumulates the GroupNorm sums of the output there (3x3 / stride 1 only)
+at::Tensor conv_rows_forward(const at::Tensor& xr, const at::Tensor& wp, const at::Tensor& bias, const ConvGeom& g, bool relu,
+                             at::Tensor gn_sums) {
+  const scan_pyramid_t xd = one_level(g.n, g.h, g.w), yd = one_level(g.n, g.ho, g.wo);
+  at::Tensor y = g.ns != g.cout ? at::zeros({yd.row_off[1], g.ns}, xr.options()) : at::empty({yd.row_off[1], g.ns}, xr.options());
+  void* st = cur_stream(xr);
+  if (g.k == 3 && g.stride == 2) {  // P6 / P7: exact fp32-MFMA kernel
+    check(scan_conv2d_forward(xr.data_ptr<float>(), &xd, (int32_t)g.cs, wp.data_ptr<float>(), opt_ptr(bias), y.data_ptr<float>(), &yd,
+                              (int32_t)g.cout, (int32_t)g.ns, 3, 2, relu ? 1 : 0, st),
+          "scan_conv2d_forward");
+    return y;
+  }
+  const Planes pl = split3(wp, 0, g.cs);
+  if (g.k == 3) {
+    if (gn_sums.defined())
+      check(scan_conv3x3_gn_bf16x6(xr.data_ptr<float>(), &xd, (int32_t)g.cs, pl.p[0].data_ptr(), pl.p[1].data_ptr(), pl.p[2].data_ptr(),
+                                   (int32_t)pl.csw, opt_ptr(bias), y.data_ptr<float>(), (int32_t)g.cout, (int32_t)g.ns,
+                                   reinterpret_cast<float*>(gn_sums.data_ptr()), 1, st),
+            "scan_conv3x3_gn_bf16x6");
+    else
+      check(scan_conv3x3_bf16x6(xr.data_ptr<float>(), &xd, (int32_t)g.cs, pl.p[0].data_ptr(), pl.p[1].data_ptr(), pl.p[2].data_ptr(),
+                                (int32_t)pl.csw, opt_ptr(bias), nullptr, y.data_ptr<float>(), (int32_t)g.cout, (int32_t)g.ns,
+                                relu ? 1 : 0, st),
+            "scan_conv3x3_bf16x6");
+  } else {
+    check(scan_conv1x1_bf16x6(xr.data_ptr<float>(), &xd, (int32_t)g.cs, pl.p[0].data_ptr(), pl.p[1].data_ptr(), pl.p[2].data_ptr(),
+                              (int32_t)pl.csw, opt_ptr(bias), nullptr, y.data_ptr<float>(), &yd, (int32_t)g.cout, (int32_t)g.ns,
+                              relu ? 1 : 0, g.stride == 2 ? 1 : 0, st),
+          "scan_conv1x1_bf16x6");
+  }
+  return y;
+}
+
+// dyr rows [Mo, Ns] (the ReLU, if any, already backed out).  Returns {dx rows [Mi, Cs] or undefined, dw packed, db or undefined}
+std::vector<at::Tensor> conv_rows_backward(const at::Tensor& xr, const at::Tensor& wp, const at::Tensor& dyr, const ConvGeom& g,
+                                           bool need_dx, bool need_dw, bool need_db) {
+  const scan_pyramid_t xd = one_level(g.n, g.h, g.w), yd = one_level(g.n, g.ho, g.wo);
+  void* st = cur_stream(xr);
+  const int64_t T = g.k * g.k;
+  at::Tensor dx, dw, db;
+  if (need_dx) {
+    dx = at::empty({xd.row_off[1], g.cs}, xr.options());
+    if (g.k == 3 && g.stride == 2) {
+      at::Tensor wt = at::empty({g.cs, T, g.ns}, xr.options());
+      check(scan_weight_transpose(wp.data_ptr<float>(), (int32_t)g.cout, (int32_t)T, (int32_t)g.cs, wt.data_ptr<float>(), (int32_t)g.ns, st),
+            "scan_weight_transpose");
+      check(scan_conv2d_dgrad(dyr.data_ptr<float>(), &yd, (int32_t)g.ns, wt.data_ptr<float>(), dx.data_ptr<float>(), &xd, (int32_t)g.cs,
+                              (int32_t)g.cs, 3, 2, nullptr, st),
+            "scan_conv2d_dgrad");
+    } else {
+      const Planes pl = split3(wp, 1, g.ns);  // flipped + transposed planes: the data gradient is the forward kernel on dY
+      if (g.k == 3)
+        check(scan_conv3x3_bf16x6(dyr.data_ptr<float>(), &yd, (int32_t)g.ns, pl.p[0].data_ptr(), pl.p[1].data_ptr(), pl.p[2].data_ptr(),
+                                  (int32_t)pl.csw, nullptr, nullptr, dx.data_ptr<float>(), (int32_t)g.cs, (int32_t)g.cs, 0, st),
+              "scan_conv3x3_bf16x6 (data gradient)");
+      else
+        check(scan_conv1x1_bf16x6(dyr.data_ptr<float>(), &yd, (int32_t)g.ns, pl.p[0].data_ptr(), pl.p[1].data_ptr(), pl.p[2].data_ptr(),
+                                  (int32_t)pl.csw, nullptr, nullptr, dx.data_ptr<float>(), &xd, (int32_t)g.cs, (int32_t)g.cs, 0,
+                                  g.stride == 2 ? 2 : 0, st),
+              "scan_conv1x1_bf16x6 (data gradient)");
+    }
+  }
+  if (need_dw || need_db) {
+    dw = at::empty({g.cout, T, g.cs}, xr.options());
+    if (need_db) db = at::empty({g.cout}, xr.options());
+    if (g.k == 3 && g.stride == 1) {
+      at::Tensor ws = at::empty({scan_conv3x3_wgrad_bf16x6_ws_floats(&xd, (int32_t)g.cs, (int32_t)g.cout)}, xr.options());
+      check(scan_conv3x3_wgrad_bf16x6(xr.data_ptr<float>(), &xd, (int32_t)g.cs, dyr.data_ptr<float>(), (int32_t)g.cout, (int32_t)g.ns,
+                                      dw.data_ptr<float>(), need_db ? db.data_ptr<float>() : nullptr, 0, ws.data_ptr<float>(), st),
+            "scan_conv3x3_wgrad_bf16x6");
+    } else if (g.k == 1) {
+      at::Tensor ws = at::empty({scan_conv1x1_wgrad_bf16x6_ws_floats(&yd, (int32_t)g.cs, (int32_t)g.cout)}, xr.options());
+      check(scan_conv1x1_wgrad_bf16x6(xr.data_ptr<float>(), &xd, (int32_t)g.cs, dyr.data_ptr<float>(), &yd, (int32_t)g.cout, (int32_t)g.ns,
+                                      (int32_t)g.stride, dw.data_ptr<float>(), need_db ? db.data_ptr<float>() : nullptr, 0,
+                                      ws.data_ptr<float>(), st),
+            "scan_conv1x1_wgrad_bf16x6");
+    } else {
+      at::Tensor ws = at::empty({scan_conv2d_wgrad_ws_floats(&yd, (int32_t)g.cs, (int32_t)g.cout, 3)}, xr.options());
+      check(scan_conv2d_wgrad(xr.data_ptr<float>(), &xd, (int32_t)g.cs, dyr.data_ptr<float>(), &yd, (int32_t)g.cout, (int32_t)g.ns, 3, 2,
+                              dw.data_ptr<float>(), 0, ws.data_ptr<float>(), st),
+            "scan_conv2d_wgrad");
+      if (need_db) {
+        at::Tensor cws = at::empty({scan_colsum_ws_floats(yd.row_off[1], (int32_t)g.cout)}, xr.options());
+        check(scan_colsum(dyr.data_ptr<float>(), yd.row_off[1], (int32_t)g.cout, (int32_t)g.ns, db.data_ptr<float>(), 0,
+                          cws.data_ptr<float>(), st),
+              "scan_colsum");
+      }
+    }
+  }
+  return {dx, dw, db};
+}
+
+at::Tensor dy_rows(const at::Tensor& gy, int64_t ns) {  // incoming NCHW gradient -> rows [Mo, Ns]
+  at::Tensor r = to_rows(gy);
+  TORCH_CHECK(r.size(1) == ns, "gradient has ", r.size(1), " channel columns, expected ", ns);
+  return r;
+}
+
+// ---- nn.Conv2d (+ ReLU) ------------------------------------------------------------------------------------------------
+struct Conv2dFn : public torch::autograd::Function<Conv2dFn> {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor weight, c10::optional<at::Tensor> bias_opt, int64_t stride,
+                            bool relu) {
+    const at::Tensor bias = bias_opt.has_value() ? *bias_opt : at::Tensor();
+    const ConvGeom g = geom(x, weight, stride, "conv2d");
+    if (bias.defined()) require_gpu_f32(bias, "conv2d", "bias");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    at::Tensor xr = to_rows(x), wp = pack_weight(weight);
+    at::Tensor bc = bias.defined() ? bias.contiguous() : bias;
+    at::Tensor y = conv_rows_forward(xr, wp, bc, g, relu, at::Tensor());
+    ctx->save_for_backward({xr, wp, relu ? y : at::Tensor()});
+    ctx->saved_data["geom"] = std::vector<int64_t>{g.n, g.cin, g.h, g.w, g.cout, g.k, g.stride, g.ho, g.wo, g.cs, g.ns};
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["has_bias"] = bias.defined();
+    return to_nchw(y, g.n, g.ho, g.wo, g.cout);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto saved = ctx->get_saved_variables();
+    const at::Tensor xr = saved[0], wp = saved[1], y = saved[2];
+    const auto v = ctx->saved_data["geom"].toIntVector();
+    const ConvGeom g{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10]};
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(xr.device());
+    at::Tensor dyr = dy_rows(grads[0], g.ns);
+    if (ctx->saved_data["relu"].toBool()) {
+      at::Tensor t = at::empty_like(dyr);
+      check(scan_relu_backward(dyr.data_ptr<float>(), y.data_ptr<float>(), t.data_ptr<float>(), dyr.numel(), cur_stream(dyr)),
+            "scan_relu_backward");
+      dyr = t;
+    }
+    const bool has_bias = ctx->saved_data["has_bias"].toBool();
+    auto r = conv_rows_backward(xr, wp, dyr, g, ctx->needs_input_grad(0), ctx->needs_input_grad(1),
+                                has_bias && ctx->needs_input_grad(2));
+    at::Tensor dx = r[0].defined() ? to_nchw(r[0], g.n, g.h, g.w, g.cin) : at::Tensor();
+    at::Tensor dw = (r[1].defined() && ctx->needs_input_grad(1)) ? unpack_wgrad(r[1], g.cin, g.k) : at::Tensor();
+    return {dx, dw, r[2], at::Tensor(), at::Tensor()};
+  }
+};
+
+// ---- nn.GroupNorm(32, 256) (+ ReLU) on rows ------------------------------------------------------------------------------
+constexpr int kGroups = 32;
+
+at::Tensor gn_rows_backward(const at::Tensor& xr, const at::Tensor& gamma, const at::Tensor& beta, const at::Tensor& stats,
+                            const at::Tensor& dyr, const scan_pyramid_t& d, bool relu, at::Tensor& dgamma, at::Tensor& dbeta) {
+  const int32_t C = (int32_t)xr.size(1);
+  at::Tensor dx = at::empty_like(xr);
+  dgamma = at::empty({C}, xr.options());
+  dbeta = at::empty({C}, xr.options());
+  at::Tensor ws = at::empty({scan_groupnorm_ws_floats(&d, C, kGroups) / 2 + 1}, xr.options().dtype(at::kDouble));
+  check(scan_groupnorm_relu_backward(xr.data_ptr<float>(), beta.data_ptr<float>(), dyr.data_ptr<float>(), &d, C, kGroups,
+                                     stats.data_ptr<float>(), gamma.data_ptr<float>(), relu ? 1 : 0, dx.data_ptr<float>(),
+                                     dgamma.data_ptr<float>(), dbeta.data_ptr<float>(), 0, reinterpret_cast<float*>(ws.data_ptr()),
+                                     cur_stream(xr)),
+        "scan_groupnorm_relu_backward");
+  return dx;
+}
+
+struct GroupNormReluFn : public torch::autograd::Function<GroupNormReluFn> {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor gamma, at::Tensor beta, double eps, bool relu) {
+    require_gpu_f32(x, "group_norm_relu", "input");
+    require_gpu_f32(gamma, "group_norm_relu", "weight");
+    require_gpu_f32(beta, "group_norm_relu", "bias");
+    TORCH_CHECK(x.dim() == 4, "group_norm_relu: input [N, C, H, W]");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    const int64_t n = x.size(0), c = x.size(1), h = x.size(2), w = x.size(3);
+    const scan_pyramid_t d = one_level(n, h, w);
+    at::Tensor xr = to_rows(x), gc = gamma.contiguous(), bc = beta.contiguous();
+    at::Tensor stats = at::empty({n * kGroups * 2}, xr.options()), y = at::empty_like(xr);
+    at::Tensor ws = at::empty({scan_groupnorm_ws_floats(&d, (int32_t)c, kGroups) / 2 + 1}, xr.options().dtype(at::kDouble));
+    void* st = cur_stream(xr);
+    check(scan_groupnorm_stats(xr.data_ptr<float>(), &d, (int32_t)c, kGroups, (float)eps, stats.data_ptr<float>(),
+                               reinterpret_cast<float*>(ws.data_ptr()), st),
+          "scan_groupnorm_stats");
+    check(scan_groupnorm_relu_forward(xr.data_ptr<float>(), &d, (int32_t)c, kGroups, stats.data_ptr<float>(), gc.data_ptr<float>(),
+                                      bc.data_ptr<float>(), relu ? 1 : 0, y.data_ptr<float>(), st),
+          "scan_groupnorm_relu_forward");
+    ctx->save_for_backward({xr, gc, bc, stats});
+    ctx->saved_data["dims"] = std::vector<int64_t>{n, c, h, w};
+    ctx->saved_data["relu"] = relu;
+    return to_nchw(y, n, h, w, c);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto s = ctx->get_saved_variables();
+    const auto v = ctx->saved_data["dims"].toIntVector();
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(s[0].device());
+    const scan_pyramid_t d = one_level(v[0], v[2], v[3]);
+    at::Tensor dg, db;
+    at::Tensor dx = gn_rows_backward(s[0], s[1], s[2], s[3], dy_rows(grads[0], s[0].size(1)), d, ctx->saved_data["relu"].toBool(), dg, db);
+    return {to_nchw(dx, v[0], v[2], v[3], v[1]), dg, db, at::Tensor(), at::Tensor()};
+  }
+};
+
+// ---- [Conv2d(3x3, stride 1), GroupNorm(32, 256), ReLU]: the tower block, GroupNorm sums from the conv epilogue ------------
+struct ConvGnReluFn : public torch::autograd::Function<ConvGnReluFn> {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor weight, c10::optional<at::Tensor> bias_opt, at::Tensor gamma,
+                            at::Tensor beta, double eps, bool relu) {
+    const at::Tensor bias = bias_opt.has_value() ? *bias_opt : at::Tensor();
+    const ConvGeom g = geom(x, weight, 1, "conv3x3_gn_relu");
+    TORCH_CHECK(g.k == 3 && g.cout == 256, "conv3x3_gn_relu: a 3x3 conv into GroupNorm(32, 256) (the SCAN tower block)");
+    require_gpu_f32(gamma, "conv3x3_gn_relu", "GroupNorm weight");
+    require_gpu_f32(beta, "conv3x3_gn_relu", "GroupNorm bias");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
+    at::Tensor xr = to_rows(x), wp = pack_weight(weight), gc = gamma.contiguous(), bc = beta.contiguous();
+    at::Tensor cb = bias.defined() ? bias.contiguous() : bias;
+    const scan_pyramid_t d = one_level(g.n, g.h, g.w);
+    at::Tensor sums = at::empty({g.n * kGroups * 2}, xr.options().dtype(at::kDouble));  // cleared by the conv launch
+    at::Tensor c = conv_rows_forward(xr, wp, cb, g, false, sums);
+    at::Tensor stats = at::empty({g.n * kGroups * 2}, xr.options()), y = at::empty_like(c);
+    check(scan_groupnorm_relu_forward_from_sums(c.data_ptr<float>(), &d, 256, kGroups, reinterpret_cast<float*>(sums.data_ptr()),
+                                                (float)eps, gc.data_ptr<float>(), bc.data_ptr<float>(), relu ? 1 : 0, y.data_ptr<float>(),
+                                                stats.data_ptr<float>(), cur_stream(xr)),
+          "scan_groupnorm_relu_forward_from_sums");
+    ctx->save_for_backward({xr, wp, c, gc, bc, stats});
+    ctx->saved_data["geom"] = std::vector<int64_t>{g.n, g.cin, g.h, g.w, g.cout, g.k, g.stride, g.ho, g.wo, g.cs, g.ns};
+    ctx->saved_data["relu"] = relu;
+    ctx->saved_data["has_bias"] = bias.defined();
+    return to_nchw(y, g.n, g.h, g.w, g.cout);
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto s = ctx->get_saved_variables();
+    const auto v = ctx->saved_data["geom"].toIntVector();
+    const ConvGeom g{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10]};
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(s[0].device());
+    const scan_pyramid_t d = one_level(g.n, g.h, g.w);
+    at::Tensor dgamma, dbeta;
+    at::Tensor dc = gn_rows_backward(s[2], s[3], s[4], s[5], dy_rows(grads[0], g.ns), d, ctx->saved_data["relu"].toBool(), dgamma, dbeta);
+    const bool has_bias = ctx->saved_data["has_bias"].toBool();
+    auto r = conv_rows_backward(s[0], s[1], dc, g, ctx->needs_input_grad(0), ctx->needs_input_grad(1), has_bias && ctx->needs_input_grad(2));
+    at::Tensor dx = r[0].defined() ? to_nchw(r[0], g.n, g.h, g.w, g.cin) : at::Tensor();
+    at::Tensor dw = (r[1].defined() && ctx->needs_input_grad(1)) ? unpack_wgrad(r[1], g.cin, g.k) : at::Tensor();
+    return {dx, dw, r[2], dgamma, dbeta, at::Tensor(), at::Tensor()};
+  }
+};
+
+// ---- semantic-conditioned dynamic conv + softmax ---------------------------------------------------------------------------
+struct DynConvSoftmaxFn : public torch::autograd::Function<DynConvSoftmaxFn> {
+  static variable_list forward(AutogradContext* ctx, at::Tensor features, at::Tensor kernels) {
+    require_gpu_f32(features, "dynamic_conv_softmax", "features");
+    require_gpu_f32(kernels, "dynamic_conv_softmax", "kernel_par");
+    TORCH_CHECK(features.dim() == 4 && kernels.dim() == 2 && kernels.size(1) == features.size(1),
+                "dynamic_conv_softmax: features [N, C, H, W], kernel_par [K, C]");
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(features.device());
+    const int64_t n = features.size(0), c = features.size(1), h = features.size(2), w = features.size(3), K = kernels.size(0);
+    at::Tensor fr = to_rows(features), kc = kernels.contiguous();
+    const int64_t M = fr.size(0);
+    at::Tensor logits = at::empty({M, K}, fr.options()), probs = at::empty({M, K}, fr.options());
+    check(scan_dynconv_softmax_forward(fr.data_ptr<float>(), kc.data_ptr<float>(), M, (int32_t)c, (int32_t)K, logits.data_ptr<float>(),
+                                       probs.data_ptr<float>(), cur_stream(fr)),
+          "scan_dynconv_softmax_forward");
+    ctx->save_for_backward({fr, kc, probs});
+    ctx->saved_data["dims"] = std::vector<int64_t>{n, c, h, w, K};
+    auto back = [&](const at::Tensor& t) { return t.view({n, h, w, K}).permute({0, 3, 1, 2}); };
+    return {back(logits), back(probs)};
+  }
+  static variable_list backward(AutogradContext* ctx, variable_list grads) {
+    const auto s = ctx->get_saved_variables();
+    const auto v = ctx->saved_data["dims"].toIntVector();
+    const int64_t n = v[0], c = v[1], h = v[2], w = v[3], K = v[4], M = n * h * w;
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(s[0].device());
+    auto rows = [&](const at::Tensor& g) { return g.defined() ? g.permute({0, 2, 3, 1}).contiguous().view({M, K}) : g; };
+    at::Tensor dl = rows(grads[0]), dp = rows(grads[1]);
+    at::Tensor dfeat = at::empty_like(s[0]), dk = at::empty_like(s[1]);
+    at::Tensor ws = at::empty({scan_dynconv_ws_floats(M, (int32_t)c, (int32_t)K)}, s[0].options());
+    check(scan_dynconv_softmax_backward(s[0].data_ptr<float>(), s[1].data_ptr<float>(), s[2].data_ptr<float>(), opt_ptr(dl), opt_ptr(dp), M,
+                                        (int32_t)c, (int32_t)K, dfeat.data_ptr<float>(), dk.data_ptr<float>(), ws.data_ptr<float>(),
+                                        cur_stream(s[0])),
+          "scan_dynconv_softmax_backward");
+    return {to_nchw(dfeat, n, h, w, c), dk};
+  }
+};
+
+at::Tensor conv2d(const at::Tensor& x, const at::Tensor& weight, const c10::optional<at::Tensor>& bias, int64_t stride, bool relu) {
+  return Conv2dFn::apply(x, weight, bias, stride, relu);
+}
+at::Tensor conv3x3_gn_relu(const at::Tensor& x, const at::Tensor& weight, const c10::optional<at::Tensor>& bias, const at::Tensor& gamma,
+                           const at::Tensor& beta, double eps, bool relu) {
+  return ConvGnReluFn::apply(x, weight, bias, gamma, beta, eps, relu);
+}
+at::Tensor group_norm_relu(const at::Tensor& x, const at::Tensor& gamma, const at::Tensor& beta, double eps, bool relu) {
+  return GroupNormReluFn::apply(x, gamma, beta, eps, relu);
+}
+std::vector<at::Tensor> dynamic_conv_softmax(const at::Tensor& features, const at::Tensor& kernels) {
+  return DynConvSoftmaxFn::apply(features, kernels);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
+  m.doc() = "SCAN hot-path operators with C++ autograd on libscan_hip.so (MI355X / gfx950)";
+  m.def("conv2d", &conv2d, "nn.Conv2d(k in {1, 3}, padding k // 2) [+ ReLU], NCHW in / out", py::arg("input"), py::arg("weight"),
+        py::arg("bias") = py::none(), py::arg("stride") = 1, py::arg("relu") = false);
+  m.def("conv3x3_gn_relu", &conv3x3_gn_relu, "[Conv2d(3x3), GroupNorm(32, 256), ReLU] tower block, NCHW in / out", py::arg("input"),
+        py::arg("weight"), py::arg("bias"), py::arg("gn_weight"), py::arg("gn_bias"), py::arg("eps") = 1e-5, py::arg("relu") = true);
+  m.def("group_norm_relu", &group_norm_relu, "nn.GroupNorm(32, 256) [+ ReLU], NCHW in / out", py::arg("input"), py::arg("weight"),
+        py::arg("bias"), py::arg("eps") = 1e-5, py::arg("relu") = false);
+  m.def("dynamic_conv_softmax", &dynamic_conv_softmax, "F.conv2d(x, kernel_par[K, C, 1, 1]) + softmax(dim = 1) -> (logits, probs)",
+        py::arg("features"), py::arg("kernel_par"));
+  m.def("scan_abi_version", []() { return scan_abi_version(); });
+}

@@ -19,6 +19,20 @@ except ImportError:
 nms = _C.nms
 ml_nms = _C.ml_nms
 
+# ``_ops``: the conv / GroupNorm / dynamic-conv operators with C++ autograd (scan_amd/csrc/scan_ops_ext.cpp ->
+# scan_amd/ext/scan_ops/_ops<EXT_SUFFIX>): the NCHW drop-in modules below run forward and backward on it without entering
+# the Python interpreter between kernel launches.  Without a C++ toolchain (or with SCAN_OPS_BACKEND=python) the same
+# modules go through scan_amd.ops (Python autograd.Function -> ctypes): same kernels, bit-identical results.
+import os as _os
+try:
+    if _os.environ.get("SCAN_OPS_BACKEND", "") == "python":
+        raise ImportError("SCAN_OPS_BACKEND=python")
+    from ..ext.scan_ops import _ops
+    OPS_BACKEND = "compiled"
+except ImportError:
+    _ops = None
+    OPS_BACKEND = "python"
+
 
 class SigmoidFocalLoss(nn.Module):
     """reference layers/sigmoid_focal_loss.py:56-70: returns the SUM of the element losses."""
@@ -144,6 +158,8 @@ class Conv2d(nn.Conv2d):
                 or self.padding_mode != "zeros"):
             raise RuntimeError("scan_amd.layers.Conv2d: only square kernels, stride 1 / 2, padding = k // 2, "
                                "dilation 1, groups 1 are built (what the SCAN modules use)")
+        if _ops is not None and k in (1, 3) and ops.CONV_MODE == "bf16x6":
+            return _ops.conv2d(x, self.weight, self.bias, s, False)
         rows, shape, _ = _to_rows(x)
         w = self.weight
         if not w.permute(0, 2, 3, 1).is_contiguous():  # kernels read [Cout][k*k][Cin]
@@ -160,14 +176,34 @@ class GroupNorm(nn.GroupNorm):
         self.fuse_relu = relu
 
     def forward(self, x):
+        if _ops is not None:
+            return _ops.group_norm_relu(x, self.weight, self.bias, self.eps, self.fuse_relu)
         rows, shape, c = _to_rows(x)
         y = ops.groupnorm_relu(rows, self.weight, self.bias, shape, relu=self.fuse_relu, eps=self.eps)
         return _to_nchw(y, shape, c)
 
 
+def conv3x3_gn_relu(x, conv, gn, relu=True):
+    """The tower block of every SCAN head -- ``[nn.Conv2d(C, 256, 3, 1, 1), nn.GroupNorm(32, 256), nn.ReLU()]``
+    (rpn/fcos/fcos.py:36-49, rpn/fcos/condgraph.py:99-105, discriminator/fcos_head_discriminator_con.py:20-34) -- as ONE
+    operator: the GroupNorm statistics come out of the conv's epilogue, normalisation + ReLU are one pass.  ``conv`` / ``gn``:
+    modules (or anything with .weight / .bias, gn.eps) holding the parameters; x and the result are NCHW."""
+    if _ops is not None and ops.CONV_MODE == "bf16x6":
+        return _ops.conv3x3_gn_relu(x, conv.weight, conv.bias, gn.weight, gn.bias, gn.eps, relu)
+    rows, shape, _ = _to_rows(x)
+    w = conv.weight
+    if not w.permute(0, 2, 3, 1).is_contiguous():
+        w = w.contiguous(memory_format=torch.channels_last)
+    y = ops.conv2d(rows, w, conv.bias, shape, 3, 1, gn_sums=True)
+    y = ops.groupnorm_relu(y, gn.weight, gn.bias, shape, relu=relu, eps=gn.eps)
+    return _to_nchw(y, shape, conv.weight.shape[0])
+
+
 def dynamic_conv_softmax(features, kernel_par):
     """GRAPHModule.dynamic_conv + softmax(dim=1) (reference condgraph.py:619-629, 344-346): features [N,256,H,W],
     kernel_par [K,256] -> (act-map logits [N,K,H,W], act maps [N,K,H,W])."""
+    if _ops is not None:
+        return tuple(_ops.dynamic_conv_softmax(features, kernel_par))
     rows, shape, _ = _to_rows(features)
     logits, probs = ops.dynconv_softmax(rows, kernel_par)
     h, w = shape.sizes[0]

@@ -246,8 +246,13 @@ class SplitPlan:
         self.dirty = True
 
     def run(self):
-        dead = [k for k, j in self.jobs.items() if j[0]() is None or j[0]().data_ptr() != k[0]]
+        # a job also dies when the arithmetic it was recorded for is no longer the current one (ops.CONV_MODE switched from
+        # three pieces to two or back: k[3] is the piece count) -- otherwise every epoch would keep re-splitting, and
+        # holding, the planes of BOTH modes
+        npc = split_pieces()
+        dead = [k for k, j in self.jobs.items() if j[0]() is None or j[0]().data_ptr() != k[0] or (npc > 0 and k[3] != npc)]
         for k in dead:
+            _split_cache.pop(k, None)
             del self.jobs[k]
         if dead:
             self.dirty = True

@@ -20,7 +20,7 @@ ALL_MODES = ("fp32", "bf16x6", "bf16x3")
 # sampled gradient elements of the mid-size / cfg1 / cfg2 / cfg5 fixtures, fp32 and bf16x6 modes: |mine - ref| <= SAMPLED_BAR x
 # (|ref| + mean |grad|).  Round 4 held 5e-2; the bar is what bf16x6 measures on those fixtures + 50 % (the printed
 # "worst sampled element" lines)
-SAMPLED_BAR = 5e-2
+SAMPLED_BAR = 2e-2  # measured worst: bf16x6 1.26e-2 (step_cfg2, dis_P6_CON/dis_tower.3.bias), fp32-MFMA 1.27e-2 (step_mid)
 
 
 def _digest(g):
@@ -150,7 +150,7 @@ def test_step_gradients_match_reference(step_result):
 # rows; ONE of those rows has a pre-activation within fp32 rounding of zero in the reference's own run, and the six-product
 # summation order of the split kernels puts its ReLU decision on the other side (1 row of 128 moves the digest by ~1.5e-3
 # against a 1e-3 bar).  Named here instead of allowing "any one discriminator digest"; the exact fp32 mode has no allowance.
-KNOWN_RELU_FLIP = set()
+KNOWN_RELU_FLIP = {("dis_P5_CON", "classifier_cls_6.0.bias")}  # measured 1.51e-3 (bar 1e-3), 4x8-pixel level: 64 rows
 
 
 def test_prototype_and_kernels_match_reference(step_result, gold_dir):
@@ -332,24 +332,43 @@ def test_trajectory_matches_reference(device, gold_dir, conv_mode):
     assert trainer.groups["middle_head"].skipped == ["cond_2.weight", "cond_2.bias"]
 
 
+def yaml_traj_bounds(gold, factor=3.0):
+    """per iteration: (bound on the worst relative loss error, the yardstick it came from).  bound = factor x the largest
+    drift any yardstick run of the fixture shows at that iteration, floor LOSS_RTOL"""
+    def worst(run, it):
+        return max(abs(run[it][k] - v) / abs(v) for k, v in gold["losses_reference"][it].items() if v != 0.0)
+    out = []
+    for it in range(gold["iters"]):
+        y = max((worst(gold["variants"][n], it), n) for n in gold["yardsticks"])
+        out.append((max(LOSS_RTOL, factor * y[0]), y[1]))
+    return out, worst
+
+
 @pytest.mark.parametrize("conv_mode", ["fp32", "bf16x6"])
 @pytest.mark.parametrize("fixture", ["traj_yaml_128x256", "traj_yaml_full_lr_128x256"])
 def test_trajectory_at_yaml_solver_values_is_drift_bounded(device, gold_dir, fixture, conv_mode):
     """Training pinned at the hyper-parameters the reference actually trains with (engine/trainer.py:266-424,
     solver/build.py:7-43): 5 DA iterations with the yaml's SOLVER section untouched (``traj_yaml``: BASE_LR 0.0025 behind the
-    constant 1/3 warm-up of the first 1000 iterations) and past the warm-up (``traj_yaml_full_lr``: the full 0.0025 / 0.005).
-    At these rates the dynamics amplify rounding differences -- the fixture holds, per iteration, the losses of the imported
-    reference AND of its CPU restatement (same fp32 operations in another summation order), which part by 2e-7 -> 4e-4 / 8e-4
-    over the five iterations -- so the bar is relative to that: |gpu - reference| <= 3 x |restatement - reference| per loss and
-    iteration, with a floor of 1e-4 (the north-star tolerance) -- i.e. this implementation may drift from the reference no
-    faster than the reference's own arithmetic re-ordered does.  Both fp32 arithmetics (exact fp32-MFMA, bf16x6)."""
+    constant 1/3 warm-up of the first 1000 iterations) and past the warm-up (``traj_yaml_full_lr``: the full 0.0025).
+    At these rates the dynamics are chaotic at rounding level and event-driven (oracle/make_golden.py gen_traj_yaml): the
+    fixture holds, per iteration, the reference's losses and those of four yardstick runs -- the reference's own arithmetic
+    re-ordered (its CPU restatement; 1e-7 noise on every convolution, two seeds; frames perturbed by one ulp) -- which part
+    from the reference by 2e-7 -> 2e-3 over the five iterations.  Bar, per iteration: the worst relative loss error of the
+    GPU run <= 3 x the largest yardstick drift of that iteration (floor 1e-4): this implementation may drift from the
+    reference no faster than the reference's own arithmetic re-ordered does.  (Per iteration, not per loss: WHICH loss a
+    chaotic trajectory moves first differs from run to run.)  The same bar rejects both negative controls of the fixture
+    (BIAS_LR_FACTOR 1 instead of 2; momentum 0.8 instead of 0.9), so a mis-set optimizer cannot hide inside it.  Both fp32
+    arithmetics (exact fp32-MFMA, bf16x6).  Measured: fp32-MFMA 0.4-1.7x, bf16x6 0.3-1.2x the yardstick."""
     from scan_amd import config, engine, ops, synth
     gold = json.load(open(os.path.join(gold_dir, fixture + ".json")))
     H, W, N, K = gold["H"], gold["W"], gold["N"], gold["num_classes"]
     opts = [tuple(x) if isinstance(x, list) else x for x in gold["opts"]]
     settings = config.settings(config.load("c2f", opts))
+    bounds, worst = yaml_traj_bounds(gold)
+    for ctl in gold["negative_controls"]:  # the bar has teeth
+        assert any(worst(gold["variants"][ctl], it) > bounds[it][0] for it in range(gold["iters"])), ctl
     ops.CONV_MODE = conv_mode
-    rows, bad = [], []
+    rows = []
     try:
         model = engine.build_model(device=device, attn_dropout=0.0, settings=settings)
         engine.load_procedural_weights(model)
@@ -359,24 +378,21 @@ def test_trajectory_at_yaml_solver_values_is_drift_bounded(device, gold_dir, fix
                 assert abs(trainer.lr_of(k) - lw) <= 1e-9 * lw and abs(trainer.lr_of(k, bias=True) - lb) <= 1e-9 * lb
             imgs_s, tg, imgs_t = synth.traj_batch(it, H, W, N, K)
             losses = trainer.step(imgs_s.to(device), tg, imgs_t.to(device))
-            ref, rst = gold["losses_reference"][it], gold["losses_restatement"][it]
-            worst_g, worst_r = (0.0, ""), (0.0, "")
-            for k, r in ref.items():
+            w = (0.0, "")
+            for k, r in gold["losses_reference"][it].items():
                 v = float(losses[k])
                 if r == 0.0:
                     assert v == 0.0, (it, k, v)
-                    continue
-                eg, er = abs(v - r) / abs(r), abs(rst[k] - r) / abs(r)
-                worst_g, worst_r = max(worst_g, (eg, k)), max(worst_r, (er, k))
-                if eg > max(LOSS_RTOL, 3.0 * er):
-                    bad.append((it, k, eg, er))
-            rows.append((it, gold["lr"][it]["backbone"][0], worst_g[0], worst_g[1], worst_r[0], worst_r[1]))
+                else:
+                    w = max(w, (abs(v - r) / abs(r), k))
+            rows.append((it, gold["lr"][it]["backbone"][0], w[0], w[1], bounds[it][0], bounds[it][1]))
         torch.cuda.synchronize()
     finally:
         ops.CONV_MODE = DEFAULT_MODE
-    print("%s %s: iteration, backbone lr, worst |gpu - ref| (loss), worst |restatement - ref| (loss)" % (fixture, conv_mode))
+    print("%s %s: iteration, backbone lr, worst |gpu - ref| (loss), bound (3 x this yardstick, floor 1e-4)" % (fixture, conv_mode))
     for r in rows:
-        print("   it %d  lr %.6f  gpu %.2e %-22s restatement %.2e %s" % r)
+        print("   it %d  lr %.6f  gpu %.2e %-22s bound %.2e %s" % r)
+    bad = [r for r in rows if r[2] > r[4]]
     assert not bad, (fixture, conv_mode, bad)
 
 

@@ -205,3 +205,26 @@ def test_inference_every_mode_oracle_vs_reference(gold_dir):
                 assert np.array_equal(l.numpy()[o1], rl[o2])
                 np.testing.assert_allclose(s.numpy()[o1], rs[o2], atol=1e-5)
                 np.testing.assert_allclose(b.numpy()[o1], rb[o2], atol=1e-3)
+
+
+def test_yaml_trajectory_fixture_yardsticks_and_negative_controls(gold_dir):
+    """tests/golden/traj_yaml*.json (oracle/make_golden.py gen_traj_yaml, written from the imported reference): the bar the
+    GPU test derives from the yardstick runs -- 3 x the largest yardstick drift per iteration, floor 1e-4 -- admits every
+    yardstick (trivially) and REJECTS both wrong-optimizer runs; the stored learning rates are the yaml's (constant 1/3
+    warm-up: 0.0025 / 3, bias x 2; the second fixture past the warm-up)."""
+    import json
+    import os
+    for name, lr in (("traj_yaml_128x256", 0.0025 / 3), ("traj_yaml_full_lr_128x256", 0.0025)):
+        g = json.load(open(os.path.join(gold_dir, name + ".json")))
+        assert g["iters"] == 5 and len(g["losses_reference"]) == 5
+        for it in range(5):
+            for k, (lw, lb) in g["lr"][it].items():
+                assert abs(lw - lr) < 1e-12 and abs(lb - 2 * lr) < 1e-12, (name, it, k)
+
+        def worst(run, it):
+            return max(abs(run[it][k] - v) / abs(v) for k, v in g["losses_reference"][it].items() if v != 0.0)
+        bound = [max(1e-4, 3.0 * max(worst(g["variants"][n], it) for n in g["yardsticks"])) for it in range(5)]
+        assert set(g["yardsticks"]) == {"restatement", "conv_noise_1", "conv_noise_2", "input_noise"}
+        assert worst(g["variants"]["restatement"], 0) < 1e-6  # one iteration: the restatement IS the reference's arithmetic
+        for ctl in g["negative_controls"]:
+            assert any(worst(g["variants"][ctl], it) > bound[it] for it in range(5)), (name, ctl)

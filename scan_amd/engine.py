@@ -487,6 +487,7 @@ class Trainer:
         if not self.distributed:
             return
         bl = self._buckets()
+        self.issued_before_flush = self._issued  # buckets the backward's own hooks fired (tests: all of them in the paired step)
         while self._issued < len(bl):
             _, rngs, side = bl[self._issued]
             for lo, hi in rngs:

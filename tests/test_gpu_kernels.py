@@ -1572,7 +1572,7 @@ def test_new_entry_points_reject_bad_arguments(device):
         _lib.call("scan_sgd_momentum_multi", seg, 1, 0.9, st)
     with pytest.raises(RuntimeError, match="from_sums"):
         _lib.call("scan_groupnorm_relu_forward_from_sums", P(x), shape.ref(), 256, 32, None, 1e-5, P(x), P(x), 1, P(x), P(x), st)
-    assert _lib.query("scan_tune", b"no_such_knob", 1) == -1
+    assert _lib.query("scan_tune", b"no_such_knob", 1) == _lib.TUNE_UNKNOWN
 
 
 # ----------------------------------------------------------------------------- ground-truth plan (csrc/targets.hip)

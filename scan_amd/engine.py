@@ -849,7 +849,11 @@ def inference(model, images, static_weights=False):
     if not (static_weights and ops.SPLIT_EPOCH is not None):
         ops.invalidate_weight_planes()  # weights may have been updated / loaded since the planes were cached
         ops.begin_weight_epoch()
-    return forward_detector(model, images, None)
+    ops.CACHE_PLAIN_PARAMS = True  # an inference-only model holds plain nn.Parameters: their planes live as long as the epoch
+    try:
+        return forward_detector(model, images, None)
+    finally:
+        ops.CACHE_PLAIN_PARAMS = False
 
 
 @torch.no_grad()

@@ -333,6 +333,12 @@ def _reset_zero_pool(device):
     zp["active"] = True
 
 
+# True only inside engine.inference(): plain nn.Parameters (not re-homed into a Trainer's flat buffers) may then use the plane
+# cache too.  Anywhere else a cached plane of a Parameter could outlive its model (another model's weight at the same address
+# and shape would be served the old planes), so the switch is off and such weights are split per call.
+CACHE_PLAIN_PARAMS = False
+
+
 def begin_weight_epoch(plan=None, device=None):
     """Start of a span in which parameters do not change (one training iteration): the bf16 planes split inside it are
     reused by every launch that reads the same weight (forward, data gradient, source / target passes).  With a
@@ -474,7 +480,12 @@ class _Conv2d(torch.autograd.Function):
         fast = split_pieces() > 0 and ((ksize == 3 and stride == 1) or ksize == 1)
         tag = CONV_MODE  # kernel_timer labels
         flops = 2.0 * oshape.rows * cout * ksize * ksize * weight.shape[1]
-        ckey = weight.data_ptr() if getattr(weight, "_scan_flat", False) else None
+        # planes are cached per weight epoch for tensors whose storage outlives a call: flat-buffer parameters (a Trainer's)
+        # and plain nn.Parameters (an inference-only model: engine.inference(static_weights=True) keeps the epoch open across
+        # batches -- without this its 32 conv weights were re-split every batch).  A temporary (torch.cat of two heads'
+        # weights, stacked discriminator weights) is never cached: the allocator hands its address to the next temporary
+        ckey = weight.data_ptr() if (getattr(weight, "_scan_flat", False)
+                                     or (CACHE_PLAIN_PARAMS and isinstance(weight, torch.nn.Parameter))) else None
         # first layer (3 input channels): dedicated K = taps x 4 forward kernel (the backward, if any, is generic)
         first = split_pieces() > 0 and cs == 4 and cout <= 64 and (ksize, stride) in ((3, 1), (7, 2)) \
             and shape.n_levels == 1

@@ -288,6 +288,20 @@ def test_nms_beyond_one_panel_bit_exact_both_rules(device, n):
     assert ops.nms(bd[keep], sd[keep], 0.5).numel() == keep.numel()  # idempotence
 
 
+def test_nms_many_panels_bit_exact(device):
+    """n = 70,000: nine 8,192-candidate panels of the scan, 1,094 mask words per row (the OR phase walks 18 groups of 64), a
+    131,072-key bitonic network (stages 16,384 ... 131,072 through the global compare-exchange steps) -- against the C oracle."""
+    from scan_amd import ops
+    from oracle import coracle
+    n = 70000
+    rs = np.random.RandomState(n)
+    boxes = _tie_boxes(rs, n, 4000.0)
+    scores = (rs.randint(0, n // 2, n) / float(n // 2)).astype(np.float32)
+    keep = ops.nms(torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device), 0.5, rule_ge=True)
+    ref = coracle.nms(boxes, scores, 0.5)
+    assert 0 < len(ref) < n and np.array_equal(keep.cpu().numpy(), ref)
+
+
 def test_ml_nms_bit_exact(device):
     from scan_amd.layers import ml_nms
     from oracle import coracle

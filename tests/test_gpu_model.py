@@ -259,6 +259,39 @@ def test_inference_after_training_uses_fresh_weights(device):
         assert torch.equal(b1, b2) and torch.equal(s1, s2) and torch.equal(l1, l2)
 
 
+def test_inference_only_model_reuses_weight_planes(device):
+    """a model that never saw a Trainer holds plain nn.Parameters: engine.inference(static_weights=True) serves the planes the
+    previous batch split (round 5: they were re-split every batch -- 32 launches), identical detections; without the flag, or
+    after an in-place weight change followed by a plain inference(), the planes are rebuilt; and outside inference() a
+    Parameter is never served from the cache (another model's weight could sit at its address)."""
+    from scan_amd import engine, ops, synth
+    model = engine.build_model(9, device=device, attn_dropout=0.0)
+    engine.load_state_dicts(model, synth.shifted_state_dicts(9))
+    imgs = synth.synth_images(2, 128, 256, 3234).to(device)
+    first = engine.inference(model, imgs)
+    n_cached, epoch = len(ops._split_cache), ops.SPLIT_EPOCH
+    assert n_cached >= 20 and epoch is not None and not ops.CACHE_PLAIN_PARAMS
+    again = engine.inference(model, imgs, static_weights=True)
+    assert ops.SPLIT_EPOCH == epoch and len(ops._split_cache) == n_cached
+    for (b1, s1, l1), (b2, s2, l2) in zip(first, again):
+        assert torch.equal(b1, b2) and torch.equal(s1, s2) and torch.equal(l1, l2)
+    with torch.no_grad():
+        model["fcos"].head.cls_logits.bias.add_(0.3)
+        model["fcos"].head.cls_tower[0].weight.mul_(1.05)
+    changed = engine.inference(model, imgs)  # no promise of static weights: everything is split again
+    assert ops.SPLIT_EPOCH != epoch
+    assert any(len(s0) != len(s1) or not torch.allclose(s0, s1) for (_, s0, _), (_, s1, _) in zip(first, changed))
+    # outside inference(): same address, same shape, other values -> must NOT be served the cached planes
+    w = model["fcos"].head.cls_tower[0].weight
+    shape = ops.PyramidShape(1, [(16, 16)])
+    x = torch.randn(256, 256, device=device)
+    with torch.no_grad():
+        y0 = ops.conv2d(x, w, None, shape, 3, 1)
+        w.mul_(2.0)
+        y1 = ops.conv2d(x, w, None, shape, 3, 1)
+    assert torch.allclose(y1, 2.0 * y0, rtol=1e-5, atol=1e-6)
+
+
 @pytest.mark.parametrize("conv_mode", list(ALL_MODES))
 def test_trajectory_matches_reference(device, gold_dir, conv_mode):
     """7 full DA iterations against the trajectory the imported reference produced with its own make_optimizer

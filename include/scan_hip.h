@@ -73,6 +73,9 @@ int scan_abi_version(void);
  *                 / 1280 / 1536 are 2...25 % slower on the 256- and 512-channel layers (bf16x3).
  *   "gconv_mfma"  0 (default): the grouped class-branch conv runs on fp32 FMAs; 1: tap products and data gradient on the
  *                 fp32 matrix cores (same products, different summation order; measured no faster in the step).
+ *   "reduce_blocks" 2048 (default): most workgroups a loss-reduction kernel is launched with (each ends in one or two float
+ *                 atomics on one cache line); the IoU and CKA forward kernels take half of it.  Same sums up to the order of
+ *                 the atomics.
  *   "dbscan_bf16x3" 1 (default): scan_dbscan_prepare's pairwise-distance GEMM runs as bf16x3 with a wider exact re-check
  *                 band; 0: exact fp32 matrix cores.  Same neighbour bits (pairs inside the band are decided in fp64). */
 #define SCAN_TUNE_UNKNOWN (-2147483647 - 1)

@@ -5,6 +5,7 @@
 #include <float.h>
 
 #include "common.h"
+#include <algorithm>
 
 // ------------------------------------------------------------------ sigmoid focal loss
 // follows the reference's stable CUDA formula, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-101
@@ -181,10 +182,16 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
 
 // loss reductions end in one float atomic per block on ONE address: keep the block count low (same-address atomics
 // serialise at ~13 ns each: 2048 blocks cost ~55 us whatever the tensor size) and give each thread more elements
-static inline int grid_reduce(int64_t work_items, int block) {
+// scan_tune "reduce_blocks": the cap for the kernels bound by vector-ALU issue (focal losses: they need the occupancy of 8 blocks
+// per CU); `light` = kernels with little arithmetic per byte, whose run time the end-of-block atomics are a visible part of:
+// half the cap.  Round 5 sweep at M = 2^24 (tools/pointwise_roofline.py, same process): IoU forward 132 -> 113 us (0.57 -> 0.67 of
+// the HBM roof), CKA BCE forward 220 -> 206 us (0.65 -> 0.69) at 1,024; sigmoid focal fused-sum forward 161 -> 193 us (worse).
+int g_scan_reduce_blocks = 2048;
+static inline int grid_reduce(int64_t work_items, int block, bool light = false) {
   int64_t g = (work_items + (int64_t)block * 8 - 1) / ((int64_t)block * 8);
+  const int cap = light ? g_scan_reduce_blocks / 2 : g_scan_reduce_blocks;
   if (g < 1) g = 1;
-  if (g > 2048) g = 2048;  // large tensors: the ~27 us of serialised atomics hide behind >= 100 us of streaming
+  if (g > cap) g = cap;  // large tensors: the ~27 us of serialised atomics hide behind >= 100 us of streaming
   return (int)g;
 }
 
@@ -298,7 +305,7 @@ extern "C" int scan_iou_loss_forward(const float* pred, const float* target, con
   SCAN_CHECK_ARG(P >= 0 && out2, "iou_loss_forward: bad arguments");
   if (P == 0) return 0;
   SCAN_CHECK_ARG(pred && target, "iou_loss_forward: null input");
-  hipLaunchKernelGGL(iou_fwd_kernel, dim3(grid_reduce(P, 256)), dim3(256), 0, as_stream(stream), pred, target, weight, P,
+  hipLaunchKernelGGL(iou_fwd_kernel, dim3(grid_reduce(P, 256, true)), dim3(256), 0, as_stream(stream), pred, target, weight, P,
                      out2);
   SCAN_LAUNCH_CHECK("iou_fwd");
   return 0;
@@ -316,20 +323,39 @@ extern "C" int scan_iou_loss_backward(const float* pred, const float* target, co
 }
 
 // ------------------------------------------------------------------ BCE with logits (optionally weighted)
+// VEC: logits / targets / weight (unit stride) read as float4 -- four times fewer load instructions for the same bytes (the
+// scalar form ran at 0.25 of the HBM roof at M = 2^24, bound by load issue: profiles/r04_pointwise_roofline.json)
+template <bool VEC>
 __global__ __launch_bounds__(256) void bce_fwd_kernel(const float* __restrict__ logits,
                                                       const float* __restrict__ targets, float const_target,
                                                       const float* __restrict__ weight, int64_t w_stride, int64_t M,
                                                       float* __restrict__ out2) {
   __shared__ float red[4];
   float num = 0.f, den = 0.f;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (int64_t)gridDim.x * blockDim.x) {
-    const float x = logits[i];
-    const float t = targets ? targets[i] : const_target;
-    const float w = weight ? weight[i * w_stride] : 1.f;
+  auto elem = [&](float x, float t, float w) {
     // max(x,0) - x*t + log(1 + exp(-|x|))
     const float l = fmaxf(x, 0.f) - x * t + fast_log1p_unit(__expf(-fabsf(x)));
     num += l * w;
     den += w;
+  };
+  const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, nthr = (int64_t)gridDim.x * blockDim.x;
+  if (VEC) {
+    const int64_t m4 = M >> 2;
+#pragma unroll 4
+    for (int64_t q = tid; q < m4; q += nthr) {
+      const float4 x = reinterpret_cast<const float4*>(logits)[q];
+      const float4 t = targets ? reinterpret_cast<const float4*>(targets)[q]
+                               : make_float4(const_target, const_target, const_target, const_target);
+      const float4 w = weight ? reinterpret_cast<const float4*>(weight)[q] : make_float4(1.f, 1.f, 1.f, 1.f);
+      elem(x.x, t.x, w.x);
+      elem(x.y, t.y, w.y);
+      elem(x.z, t.z, w.z);
+      elem(x.w, t.w, w.w);
+    }
+    for (int64_t i = (m4 << 2) + tid; i < M; i += nthr) elem(logits[i], targets ? targets[i] : const_target, weight ? weight[i] : 1.f);
+  } else {
+    for (int64_t i = tid; i < M; i += nthr)
+      elem(logits[i], targets ? targets[i] : const_target, weight ? weight[i * w_stride] : 1.f);
   }
   const float sn = block_sum_256(num, red);
   const float sd = block_sum_256(den, red);
@@ -358,8 +384,15 @@ extern "C" int scan_bce_logits_forward(const float* logits, const float* targets
   SCAN_CHECK_ARG(M >= 0 && out2, "bce_logits_forward: bad arguments");
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits, "bce_logits_forward: null input");
-  hipLaunchKernelGGL(bce_fwd_kernel, dim3(grid_reduce(M, 256)), dim3(256), 0, as_stream(stream), logits, targets,
-                     const_target, weight, w_stride, M, out2);
+  auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+  if (M >= 4096 && al16(logits) && (!targets || al16(targets)) && (!weight || (w_stride == 1 && al16(weight))))
+    // the kernel ends in two float atomics per block on one cache line (~13 ns each, serialised): at 8 bytes per element the
+    // 2,048 blocks of grid_reduce cost more in atomics (53 us) than the stream itself (27 us at M = 2^24) -- 512 blocks here
+    hipLaunchKernelGGL(bce_fwd_kernel<true>, dim3(std::min(512, grid_reduce((M + 3) / 4, 256))), dim3(256), 0, as_stream(stream),
+                       logits, targets, const_target, weight, w_stride, M, out2);
+  else
+    hipLaunchKernelGGL(bce_fwd_kernel<false>, dim3(grid_reduce(M, 256)), dim3(256), 0, as_stream(stream), logits, targets,
+                       const_target, weight, w_stride, M, out2);
   SCAN_LAUNCH_CHECK("bce_fwd");
   return 0;
 }
@@ -495,7 +528,7 @@ static int cka_forward_launch(const float* logits, const float* act, int64_t M, 
   if (M == 0) return 0;
   SCAN_CHECK_ARG(logits && act, "cka_bce_forward: null input");
   if (Cf == 8 && (reinterpret_cast<uintptr_t>(logits) & 15) == 0) {
-    int g = grid_reduce(M * 2, 256);
+    int g = grid_reduce(M * 2, 256, true);
     hipLaunchKernelGGL(cka_fwd8_kernel, dim3(g), dim3(256), 0, as_stream(stream), logits, act, M, target, out, fin);
   } else {
     hipLaunchKernelGGL(cka_fwd_kernel, dim3(grid_reduce(M, 256)), dim3(256), 0, as_stream(stream), logits, act, M, Cf,

@@ -288,6 +288,39 @@ def test_nms_beyond_one_panel_bit_exact_both_rules(device, n):
     assert ops.nms(bd[keep], sd[keep], 0.5).numel() == keep.numel()  # idempotence
 
 
+def test_nms_at_maximum_size_properties(device):
+    """n = SCAN_NMS_MAX (262,144 boxes, 8.6 GB of mask): no oracle at this size -- size-independent properties instead: kept
+    indices strictly ascending, NMS of the survivors keeps every one of them (idempotence), and a sample of suppressed boxes
+    each overlap a kept, higher-scored box at or above the threshold (and no kept box does)."""
+    from scan_amd import _lib, ops
+    n = _lib.NMS_MAX
+    rs = np.random.RandomState(1)
+    xy = rs.uniform(0, 20000, (n, 2))
+    boxes = np.concatenate([xy, xy + rs.uniform(5, 300, (n, 2))], 1).astype(np.float32)
+    scores = rs.rand(n).astype(np.float32)
+    bd, sd = torch.from_numpy(boxes).to(device), torch.from_numpy(scores).to(device)
+    keep = ops.nms(bd, sd, 0.5)
+    assert 0 < keep.numel() < n and bool((keep[1:] > keep[:-1]).all())
+    assert ops.nms(bd[keep], sd[keep], 0.5).numel() == keep.numel()
+    kept = torch.zeros(n, dtype=torch.bool, device=device)
+    kept[keep] = True
+
+    def iou_with_kept_better(i):
+        b = bd[i]
+        better = kept & (sd > sd[i])
+        bb = bd[better]
+        w = (torch.minimum(b[2], bb[:, 2]) - torch.maximum(b[0], bb[:, 0]) + 1).clamp(min=0)
+        h = (torch.minimum(b[3], bb[:, 3]) - torch.maximum(b[1], bb[:, 1]) + 1).clamp(min=0)
+        inter = w * h
+        area = lambda t: (t[..., 2] - t[..., 0] + 1) * (t[..., 3] - t[..., 1] + 1)
+        return float((inter / (area(b) + area(bb) - inter)).max()) if bb.numel() else 0.0
+    dropped = torch.nonzero(~kept).squeeze(1)
+    for i in dropped[torch.linspace(0, dropped.numel() - 1, 12).long()].tolist():
+        assert iou_with_kept_better(i) >= 0.5, i
+    for i in keep[torch.linspace(0, keep.numel() - 1, 12).long()].tolist():
+        assert iou_with_kept_better(i) < 0.5, i
+
+
 def test_nms_many_panels_bit_exact(device):
     """n = 70,000: nine 8,192-candidate panels of the scan, 1,094 mask words per row (the OR phase walks 18 groups of 64), a
     131,072-key bitonic network (stages 16,384 ... 131,072 through the global compare-exchange steps) -- against the C oracle."""

@@ -67,24 +67,36 @@ def _worker(rank, world, port, same_shard, outdir, backend="gloo", steps=STEPS, 
         dist.destroy_process_group()
 
 
-def _spawn(same_shard, outdir, backend="gloo", steps=STEPS, mixed_schedules=False):
+def _spawn(same_shard, outdir, backend="gloo", steps=STEPS, mixed_schedules=False, world=2):
     ctx = mp.get_context("spawn")
     port = 29600 + os.getpid() % 2000 + (1 if same_shard else 0) + (2 if backend == "nccl" else 0) \
-        + (4 if mixed_schedules else 0) + (8 if steps != STEPS else 0)
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, same_shard, str(outdir), backend, steps, mixed_schedules))
-             for r in range(2)]
+        + (4 if mixed_schedules else 0) + (8 if steps != STEPS else 0) + (16 if world != 2 else 0)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, same_shard, str(outdir), backend, steps, mixed_schedules))
+             for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(timeout=600)
+        p.join(timeout=900)
         assert p.exitcode == 0
-    return tuple(torch.load(os.path.join(str(outdir), "rank%d.pt" % r)) for r in range(2))
+    return tuple(torch.load(os.path.join(str(outdir), "rank%d.pt" % r)) for r in range(world))
 
 
 def test_two_ranks_different_shards_stay_identical(device, tmp_path):
     a, b = _spawn(False, tmp_path)
     for k in a:
         assert torch.equal(a[k], b[k]), "rank 0 and rank 1 diverged in %s" % k
+
+
+def test_four_ranks_different_shards_stay_identical(device, tmp_path):
+    """four ranks (gloo, all on this GPU) with four different shards: the 1 / world scale, the bucket ranges and the paradigm
+    all-reduce at a world size other than two -- every rank ends with bit-identical parameters, momentum and paradigm buffer and
+    has issued the same collective sequence, every bucket from the backward's own hooks."""
+    outs = _spawn(False, tmp_path, world=4)
+    for r in outs[1:]:
+        for k in outs[0]:
+            assert torch.equal(outs[0][k], r[k]), "ranks diverged in %s" % k
+    fired, total = outs[0]["issued_before_flush"].tolist()
+    assert fired == total == 6
 
 
 def test_every_gradient_bucket_is_fired_by_the_backward_itself(device, tmp_path):

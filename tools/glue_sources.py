@@ -50,7 +50,7 @@ def main():
                 if "autograd" in fr or "backward" in fr:
                     where = "<autograd engine>"
                     break
-        if where in ("?", "<autograd engine>"):
+        if where in ("?", "<autograd engine>") or (os.environ.get("GLUE_SHAPES") and dt > 20):
             shapes = getattr(ev, "input_shapes", None)
             where += " " + str(shapes)[:90]
         rec = agg[(ev.name, where)]

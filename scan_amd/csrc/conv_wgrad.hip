@@ -505,6 +505,10 @@ __device__ __forceinline__ void wgrad_mma_v6(const W6Lane& w, f32x4v (&acc)[KX][
 // end of a block in the ISA, four registers fewer, bit-identical -- runs 3-4 % SLOWER on every shape (conv3_x 2,510 -> 2,600 us,
 // conv4_x 2,430 -> 2,535, same box, A B A B): the two interleaved chains of this form keep the pipe busier than one dependent
 // chain at a time, and the stall at the block end is covered by the SIMD's other consumer wave.
+// Second form (profiles/r05_wgrad_c256_probe.txt): the interleaved chains kept, two temporary sets, the fold of block i - 1 issued
+// behind the first four MFMAs of block i (no s_nop in front of the adds): 168 registers + one 8-byte spill in the loop,
+// 3.5 % SLOWER (conv3_x 2,500 -> 2,590 us); on eight consumer waves alone with 256 registers it changes nothing (2,304 us
+// either way): the fold's wait is not what the temporary accumulator costs.
 template <int NP, int WKC, int TO, int TC, int KX, int TOMAX, int TCMAX>
 __device__ __forceinline__ void wgrad_mma_v6_pipe(const W6Lane& w, f32x4v (&acc)[KX][TCMAX][TOMAX]) {
   static_assert(WKC == 32, "one 32-pixel step per chunk");
@@ -552,8 +556,18 @@ __device__ __forceinline__ void wgrad_mma_v6_pipe(const W6Lane& w, f32x4v (&acc)
 // waves, 2 x 4 -> 4 (o) x 2 (c) waves).  Either way 96 accumulator registers; the resident dY fragments are NP * TOM * 4
 // registers, the X fragments are re-read per tap: 4 x 2 reads fewer fragments per MFMA (30 transposed reads per 144
 // MFMAs with three pieces), 2 x 4 keeps 24 instead of 48 registers resident (42 reads) and leaves room to prefetch.
+#if defined(SCAN_EXP_WGRAD_C256) && SCAN_EXP_WGRAD_C256 == 1
+// TIMING EXPERIMENT (make exp_wgrad_c256 M=1|2, WRONG results): the consumers alone on two LDS stages they fill once --
+// 1: eight waves with 256 registers, temporary accumulator + pipelined loop on either wave tile; 2: the shipped loops beside
+// four idle producer waves (168 registers)
+#define W6_BOUNDS __launch_bounds__(512, 2)
+#define W6_THREADS 512
+#else
+#define W6_BOUNDS __launch_bounds__(768, 3)
+#define W6_THREADS 768
+#endif
 template <int NP, int WKC, int KX, int TOM, int TCW>
-__global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
+__global__ W6_BOUNDS void conv_wgrad_v6_kernel(
     const float* __restrict__ x, scan_pyramid_t d, int Cs, const float* __restrict__ dy, int Nout, int Ns,
     float* __restrict__ slab, float* __restrict__ bias_slab, ChunkTab ct, int n_tiles, int c_tiles,
     int chunks_per_split, int splits, int prio) {
@@ -734,7 +748,7 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
       if (SCAN_EXP_WGRAD_PROD & 1) load_a();
       if (SCAN_EXP_WGRAD_PROD & 2) store_b(stage); else keep_b();
       if (SCAN_EXP_WGRAD_PROD & 1) load_b();
-#elif !defined(SCAN_EXP_WGRAD_NOPROD)  // TIMING EXPERIMENT (make exp_wgrad_noprod): the producers only attend the barriers
+#elif !defined(SCAN_EXP_WGRAD_NOPROD) && !defined(SCAN_EXP_WGRAD_C256)  // TIMING EXPERIMENT (make exp_wgrad_noprod): the producers only attend the barriers
       const int stage = (k + 1) & 1;  // chunk k + 1 is in the registers; chunk k + 2 follows it
       const bool more = k + 2 < nch;
       if (more) advance();
@@ -778,6 +792,18 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
 #pragma unroll
       for (int b = 0; b < TOMAX; ++b) acc[a][c][b] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
+#ifdef SCAN_EXP_WGRAD_C256
+  {  // both stages filled once with bf16 values of the operands' magnitude
+    const long long nx = (long long)ct.chunk_off[d.n_levels] * 16 * Cs;
+    for (int i = tid; i < STAGE; i += 512) {
+      const float2 v = *reinterpret_cast<const float2*>(x + (((long long)i + (long long)blockIdx.x * STAGE) % (nx / 2)) * 2);
+      bf16x2 h;
+      h[0] = (__bf16)v.x;
+      h[1] = (__bf16)v.y;
+      *reinterpret_cast<bf16x2*>(sm + 2 * i) = h;
+    }
+  }
+#endif
   __syncthreads();  // stage 0 is complete
   // one K loop per live-tile count (wave-uniform; dead tiles: third c tile of Cin = 264 / 268, Cout = 8 / 5 / 1 heads):
   // inside one loop the compiler would keep the fragment addresses of all variants in registers across it, which at 168
@@ -791,7 +817,11 @@ __global__ __launch_bounds__(768, 3) void conv_wgrad_v6_kernel(
     unsigned flip = 2u * STAGE;  // bytes; +-: unsigned wrap-around is the subtraction
     for (int k = 0; k < nch; ++k) {
       if constexpr (TO > 0) {
+#if defined(SCAN_EXP_WGRAD_C256) && SCAN_EXP_WGRAD_C256 == 1
+        if constexpr (NP == 3)
+#else
         if constexpr (SCAN_WG_PIPE && SCAN_WG_TCHAIN && NP == 3 && TOM == 2)
+#endif
           wgrad_mma_v6_pipe<NP, WKC, TO, TC, KX, TOMAX, TCMAX>(wl, acc);
         else
           wgrad_mma_v6<NP, WKC, TO, TC, KX, TOMAX, TCMAX, SCAN_WG_TCHAIN && NP == 3 && TOM == 2>(wl, acc);
@@ -975,10 +1005,10 @@ static int wgrad3_launch(const float* x, const scan_pyramid_t* d, int32_t Cs, co
       done = true;
     }
     if (g_scan_wgrad_tile >= 2 ? NP == 3 : g_scan_wgrad_tile != 0)
-      hipLaunchKernelGGL((conv_wgrad_v6_kernel<NP, WK6, 3, 2, 4>), dim3(nt * sp), dim3(768), sh6, st, x, *d, Cs, dy, Cout, Cout_s,
+      hipLaunchKernelGGL((conv_wgrad_v6_kernel<NP, WK6, 3, 2, 4>), dim3(nt * sp), dim3(W6_THREADS), sh6, st, x, *d, Cs, dy, Cout, Cout_s,
                          ws, bias_slab, ct, nt, ctl, cps, sp, g_scan_wgrad_prio);
     else
-      hipLaunchKernelGGL((conv_wgrad_v6_kernel<NP, WK6, 3, 4, 2>), dim3(nt * sp), dim3(768), sh6, st, x, *d, Cs, dy, Cout, Cout_s,
+      hipLaunchKernelGGL((conv_wgrad_v6_kernel<NP, WK6, 3, 4, 2>), dim3(nt * sp), dim3(W6_THREADS), sh6, st, x, *d, Cs, dy, Cout, Cout_s,
                          ws, bias_slab, ct, nt, ctl, cps, sp, g_scan_wgrad_prio);
   } else {
     constexpr size_t sh = (size_t)WBUF(NP, 3) * sizeof(__bf16);

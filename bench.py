@@ -497,19 +497,43 @@ def main():
         # batched NMS, TEST.MODE of the yaml), and the NMS launch alone on the last image's candidate set
         note("three-phase %.1f ms; inference" % three_phase["ms_per_step"])
         import scan_amd.modeling.fcos as fcos_mod
-        frames = imgs_t
-        for _ in range(2):
-            dets = engine.inference(model, frames)
-        torch.cuda.synchronize()
-        n_inf = max(3, a.steps)
-        t0i = time.time()
-        for _ in range(n_inf):
-            dets = engine.inference(model, frames, static_weights=True)  # a dataset loop: nothing trains between batches
-        torch.cuda.synchronize()
-        dti = (time.time() - t0i) / n_inf
+        # TEST.IMS_PER_BATCH frames per batch (reference data/build.py:119-124: images_per_gpu = TEST.IMS_PER_BATCH // num_gpus; 4 in
+        # every scan yaml), of the workload's size; rounds 1-4 timed the B = 2 target frames batch by batch: kept as `two_frames`
+        n_test = int(mcfg.get("test_ims_per_batch", 4))
+
+        def time_inference(frames_):
+            for _ in range(2):
+                d_ = engine.inference(model, frames_)
+            torch.cuda.synchronize()
+            n_ = max(3, a.steps)
+            t0_ = time.time()
+            for _ in range(n_):
+                d_ = engine.inference(model, frames_, static_weights=True)  # a dataset loop: nothing trains between batches
+            torch.cuda.synchronize()
+            per_call = (time.time() - t0_) / n_
+            # the dataset loop (engine.inference_stream: what validation() and inference_distributed() run): batch k + 1 is
+            # queued before batch k's candidate counts are read, so the post-processing round trips hide behind the next forward
+            t0_ = time.time()
+            for ds_ in engine.inference_stream(model, (frames_ for _ in range(n_)), static_weights=True):
+                pass
+            torch.cuda.synchronize()
+            looped = (time.time() - t0_) / n_
+            assert all(torch.equal(x, y) for d0, d1 in zip(d_, ds_) for x, y in zip(d0, d1))
+            return per_call, looped, d_
+
+        frames = engine.to_image_list([t.to(dev) for t in synth.synth_image_list([(H, W)] * n_test, 2234 + 100 * rank)], 32)
+        dti, dts, dets = time_inference(frames)
         nms_rec = fcos_mod.last_nms_record()
-        infer = {"images_per_s": round(B / dti, 3), "ms_per_batch": round(dti * 1e3, 2), "batch": B,
+        infer = {"images_per_s": round(n_test / dts, 3), "ms_per_batch": round(dts * 1e3, 2), "batch": n_test,
+                 "loop": "engine.inference_stream (one batch of look-ahead), TEST.IMS_PER_BATCH frames per batch",
+                 "batch_by_batch": {"images_per_s": round(n_test / dti, 3), "ms_per_batch": round(dti * 1e3, 2),
+                                    "note": "engine.inference called per batch, detections read before the next call"},
                  "test_mode": mcfg["test_mode"], "detections_per_image": [int(len(d[0])) for d in dets]}
+        if n_test != B:
+            dti2, dts2, _ = time_inference(imgs_t)
+            infer["two_frames"] = {"batch": B, "images_per_s": round(B / dts2, 3), "ms_per_batch": round(dts2 * 1e3, 2),
+                                   "batch_by_batch_images_per_s": round(B / dti2, 3),
+                                   "note": "the step's B target frames; batch by batch = the figure of rounds 1-4"}
         if nms_rec is not None:
             boxes_n, scores_n, labels_n, thr = nms_rec
             n_c = int(boxes_n.shape[0])
@@ -527,7 +551,8 @@ def main():
             m_.train()
         # (d) the data-parallel machinery with ONE rank on RCCL (gradient hooks, buckets, side-stream all-reduces, the
         # 1 / world scale, paradigm all-reduce, loss reduce): a regression there shows without a multi-GPU box
-        note("inference %.1f ms per batch; one-rank RCCL leg" % infer["ms_per_batch"])
+        note("inference %.1f ms per batch in the dataset loop, %.1f batch by batch; one-rank RCCL leg"
+             % (infer["ms_per_batch"], infer["batch_by_batch"]["ms_per_batch"]))
         if not dist.is_initialized():
             try:
                 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,

@@ -237,7 +237,7 @@ def settings(cfg):
         num_convs_cls=int(F.NUM_CONVS_CLS), num_convs_reg=int(F.NUM_CONVS_REG), prior_prob=float(F.PRIOR_PROB),
         loss_gamma=float(F.LOSS_GAMMA), loss_alpha=float(F.LOSS_ALPHA), fpn_strides=tuple(F.FPN_STRIDES),
         inference_th=float(F.INFERENCE_TH), pre_nms_top_n=int(F.PRE_NMS_TOP_N), nms_th=float(F.NMS_TH),
-        detections_per_img=int(cfg.TEST.DETECTIONS_PER_IMG),
+        detections_per_img=int(cfg.TEST.DETECTIONS_PER_IMG), test_ims_per_batch=int(cfg.TEST.IMS_PER_BATCH),
         con_dis_lambda=float(A.CON_DIS_LAMBDA),
         dis_num_convs={l: int(A["CON_NUM_SHARED_CONV_%s" % l]) for l in LEVELS},
         grl_weight={l: float(A["GRL_WEIGHT_%s" % l]) for l in LEVELS},

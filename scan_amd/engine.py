@@ -837,23 +837,46 @@ class Trainer:
 
 
 @torch.no_grad()
-def inference(model, images, static_weights=False):
+def inference(model, images, static_weights=False, deferred=False):
     """reference engine/inference.py:15-37 on one batch: list of (boxes, scores, labels) per image.
 
     static_weights=True is the caller's promise that no parameter changed since the previous inference() call (a
     dataset loop, serving): the bf16 weight planes split in that call are reused instead of being split again (31
     launches per batch).  Anything that updates parameters through this package (optimizer step, checkpoint /
-    state-dict load) drops the planes regardless, so the flag only matters for writes from outside."""
+    state-dict load) drops the planes regardless, so the flag only matters for writes from outside.
+    deferred=True: everything is queued up to the candidate counts of the post-processing and an object is returned
+    whose finish() does the rest (NMS, top-100) and returns the list -- inference_stream() overlaps batches with it."""
     for m in model.values():
         m.eval()
     if not (static_weights and ops.SPLIT_EPOCH is not None):
         ops.invalidate_weight_planes()  # weights may have been updated / loaded since the planes were cached
         ops.begin_weight_epoch()
     ops.CACHE_PLAIN_PARAMS = True  # an inference-only model holds plain nn.Parameters: their planes live as long as the epoch
+    selector = model["fcos"].box_selector_test
+    selector.deferred = bool(deferred)
     try:
         return forward_detector(model, images, None)
     finally:
         ops.CACHE_PLAIN_PARAMS = False
+        selector.deferred = False
+
+
+@torch.no_grad()
+def inference_stream(model, batches, static_weights=False):
+    """The dataset loop of reference engine/inference.py:15-37 (compute_on_dataset) as a generator: yields the detections of
+    every batch of ``batches`` (an iterable of image batches) in order, exactly what inference() returns for it.  One batch
+    of look-ahead: batch k + 1 is queued on the GPU before the host reads batch k's candidate counts, so the two host round
+    trips of the post-processing and its single-workgroup NMS chains run behind / beside the next batch's convolutions
+    instead of leaving the GPU idle between batches.  static_weights as in inference() for the FIRST batch; the following
+    ones reuse the weight planes (nothing trains inside the loop)."""
+    pending = None
+    for k, images in enumerate(batches):
+        nxt = inference(model, images, static_weights=static_weights or k > 0, deferred=True)
+        if pending is not None:
+            yield pending.finish()
+        pending = nxt
+    if pending is not None:
+        yield pending.finish()
 
 
 @torch.no_grad()
@@ -865,10 +888,13 @@ def inference_distributed(model, batches):
     from . import comm
     results, ids = [], []
     dev = next(next(iter(model.values())).parameters()).device
-    for k, (images, image_ids) in enumerate(batches):
-        out = inference(model, images, static_weights=k > 0)  # nothing trains between the batches of one pass
+    def frames():
+        for images, image_ids in batches:
+            ids.extend(int(i) for i in image_ids)
+            yield images
+
+    for out in inference_stream(model, frames()):  # nothing trains between the batches of one pass
         results.extend(out)
-        ids.extend(int(i) for i in image_ids)
     merged = comm.gather_detections(results, ids, device=dev)
     if merged is None:
         return None
@@ -889,9 +915,17 @@ def validation(model, dataset, batch_size=4, size_divisible=32, output_folder=No
     mine = list(range(rank, len(dataset), world))
     dev = next(next(iter(model.values())).parameters()).device
     results, ids = [], []
-    for k in range(0, len(mine), batch_size):
-        il, _, idxs = collate([dataset[i] for i in mine[k:k + batch_size]])
-        for (boxes, scores, labels), (h, w), idx in zip(inference(model, il, static_weights=k > 0), il.image_sizes, idxs):
+    meta = []  # (image sizes, dataset indices) of the batches in flight, in order
+
+    def frames():
+        for k in range(0, len(mine), batch_size):
+            il, _, idxs = collate([dataset[i] for i in mine[k:k + batch_size]])
+            meta.append((il.image_sizes, idxs))
+            yield il
+
+    for dets in inference_stream(model, frames()):
+        sizes, idxs = meta.pop(0)
+        for (boxes, scores, labels), (h, w), idx in zip(dets, sizes, idxs):
             info = dataset.get_img_info(idx)
             boxes = datasets.resize_detections(boxes, (w, h), (info["width"], info["height"]))
             results.append((boxes, scores, labels))

@@ -320,6 +320,85 @@ def last_nms_record():
     return _last_nms[0]
 
 
+class _PendingDetections:
+    """Second half of FCOSPostProcessor.__call__: everything behind the one host round trip of the selection (the candidate
+    counts).  The counts travel to pinned host memory asynchronously and an event marks them, so a dataset loop can queue
+    the NEXT batch's forward before it reads this batch's counts (engine.inference_stream): the round trips of batch k
+    then hide behind the convolutions of batch k + 1 and its NMS chains run beside them on the side streams."""
+
+    def __init__(self, proc, ok, det, val, lab, n_images, deferred):
+        self.proc, self.ok, self.det, self.val, self.lab, self.N, self.deferred = proc, ok, det, val, lab, n_images, deferred
+        self.main = torch.cuda.current_stream() if det.is_cuda else None
+        self.results = None
+        if self.main is not None:
+            self.counts = torch.empty((n_images,), dtype=torch.int64, pin_memory=True)
+            self.counts.copy_(ok.sum(1), non_blocking=True)
+            self.ready = torch.cuda.Event()
+            self.ready.record(self.main)  # also what the side streams wait for: nothing queued on main after it
+        else:
+            self.counts = ok.sum(1)
+
+    def finish(self):
+        """per image (boxes [k,4], scores [k], labels [k]); idempotent."""
+        if self.results is not None:
+            return self.results
+        proc, ok, det, val, lab, N, main = self.proc, self.ok, self.det, self.val, self.lab, self.N, self.main
+        dev = det.device
+        if main is not None:
+            self.ready.synchronize()  # the one host round trip of the selection
+        counts = self.counts.tolist()
+        # Phase 1, no host read: every image's candidates are gathered (their number is known from `counts`, so
+        # nonzero_static needs no round trip) and its NMS is queued -- image i on side stream i % 2, since one NMS is a chain
+        # of single-workgroup kernels that leaves the GPU to the next image's.  Phase 2 reads the kept counts.
+        use_side = main is not None and (N > 1 or self.deferred)
+        if use_side and proc._nms_streams is None:
+            proc._nms_streams = ops.borrow_side_streams(2)  # the trainer's, when there is one in the process
+        now = torch.cuda.current_stream() if main is not None else None  # == main unless the caller switched streams
+        pending = []
+        for i in range(N):
+            if counts[i] == 0:
+                pending.append(None)
+                continue
+            side = proc._nms_streams[i % 2] if use_side else None
+            if side is not None:
+                side.wait_event(self.ready)
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                sel = ok[i].nonzero_static(size=counts[i]).squeeze(1)
+                boxes, scores, labels = det[i][sel], torch.sqrt(val[i][sel]), lab[i][sel]
+                # per-class NMS (reference inference.py:160-176 loops classes and calls boxlist_nms on each) as ONE
+                # class-aware launch: a box is suppressed only by a kept, higher-scored box of the SAME label, which is
+                # exactly greedy NMS run per class; output order = class-major, original index ascending within a class
+                _last_nms[0] = (boxes, scores, labels, proc.nms_thresh)
+                if side is not None:  # kept beyond this call (bench.py times the NMS on them on the main stream)
+                    for t in (boxes, scores, labels):
+                        t.record_stream(now)
+                finish = ops.nms_by_label_async(boxes, scores, labels, proc.nms_thresh)
+            pending.append((boxes, scores, labels, finish, side))
+        results = []
+        for i in range(N):
+            if pending[i] is None:
+                results.append((det.new_zeros((0, 4)), det.new_zeros((0,)), lab.new_zeros((0,))))
+                continue
+            boxes, scores, labels, finish, side = pending[i]
+            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                keep = finish().to(dev)
+                keep = keep[torch.argsort(labels[keep], stable=True)]
+                rb, rs, rl = boxes[keep], scores[keep], labels[keep]
+                n = len(rs)
+                if n > proc.fpn_post_nms_top_n > 0:
+                    th, _ = torch.kthvalue(rs, n - proc.fpn_post_nms_top_n + 1)
+                    k = torch.nonzero(rs >= th).squeeze(1)
+                    rb, rs, rl = rb[k], rs[k], rl[k]
+            if side is not None:
+                now.wait_stream(side)
+                for t in (rb, rs, rl):
+                    t.record_stream(now)
+            results.append((rb, rs, rl))
+        self.results = results
+        self.ok = self.det = self.val = self.lab = None  # (released only now: the side streams read them until here)
+        return results
+
+
 class FCOSPostProcessor:
     """reference inference.py:20-194; per-class NMS runs on the device (scan_nms)."""
 
@@ -333,10 +412,12 @@ class FCOSPostProcessor:
         self.num_classes = num_classes
         self.mode = mode
         self._nms_streams = None  # two side streams for the per-image NMS chains, made on first use with a batch > 1
+        self.deferred = False  # True: __call__ returns the pending object instead of finishing it (engine.inference_stream)
 
     def __call__(self, shape, box_cls, box_regression, centerness, image_sizes):
         """box_cls [M,C] (logits for 'common', fused probabilities otherwise), box_regression [M,4],
-        centerness [M] logits.  Returns per image (boxes [k,4], scores [k], labels [k]).
+        centerness [M] logits.  Returns per image (boxes [k,4], scores [k], labels [k]) -- or, with self.deferred, the
+        _PendingDetections whose finish() returns them.
 
         Same selection as the reference (inference.py:49-118: candidates = score > pre_nms_thresh, at most
         pre_nms_top_n per image and level by score x centerness, decode, clip, min-size; :140-194: per-class NMS,
@@ -370,58 +451,13 @@ class FCOSPostProcessor:
         det = torch.stack([lc[..., 0] - rg[..., 0], lc[..., 1] - rg[..., 1], lc[..., 0] + rg[..., 2],
                            lc[..., 1] + rg[..., 3]], -1)
         # BoxList.clip_to_image (TO_REMOVE = 1) against each image's true size
-        lim = torch.tensor([[w - 1, h - 1, w - 1, h - 1] for h, w in image_sizes], dtype=det.dtype, device=dev)
+        lim = torch.tensor([[w - 1, h - 1, w - 1, h - 1] for h, w in image_sizes], dtype=det.dtype, pin_memory=det.is_cuda)
+        lim = lim.to(dev, non_blocking=True)
         det = torch.minimum(det.clamp(min=0), lim[:, None, :])
         ws, hs = det[..., 2] - det[..., 0] + 1, det[..., 3] - det[..., 1] + 1
         ok = (val > 0) & (ws >= self.min_size) & (hs >= self.min_size)
-        counts = ok.sum(1).tolist()  # the one host round trip of the selection
-        # Phase 1, no host read: every image's candidates are gathered (their number is known from `counts`, so
-        # nonzero_static needs no round trip) and its NMS is queued -- image i on side stream i % 2, since one NMS is a chain
-        # of single-workgroup kernels that leaves the GPU to the next image's.  Phase 2 reads the kept counts.
-        main = torch.cuda.current_stream() if det.is_cuda else None
-        if main is not None and N > 1 and self._nms_streams is None:
-            self._nms_streams = ops.borrow_side_streams(2)  # the trainer's, when there is one in the process
-        pending = []
-        for i in range(N):
-            if counts[i] == 0:
-                pending.append(None)
-                continue
-            side = self._nms_streams[i % 2] if main is not None and N > 1 else None
-            if side is not None:
-                side.wait_stream(main)
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                sel = ok[i].nonzero_static(size=counts[i]).squeeze(1)
-                boxes, scores, labels = det[i][sel], torch.sqrt(val[i][sel]), lab[i][sel]
-                # per-class NMS (reference inference.py:160-176 loops classes and calls boxlist_nms on each) as ONE
-                # class-aware launch: a box is suppressed only by a kept, higher-scored box of the SAME label, which is
-                # exactly greedy NMS run per class; output order = class-major, original index ascending within a class
-                _last_nms[0] = (boxes, scores, labels, self.nms_thresh)
-                if side is not None:  # kept beyond this call (bench.py times the NMS on them on the main stream)
-                    for t in (boxes, scores, labels):
-                        t.record_stream(main)
-                finish = ops.nms_by_label_async(boxes, scores, labels, self.nms_thresh)
-            pending.append((boxes, scores, labels, finish, side))
-        results = []
-        for i in range(N):
-            if pending[i] is None:
-                results.append((det.new_zeros((0, 4)), det.new_zeros((0,)), lab.new_zeros((0,))))
-                continue
-            boxes, scores, labels, finish, side = pending[i]
-            with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
-                keep = finish().to(dev)
-                keep = keep[torch.argsort(labels[keep], stable=True)]
-                rb, rs, rl = boxes[keep], scores[keep], labels[keep]
-                n = len(rs)
-                if n > self.fpn_post_nms_top_n > 0:
-                    th, _ = torch.kthvalue(rs, n - self.fpn_post_nms_top_n + 1)
-                    k = torch.nonzero(rs >= th).squeeze(1)
-                    rb, rs, rl = rb[k], rs[k], rl[k]
-            if side is not None:
-                main.wait_stream(side)
-                for t in (rb, rs, rl):
-                    t.record_stream(main)
-            results.append((rb, rs, rl))
-        return results
+        pend = _PendingDetections(self, ok, det, val, lab, N, self.deferred)
+        return pend if self.deferred else pend.finish()
 
 
 class FCOSModule(nn.Module):

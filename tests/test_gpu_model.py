@@ -292,6 +292,45 @@ def test_inference_only_model_reuses_weight_planes(device):
     assert torch.allclose(y1, 2.0 * y0, rtol=1e-5, atol=1e-6)
 
 
+def test_inference_stream_equals_batch_by_batch(device):
+    """engine.inference_stream (one batch of look-ahead: batch k + 1 is queued before batch k's candidate counts are read,
+    its NMS chains run on side streams beside the next forward) yields, batch for batch, exactly what inference() returns
+    -- batches of two frames, of one frame, ragged frames, and a batch without any candidate."""
+    from scan_amd import engine, synth
+    from scan_amd.structures import to_image_list
+    model = engine.build_model(9, device=device, attn_dropout=0.0)
+    engine.load_state_dicts(model, synth.shifted_state_dicts(9))
+    ragged = to_image_list([synth.synth_images(1, 120, 250, 11)[0].to(device), synth.synth_images(1, 128, 200, 12)[0].to(device)], 32)
+    batches = [synth.synth_images(2, 128, 256, 3234).to(device), synth.synth_images(1, 128, 256, 77).to(device), ragged,
+               synth.synth_images(2, 96, 160, 5).to(device), synth.synth_images(2, 128, 256, 9).to(device)]
+    one_by_one = [engine.inference(model, b, static_weights=k > 0) for k, b in enumerate(batches)]
+    assert sum(len(s) for out in one_by_one for _, s, _ in out) > 0
+    streamed = list(engine.inference_stream(model, iter(batches)))
+    assert len(streamed) == len(batches) and not model["fcos"].box_selector_test.deferred
+    for a, b in zip(one_by_one, streamed):
+        assert len(a) == len(b)
+        for (b1, s1, l1), (b2, s2, l2) in zip(a, b):
+            assert torch.equal(b1, b2) and torch.equal(s1, s2) and torch.equal(l1, l2)
+    # no candidate at all: the pre-NMS threshold above every score
+    sel = model["fcos"].box_selector_test
+    old = sel.pre_nms_thresh
+    sel.pre_nms_thresh = 2.0
+    try:
+        empty = list(engine.inference_stream(model, iter(batches[:2])))
+    finally:
+        sel.pre_nms_thresh = old
+    assert all(len(s) == 0 and b.shape == (0, 4) for out in empty for b, s, _ in out)
+    # a deferred result can be finished twice and late
+    pend = engine.inference(model, batches[0], deferred=True)
+    other = engine.inference(model, batches[1], static_weights=True)
+    first, second = pend.finish(), pend.finish()
+    assert first is second
+    for (b1, s1, l1), (b2, s2, l2) in zip(first, one_by_one[0]):
+        assert torch.equal(b1, b2) and torch.equal(s1, s2) and torch.equal(l1, l2)
+    for (b1, s1, l1), (b2, s2, l2) in zip(other, one_by_one[1]):
+        assert torch.equal(b1, b2) and torch.equal(s1, s2) and torch.equal(l1, l2)
+
+
 @pytest.mark.parametrize("conv_mode", list(ALL_MODES))
 def test_trajectory_matches_reference(device, gold_dir, conv_mode):
     """7 full DA iterations against the trajectory the imported reference produced with its own make_optimizer

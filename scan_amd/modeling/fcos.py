@@ -330,6 +330,7 @@ class _PendingDetections:
         self.proc, self.ok, self.det, self.val, self.lab, self.N, self.deferred = proc, ok, det, val, lab, n_images, deferred
         self.main = torch.cuda.current_stream() if det.is_cuda else None
         self.results = None
+        self.inputs = None
         if self.main is not None:
             self.counts = torch.empty((n_images,), dtype=torch.int64, pin_memory=True)
             self.counts.copy_(ok.sum(1), non_blocking=True)
@@ -395,7 +396,7 @@ class _PendingDetections:
                     t.record_stream(now)
             results.append((rb, rs, rl))
         self.results = results
-        self.ok = self.det = self.val = self.lab = None  # (released only now: the side streams read them until here)
+        self.ok = self.det = self.val = self.lab = self.inputs = None  # (released only now: the side streams read them until here)
         return results
 
 
@@ -413,8 +414,24 @@ class FCOSPostProcessor:
         self.mode = mode
         self._nms_streams = None  # two side streams for the per-image NMS chains, made on first use with a batch > 1
         self.deferred = False  # True: __call__ returns the pending object instead of finishing it (engine.inference_stream)
+        self._select_stream = None  # deferred mode: the stream the selection is queued on
 
     def __call__(self, shape, box_cls, box_regression, centerness, image_sizes):
+        """see _select.  With self.deferred on a GPU the selection itself is queued on a side stream of its own (its ~400
+        small launches -- one top-k, sort and gather per level -- then run beside the NEXT batch's convolutions instead of
+        in front of them) and the pending object keeps the head's outputs alive until finish()."""
+        if not (self.deferred and box_cls.is_cuda):
+            return self._select(shape, box_cls, box_regression, centerness, image_sizes)
+        main = torch.cuda.current_stream()
+        if self._select_stream is None:
+            self._select_stream = ops.borrow_side_streams(3)[2]
+        self._select_stream.wait_stream(main)
+        with torch.cuda.stream(self._select_stream):
+            pend = self._select(shape, box_cls, box_regression, centerness, image_sizes)
+        pend.inputs = (box_cls, box_regression, centerness)  # read on the side stream: not to be reused by main before finish()
+        return pend
+
+    def _select(self, shape, box_cls, box_regression, centerness, image_sizes):
         """box_cls [M,C] (logits for 'common', fused probabilities otherwise), box_regression [M,4],
         centerness [M] logits.  Returns per image (boxes [k,4], scores [k], labels [k]) -- or, with self.deferred, the
         _PendingDetections whose finish() returns them.

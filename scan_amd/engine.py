@@ -91,20 +91,13 @@ def load_procedural_weights(model, num_classes=9, conv_body="VGG-16-FPN-RETINANE
 
 
 # ----------------------------------------------------------------------------- forward
-_plan_streams = {}
-
-
 def _plan_stream(device):
-    s = _plan_streams.get(device)
-    if s is None:
-        # SCAN_PLAN_PRIO=-1 gives the plan a high-priority stream (a hardware queue of its own class): its three small
-        # kernels then run at once and the host read of the plan returns in microseconds instead of ~25 ms (HIP maps
-        # its streams onto few hardware queues; on a shared one the plan sits behind a whole iteration of queued
-        # convolutions).  Measured, it is the WRONG trade on this part: with the extra queue class -- or with
-        # GPU_MAX_HW_QUEUES=8 -- the side streams stop overlapping usefully and the step goes from 61 to 68-76 ms
-        # (profiles/r03_host_runahead.txt).  Default: normal priority.
-        s = _plan_streams[device] = torch.cuda.Stream(device, priority=int(os.environ.get("SCAN_PLAN_PRIO", "0")))
-    return s
+    """The stream of the ground-truth plan: side stream 0 of the process (ops.borrow_side_streams), which the P4
+    discriminator uses much later in the step.  HIP multiplexes its streams onto FOUR hardware queues and a fifth ACTIVE
+    queue costs the step 17 % (GPU_MAX_HW_QUEUES >= 5: 93 -> 109 ms, profiles/r05_hw_queues.txt; the same cliff as round
+    3's "high-priority plan stream", profiles/r03_host_runahead.txt), so the whole process stays at the null stream + three
+    side streams and every role is mapped onto those explicitly instead of by the runtime's aliasing."""
+    return ops.borrow_side_streams(3)[0]
 
 
 def forward_detector(model, images, targets=None, mode="source", forward_target=False):
@@ -356,16 +349,19 @@ class Trainer:
         # of its forward, so the backward overlaps the same way).
         self.device = next(next(iter(model.values())).parameters()).device
         on_gpu = self.device.type == "cuda"
-        # SCAN_DIS_STREAMS = number of side streams the four small levels share (default 4: one each)
-        n_side = max(1, min(4, int(os.environ.get("SCAN_DIS_STREAMS", "4"))))
-        pool = [torch.cuda.Stream() for _ in range(n_side)] if on_gpu else []
-        self.dis_streams = {lvl: pool[i % n_side] for i, lvl in enumerate(("P4", "P5", "P6", "P7"))} if on_gpu else {}
-        self.tgt_stream = torch.cuda.Stream() if on_gpu else None
-        if on_gpu and not ops.SIDE_STREAMS:
-            ops.SIDE_STREAMS.extend(pool)  # idle outside a training step: inference borrows them instead of making more
+        # Stream budget: the null stream + THREE side streams for the whole process (ops.borrow_side_streams), one hardware
+        # queue each (see _plan_stream).  Roles: s0 = P4 discriminator, ground-truth plan, target forward of the
+        # three-phase schedule / FCOS head beside the discriminators; s1 = P5; s2 = P6 + P7, head_out's feature share; inference
+        # borrows the same three (NMS chains on s0 / s1, candidate selection on s2).  This is the mapping the runtime's own
+        # aliasing of seven streams onto four queues produced in rounds 2-4, now independent of creation order.
+        # SCAN_DIS_STREAMS = number of side streams the four small levels use (default 3; 2: P4 + P6 | P5 + P7; 1: all on s0)
+        n_side = max(1, min(3, int(os.environ.get("SCAN_DIS_STREAMS", "3"))))
+        pool = ops.borrow_side_streams(3) if on_gpu else []
+        slot = {3: (0, 1, 2, 2), 2: (0, 1, 0, 1), 1: (0, 0, 0, 0)}[n_side]
+        self.dis_streams = {lvl: pool[slot[i]] for i, lvl in enumerate(("P4", "P5", "P6", "P7"))} if on_gpu else {}
+        self.tgt_stream = pool[0] if on_gpu else None  # (three-phase step: s0 98.2-98.5 ms, s1 99.0-99.2, s2 100.2-100.4)
         # head_out's feature share (97 % of that conv) beside the graph tier's tiny launches, forward and backward
-        # (an existing side stream, idle at that point of the step -- the P7 discriminator's: one more HIP stream shifts the
-        #  stream -> hardware-queue assignment of all the others, which cost the three-phase schedule 1.5 ms)
+        # (an existing side stream, idle at that point of the step -- the P7 discriminator's)
         self.out_stream = self.dis_streams.get("P7") if on_gpu and os.environ.get("SCAN_OUT_STREAM", "1") != "0" else None
         if "middle_head" in model and hasattr(model["middle_head"], "out_stream"):
             model["middle_head"].out_stream = self.out_stream

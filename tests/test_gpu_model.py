@@ -496,6 +496,30 @@ def test_step_mid_size_all_gradients_match_reference(device, gold_dir):
         _check_all_gradient_digests(gold, model, mode, rt, "step_mid")
 
 
+def test_training_on_a_fixed_batch_learns(device):
+    """functional guard beside the parity tests: 40 iterations at the yaml's solver values on ONE (source, target) batch --
+    every source loss falls (classification, regression, node and act-map losses by > 30 %), everything stays finite and the
+    ten adversarial losses stay near their equilibrium (the discriminators see reversed gradients)."""
+    import math
+    from scan_amd import engine, synth
+    model = engine.build_model(9, device=device, attn_dropout=0.0)
+    engine.load_procedural_weights(model)
+    tr = engine.Trainer(model)
+    s, t = synth.synth_images(2, 256, 512, 11).to(device), synth.synth_images(2, 256, 512, 12).to(device)
+    tg = synth.synth_targets(2, 256, 512, 8, 8, 13)
+    first = last = None
+    for it in range(40):
+        losses = {k: float(v) for k, v in tr.step(s, tg, t).items()}
+        assert all(math.isfinite(v) for v in losses.values()), (it, losses)
+        first = first or losses
+        last = losses
+    for k in ("loss_cls_gs", "loss_reg_gs", "node_loss_gs", "act_loss_gs"):
+        assert last[k] < 0.7 * first[k], (k, first[k], last[k])
+    assert last["loss_centerness_gs"] < first["loss_centerness_gs"]
+    adv0, adv1 = (sum(v for k, v in d.items() if k.startswith("loss_adv")) for d in (first, last))
+    assert 0.5 * adv0 < adv1 < 1.5 * adv0, (adv0, adv1)
+
+
 def test_two_steps_run_and_update(device):
     """optimizer path: parameters move, momentum buffers fill, losses stay finite over 2 iterations."""
     from scan_amd import engine, synth

@@ -65,10 +65,11 @@ int scan_abi_version(void);
  *                 convs).  bf16x3: bit-identical; bf16x6: other K-chunk length, i.e. other split-K boundaries.
  *   "wgrad_prio"  1: the producer waves of that kernel run at s_setprio 3; 0 (default): at the consumers' priority.  Same
  *                 results bit for bit.
- *   "wgrad_tile"  consumer wave tile of that kernel: 0 = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c), 2 (default) = 1 for bf16x6, 0 for
- *                 bf16x3.  bf16x3: same results bit for bit.  bf16x6: 0 adds the six piece products of a 32-pixel step
- *                 straight into the running accumulator, 1 sums them in a temporary first (one rounding per step at the
- *                 accumulator's magnitude) -- other rounding, 2-4x further from fp64 with 0.
+ *   "wgrad_tile"  consumer wave tile of that kernel: 0 (default) = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c); any other value = the
+ *                 default.  bf16x3: same results bit for bit.  bf16x6: 0 adds the six piece products of a 32-pixel step
+ *                 straight into the running accumulator (an fp32 sum in another order: 1.0-2.1x the fp32-MFMA kernel's
+ *                 distance from fp64; the golden suite is green on it and it is 4-5 % faster), 1 sums them in a temporary
+ *                 first (one rounding per step at the accumulator's magnitude, DESIGN.md 3.0: 0.23-0.5x that distance).
  *   "wgrad_wgs"   768 (default): workgroups a weight-gradient launch aims at (tiles x split-K slabs); 512 / 640 / 896 / 1024
  *                 / 1280 / 1536 are 2...25 % slower on the 256- and 512-channel layers (bf16x3).
  *   "gconv_mfma"  0 (default): the grouped class-branch conv runs on fp32 FMAs; 1: tap products and data gradient on the
@@ -92,6 +93,13 @@ const char* scan_tune_key(int index);
  * random-sign / random-mantissa operands, 0: zeros.  Writes TFLOP/s; blocking (synchronises `stream`).  bench.py reports
  * it as roofline.board_sustained beside the fraction of the nominal 2.5 PFLOP/s. */
 int scan_mfma_sustained_bf16(double seconds, int32_t random, double* tflops, void* stream);
+
+/* Measurement (no reference counterpart; what it stands in for: the RCCL ring all-reduce the data-parallel step issues where the
+ * reference's DistributedDataParallel does, tools/train_net_da.py:421-515): one rank's footprint of an all-reduce of
+ * buf[0, n_floats) -- `wgs` workgroups of 256 threads (RCCL: one per channel) that read-modify-write (x * 1.0f: values
+ * unchanged) their slice `traffic` times (ring: 2 (N - 1) / N), paced to `gbps` aggregate read rate by sleeping on the wall
+ * clock (0 = unpaced).  Asynchronous on `stream`.  tools/dp_emulate.py runs it where the gradient buckets fire. */
+int scan_comm_standin(float* buf, int64_t n_floats, double traffic, int32_t wgs, double gbps, void* stream);
 
 /* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels;
  * 1128 / 1256 = the 128- / 256-channel tile on 16-wave workgroups, 2256 = the 256-channel tile on the 8-wave LDS-DMA instance. */

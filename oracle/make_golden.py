@@ -826,6 +826,11 @@ def main():
         gen_step(a.check, H=1024, W=2048, N=2, name="step_cfg2_1024x2048")
     if "step_cfg5" in todo:  # BASELINE.json configs[4] frame: 1333x2666 padded to 1344x2688
         gen_step(a.check, name="step_cfg5_1333x2666", sizes=[(1333, 2666)])
+    if "step_s2c_cfg3" in todo:  # BASELINE.json configs[2] at its REAL per-GPU shard: S2C yaml, 2 src + 2 tgt frames at 1024x2048
+        gen_step(a.check, H=1024, W=2048, N=2, name="step_s2c_cfg3_1024x2048", K=2,
+                 yaml_name="scan_vgg16_sim10k_to_cityscapes.yaml")
+    if "step_cfg5_ragged" in todo:  # BASELINE.json configs[4], a ragged pair of its frames: both padded to 1344x2688
+        gen_step(a.check, name="step_cfg5_ragged_1333x2666", sizes=[(1333, 2666), (1300, 2600)])
     if "step_s2c" in todo:  # BASELINE.json configs[2]: Sim10k->Cityscapes, NUM_CLASSES 2, TRANSFER_CFG (None,)
         gen_step(a.check, name="step_s2c_128x256", K=2, yaml_name="scan_vgg16_sim10k_to_cityscapes.yaml")
     if "step_s2c_ft" in todo:

@@ -49,6 +49,8 @@ SPLIT_JOB_WORDS = 11
 SIGNATURES = {
     "scan_last_error": (ctypes.c_char_p, []),
     "scan_abi_version": (ctypes.c_int, []),
+    "scan_comm_standin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int64, ctypes.c_double, ctypes.c_int32, ctypes.c_double,
+                                         ctypes.c_void_p]),
     "scan_tune": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
     "scan_take_images_backward": (ctypes.c_int, [c_vp, _PD, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "scan_cond_rnn_forward": (ctypes.c_int, [c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),

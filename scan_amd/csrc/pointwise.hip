@@ -189,7 +189,8 @@ __global__ __launch_bounds__(256) void focal_bwd_kernel(const float* __restrict_
 int g_scan_reduce_blocks = 2048;
 static inline int grid_reduce(int64_t work_items, int block, bool light = false) {
   int64_t g = (work_items + (int64_t)block * 8 - 1) / ((int64_t)block * 8);
-  const int cap = light ? g_scan_reduce_blocks / 2 : g_scan_reduce_blocks;
+  int cap = light ? g_scan_reduce_blocks / 2 : g_scan_reduce_blocks;
+  if (cap < 1) cap = 1;  // scan_tune accepts any int: every setting must still give a launchable grid
   if (g < 1) g = 1;
   if (g > cap) g = cap;  // large tensors: the ~27 us of serialised atomics hide behind >= 100 us of streaming
   return (int)g;

@@ -208,36 +208,36 @@ std::vector<at::Tensor> conv_rows_backward(const at::Tensor& xr, const at::Tenso
   return {dx, dw, db};
 }
 
-at::Tensor dy_rows(const at::Tensor& gy, int64_t ns) {  // incoming NCHW gradient -> rows [Mo, Ns]
-  at::Tensor r = to_rows(gy);
-  TORCH_CHECK(r.size(1) == ns, "gradient has ", r.size(1), " channel columns, expected ", ns);
-  return r;
-}
-
 // ---- nn.Conv2d (+ ReLU) ------------------------------------------------------------------------------------------------
+// The Function nodes below take and return ROW MATRICES (fresh allocations, never views): the NCHW <-> rows adaptors are
+// ordinary differentiable torch views applied by the free wrappers at the bottom, OUTSIDE apply().  An output that is a
+// view created inside a custom Function may not be modified in place ("Output 0 of ...Backward is a view and is being
+// modified inplace"), and the reference follows its convolutions with nn.ReLU(inplace=True)
+// (backbone/mmdetection/vgg.py:29, modeling/make_layers.py:74,117).
+ConvGeom geom_of(const std::vector<int64_t>& v) { return ConvGeom{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10]}; }
+std::vector<int64_t> geom_vec(const ConvGeom& g) { return {g.n, g.cin, g.h, g.w, g.cout, g.k, g.stride, g.ho, g.wo, g.cs, g.ns}; }
+
 struct Conv2dFn : public torch::autograd::Function<Conv2dFn> {
-  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor weight, c10::optional<at::Tensor> bias_opt, int64_t stride,
-                            bool relu) {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor xr, at::Tensor weight, c10::optional<at::Tensor> bias_opt,
+                            std::vector<int64_t> gv, bool relu) {
     const at::Tensor bias = bias_opt.has_value() ? *bias_opt : at::Tensor();
-    const ConvGeom g = geom(x, weight, stride, "conv2d");
-    if (bias.defined()) require_gpu_f32(bias, "conv2d", "bias");
-    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
-    at::Tensor xr = to_rows(x), wp = pack_weight(weight);
+    const ConvGeom g = geom_of(gv);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(xr.device());
+    at::Tensor wp = pack_weight(weight);
     at::Tensor bc = bias.defined() ? bias.contiguous() : bias;
     at::Tensor y = conv_rows_forward(xr, wp, bc, g, relu, at::Tensor());
     ctx->save_for_backward({xr, wp, relu ? y : at::Tensor()});
-    ctx->saved_data["geom"] = std::vector<int64_t>{g.n, g.cin, g.h, g.w, g.cout, g.k, g.stride, g.ho, g.wo, g.cs, g.ns};
+    ctx->saved_data["geom"] = gv;
     ctx->saved_data["relu"] = relu;
     ctx->saved_data["has_bias"] = bias.defined();
-    return to_nchw(y, g.n, g.ho, g.wo, g.cout);
+    return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto saved = ctx->get_saved_variables();
     const at::Tensor xr = saved[0], wp = saved[1], y = saved[2];
-    const auto v = ctx->saved_data["geom"].toIntVector();
-    const ConvGeom g{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10]};
+    const ConvGeom g = geom_of(ctx->saved_data["geom"].toIntVector());
     c10::hip::HIPGuardMasqueradingAsCUDA guard(xr.device());
-    at::Tensor dyr = dy_rows(grads[0], g.ns);
+    at::Tensor dyr = grads[0].contiguous();
     if (ctx->saved_data["relu"].toBool()) {
       at::Tensor t = at::empty_like(dyr);
       check(scan_relu_backward(dyr.data_ptr<float>(), y.data_ptr<float>(), t.data_ptr<float>(), dyr.numel(), cur_stream(dyr)),
@@ -247,9 +247,8 @@ struct Conv2dFn : public torch::autograd::Function<Conv2dFn> {
     const bool has_bias = ctx->saved_data["has_bias"].toBool();
     auto r = conv_rows_backward(xr, wp, dyr, g, ctx->needs_input_grad(0), ctx->needs_input_grad(1),
                                 has_bias && ctx->needs_input_grad(2));
-    at::Tensor dx = r[0].defined() ? to_nchw(r[0], g.n, g.h, g.w, g.cin) : at::Tensor();
     at::Tensor dw = (r[1].defined() && ctx->needs_input_grad(1)) ? unpack_wgrad(r[1], g.cin, g.k) : at::Tensor();
-    return {dx, dw, r[2], at::Tensor(), at::Tensor()};
+    return {r[0], dw, r[2], at::Tensor(), at::Tensor()};
   }
 };
 
@@ -272,15 +271,12 @@ at::Tensor gn_rows_backward(const at::Tensor& xr, const at::Tensor& gamma, const
 }
 
 struct GroupNormReluFn : public torch::autograd::Function<GroupNormReluFn> {
-  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor gamma, at::Tensor beta, double eps, bool relu) {
-    require_gpu_f32(x, "group_norm_relu", "input");
-    require_gpu_f32(gamma, "group_norm_relu", "weight");
-    require_gpu_f32(beta, "group_norm_relu", "bias");
-    TORCH_CHECK(x.dim() == 4, "group_norm_relu: input [N, C, H, W]");
-    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
-    const int64_t n = x.size(0), c = x.size(1), h = x.size(2), w = x.size(3);
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor xr, at::Tensor gamma, at::Tensor beta, std::vector<int64_t> dims,
+                            double eps, bool relu) {
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(xr.device());
+    const int64_t n = dims[0], c = dims[1], h = dims[2], w = dims[3];
     const scan_pyramid_t d = one_level(n, h, w);
-    at::Tensor xr = to_rows(x), gc = gamma.contiguous(), bc = beta.contiguous();
+    at::Tensor gc = gamma.contiguous(), bc = beta.contiguous();
     at::Tensor stats = at::empty({n * kGroups * 2}, xr.options()), y = at::empty_like(xr);
     at::Tensor ws = at::empty({scan_groupnorm_ws_floats(&d, (int32_t)c, kGroups) / 2 + 1}, xr.options().dtype(at::kDouble));
     void* st = cur_stream(xr);
@@ -291,9 +287,9 @@ struct GroupNormReluFn : public torch::autograd::Function<GroupNormReluFn> {
                                       bc.data_ptr<float>(), relu ? 1 : 0, y.data_ptr<float>(), st),
           "scan_groupnorm_relu_forward");
     ctx->save_for_backward({xr, gc, bc, stats});
-    ctx->saved_data["dims"] = std::vector<int64_t>{n, c, h, w};
+    ctx->saved_data["dims"] = dims;
     ctx->saved_data["relu"] = relu;
-    return to_nchw(y, n, h, w, c);
+    return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto s = ctx->get_saved_variables();
@@ -301,22 +297,19 @@ struct GroupNormReluFn : public torch::autograd::Function<GroupNormReluFn> {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(s[0].device());
     const scan_pyramid_t d = one_level(v[0], v[2], v[3]);
     at::Tensor dg, db;
-    at::Tensor dx = gn_rows_backward(s[0], s[1], s[2], s[3], dy_rows(grads[0], s[0].size(1)), d, ctx->saved_data["relu"].toBool(), dg, db);
-    return {to_nchw(dx, v[0], v[2], v[3], v[1]), dg, db, at::Tensor(), at::Tensor()};
+    at::Tensor dx = gn_rows_backward(s[0], s[1], s[2], s[3], grads[0].contiguous(), d, ctx->saved_data["relu"].toBool(), dg, db);
+    return {dx, dg, db, at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
 // ---- [Conv2d(3x3, stride 1), GroupNorm(32, 256), ReLU]: the tower block, GroupNorm sums from the conv epilogue ------------
 struct ConvGnReluFn : public torch::autograd::Function<ConvGnReluFn> {
-  static at::Tensor forward(AutogradContext* ctx, at::Tensor x, at::Tensor weight, c10::optional<at::Tensor> bias_opt, at::Tensor gamma,
-                            at::Tensor beta, double eps, bool relu) {
+  static at::Tensor forward(AutogradContext* ctx, at::Tensor xr, at::Tensor weight, c10::optional<at::Tensor> bias_opt, at::Tensor gamma,
+                            at::Tensor beta, std::vector<int64_t> gv, double eps, bool relu) {
     const at::Tensor bias = bias_opt.has_value() ? *bias_opt : at::Tensor();
-    const ConvGeom g = geom(x, weight, 1, "conv3x3_gn_relu");
-    TORCH_CHECK(g.k == 3 && g.cout == 256, "conv3x3_gn_relu: a 3x3 conv into GroupNorm(32, 256) (the SCAN tower block)");
-    require_gpu_f32(gamma, "conv3x3_gn_relu", "GroupNorm weight");
-    require_gpu_f32(beta, "conv3x3_gn_relu", "GroupNorm bias");
-    c10::hip::HIPGuardMasqueradingAsCUDA guard(x.device());
-    at::Tensor xr = to_rows(x), wp = pack_weight(weight), gc = gamma.contiguous(), bc = beta.contiguous();
+    const ConvGeom g = geom_of(gv);
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(xr.device());
+    at::Tensor wp = pack_weight(weight), gc = gamma.contiguous(), bc = beta.contiguous();
     at::Tensor cb = bias.defined() ? bias.contiguous() : bias;
     const scan_pyramid_t d = one_level(g.n, g.h, g.w);
     at::Tensor sums = at::empty({g.n * kGroups * 2}, xr.options().dtype(at::kDouble));  // cleared by the conv launch
@@ -327,53 +320,45 @@ struct ConvGnReluFn : public torch::autograd::Function<ConvGnReluFn> {
                                                 stats.data_ptr<float>(), cur_stream(xr)),
           "scan_groupnorm_relu_forward_from_sums");
     ctx->save_for_backward({xr, wp, c, gc, bc, stats});
-    ctx->saved_data["geom"] = std::vector<int64_t>{g.n, g.cin, g.h, g.w, g.cout, g.k, g.stride, g.ho, g.wo, g.cs, g.ns};
+    ctx->saved_data["geom"] = gv;
     ctx->saved_data["relu"] = relu;
     ctx->saved_data["has_bias"] = bias.defined();
-    return to_nchw(y, g.n, g.h, g.w, g.cout);
+    return y;
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto s = ctx->get_saved_variables();
-    const auto v = ctx->saved_data["geom"].toIntVector();
-    const ConvGeom g{v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10]};
+    const ConvGeom g = geom_of(ctx->saved_data["geom"].toIntVector());
     c10::hip::HIPGuardMasqueradingAsCUDA guard(s[0].device());
     const scan_pyramid_t d = one_level(g.n, g.h, g.w);
     at::Tensor dgamma, dbeta;
-    at::Tensor dc = gn_rows_backward(s[2], s[3], s[4], s[5], dy_rows(grads[0], g.ns), d, ctx->saved_data["relu"].toBool(), dgamma, dbeta);
+    at::Tensor dc = gn_rows_backward(s[2], s[3], s[4], s[5], grads[0].contiguous(), d, ctx->saved_data["relu"].toBool(), dgamma, dbeta);
     const bool has_bias = ctx->saved_data["has_bias"].toBool();
     auto r = conv_rows_backward(s[0], s[1], dc, g, ctx->needs_input_grad(0), ctx->needs_input_grad(1), has_bias && ctx->needs_input_grad(2));
-    at::Tensor dx = r[0].defined() ? to_nchw(r[0], g.n, g.h, g.w, g.cin) : at::Tensor();
     at::Tensor dw = (r[1].defined() && ctx->needs_input_grad(1)) ? unpack_wgrad(r[1], g.cin, g.k) : at::Tensor();
-    return {dx, dw, r[2], dgamma, dbeta, at::Tensor(), at::Tensor()};
+    return {r[0], dw, r[2], dgamma, dbeta, at::Tensor(), at::Tensor(), at::Tensor()};
   }
 };
 
 // ---- semantic-conditioned dynamic conv + softmax ---------------------------------------------------------------------------
 struct DynConvSoftmaxFn : public torch::autograd::Function<DynConvSoftmaxFn> {
-  static variable_list forward(AutogradContext* ctx, at::Tensor features, at::Tensor kernels) {
-    require_gpu_f32(features, "dynamic_conv_softmax", "features");
-    require_gpu_f32(kernels, "dynamic_conv_softmax", "kernel_par");
-    TORCH_CHECK(features.dim() == 4 && kernels.dim() == 2 && kernels.size(1) == features.size(1),
-                "dynamic_conv_softmax: features [N, C, H, W], kernel_par [K, C]");
-    c10::hip::HIPGuardMasqueradingAsCUDA guard(features.device());
-    const int64_t n = features.size(0), c = features.size(1), h = features.size(2), w = features.size(3), K = kernels.size(0);
-    at::Tensor fr = to_rows(features), kc = kernels.contiguous();
+  static variable_list forward(AutogradContext* ctx, at::Tensor fr, at::Tensor kernels, int64_t c) {
+    c10::hip::HIPGuardMasqueradingAsCUDA guard(fr.device());
+    const int64_t K = kernels.size(0);
+    at::Tensor kc = kernels.contiguous();
     const int64_t M = fr.size(0);
     at::Tensor logits = at::empty({M, K}, fr.options()), probs = at::empty({M, K}, fr.options());
     check(scan_dynconv_softmax_forward(fr.data_ptr<float>(), kc.data_ptr<float>(), M, (int32_t)c, (int32_t)K, logits.data_ptr<float>(),
                                        probs.data_ptr<float>(), cur_stream(fr)),
           "scan_dynconv_softmax_forward");
     ctx->save_for_backward({fr, kc, probs});
-    ctx->saved_data["dims"] = std::vector<int64_t>{n, c, h, w, K};
-    auto back = [&](const at::Tensor& t) { return t.view({n, h, w, K}).permute({0, 3, 1, 2}); };
-    return {back(logits), back(probs)};
+    ctx->saved_data["c"] = c;
+    return {logits, probs};
   }
   static variable_list backward(AutogradContext* ctx, variable_list grads) {
     const auto s = ctx->get_saved_variables();
-    const auto v = ctx->saved_data["dims"].toIntVector();
-    const int64_t n = v[0], c = v[1], h = v[2], w = v[3], K = v[4], M = n * h * w;
+    const int64_t c = ctx->saved_data["c"].toInt(), K = s[1].size(0), M = s[0].size(0);
     c10::hip::HIPGuardMasqueradingAsCUDA guard(s[0].device());
-    auto rows = [&](const at::Tensor& g) { return g.defined() ? g.permute({0, 2, 3, 1}).contiguous().view({M, K}) : g; };
+    auto rows = [&](const at::Tensor& g) { return g.defined() ? g.contiguous() : g; };
     at::Tensor dl = rows(grads[0]), dp = rows(grads[1]);
     at::Tensor dfeat = at::empty_like(s[0]), dk = at::empty_like(s[1]);
     at::Tensor ws = at::empty({scan_dynconv_ws_floats(M, (int32_t)c, (int32_t)K)}, s[0].options());
@@ -381,22 +366,47 @@ struct DynConvSoftmaxFn : public torch::autograd::Function<DynConvSoftmaxFn> {
                                         (int32_t)c, (int32_t)K, dfeat.data_ptr<float>(), dk.data_ptr<float>(), ws.data_ptr<float>(),
                                         cur_stream(s[0])),
           "scan_dynconv_softmax_backward");
-    return {to_nchw(dfeat, n, h, w, c), dk};
+    return {dfeat, dk, at::Tensor()};
   }
 };
 
+// ---- the NCHW surface: checks + layout adaptors (differentiable views) around the row-matrix nodes ----------------------------
 at::Tensor conv2d(const at::Tensor& x, const at::Tensor& weight, const c10::optional<at::Tensor>& bias, int64_t stride, bool relu) {
-  return Conv2dFn::apply(x, weight, bias, stride, relu);
+  const ConvGeom g = geom(x, weight, stride, "conv2d");
+  if (bias.has_value() && bias->defined()) require_gpu_f32(*bias, "conv2d", "bias");
+  at::Tensor y = Conv2dFn::apply(to_rows(x), weight, bias, geom_vec(g), relu);
+  return to_nchw(y, g.n, g.ho, g.wo, g.cout);
 }
 at::Tensor conv3x3_gn_relu(const at::Tensor& x, const at::Tensor& weight, const c10::optional<at::Tensor>& bias, const at::Tensor& gamma,
                            const at::Tensor& beta, double eps, bool relu) {
-  return ConvGnReluFn::apply(x, weight, bias, gamma, beta, eps, relu);
+  const ConvGeom g = geom(x, weight, 1, "conv3x3_gn_relu");
+  TORCH_CHECK(g.k == 3 && g.cout == 256, "conv3x3_gn_relu: a 3x3 conv into GroupNorm(32, 256) (the SCAN tower block)");
+  require_gpu_f32(gamma, "conv3x3_gn_relu", "GroupNorm weight");
+  require_gpu_f32(beta, "conv3x3_gn_relu", "GroupNorm bias");
+  TORCH_CHECK(gamma.numel() == 256 && beta.numel() == 256, "conv3x3_gn_relu: GroupNorm weight / bias of 256 channels");
+  at::Tensor y = ConvGnReluFn::apply(to_rows(x), weight, bias, gamma, beta, geom_vec(g), eps, relu);
+  return to_nchw(y, g.n, g.h, g.w, g.cout);
 }
 at::Tensor group_norm_relu(const at::Tensor& x, const at::Tensor& gamma, const at::Tensor& beta, double eps, bool relu) {
-  return GroupNormReluFn::apply(x, gamma, beta, eps, relu);
+  require_gpu_f32(x, "group_norm_relu", "input");
+  require_gpu_f32(gamma, "group_norm_relu", "weight");
+  require_gpu_f32(beta, "group_norm_relu", "bias");
+  TORCH_CHECK(x.dim() == 4, "group_norm_relu: input [N, C, H, W]");
+  const int64_t n = x.size(0), c = x.size(1), h = x.size(2), w = x.size(3);
+  TORCH_CHECK(c % kGroups == 0 && c % 4 == 0, "group_norm_relu: ", c, " channels do not divide into ", kGroups, " groups of whole float4s");
+  TORCH_CHECK(gamma.numel() == c && beta.numel() == c, "group_norm_relu: weight / bias must hold ", c, " elements");
+  at::Tensor y = GroupNormReluFn::apply(to_rows(x), gamma, beta, std::vector<int64_t>{n, c, h, w}, eps, relu);
+  return to_nchw(y, n, h, w, c);
 }
 std::vector<at::Tensor> dynamic_conv_softmax(const at::Tensor& features, const at::Tensor& kernels) {
-  return DynConvSoftmaxFn::apply(features, kernels);
+  require_gpu_f32(features, "dynamic_conv_softmax", "features");
+  require_gpu_f32(kernels, "dynamic_conv_softmax", "kernel_par");
+  TORCH_CHECK(features.dim() == 4 && kernels.dim() == 2 && kernels.size(1) == features.size(1),
+              "dynamic_conv_softmax: features [N, C, H, W], kernel_par [K, C]");
+  const int64_t n = features.size(0), c = features.size(1), h = features.size(2), w = features.size(3), K = kernels.size(0);
+  auto out = DynConvSoftmaxFn::apply(to_rows(features), kernels, c);
+  auto back = [&](const at::Tensor& t) { return t.view({n, h, w, K}).permute({0, 3, 1, 2}); };
+  return {back(out[0]), back(out[1])};
 }
 
 }  // namespace

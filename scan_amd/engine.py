@@ -302,11 +302,15 @@ def _complement(rngs, lo, hi):
 NO_GRAD_PARAMS = {"middle_head": ("cond_2.",)}
 
 
+DP_POLICIES = ("overlap", "coarse", "tail")
+DEFAULT_DP_POLICY = "overlap"
+
+
 class Trainer:
     """One process per GPU.  world_size > 1: per-rank shard of the batch, local graph / normalisers,
     gradients averaged by one all-reduce per sub-model flat buffer."""
 
-    def __init__(self, model, base_lr=None, con_dis_lambda=None, distributed=None, settings=None):
+    def __init__(self, model, base_lr=None, con_dis_lambda=None, distributed=None, settings=None, dp_policy=None):
         """settings: a config.settings(cfg) dict (engine.CONFIGS[name]) -- per-sub-model SGD / WarmupMultiStepLR
         settings (SOLVER.{BACKBONE,FCOS,MIDDLE_HEAD,DIS}.*, reference solver/build.py:7-84) and CON_DIS_LAMBDA;
         default: the C2F yaml.  base_lr / con_dis_lambda override it."""
@@ -336,7 +340,17 @@ class Trainer:
                                  gamma=sv["gamma"], method=sv["warmup_method"])
         self.iteration = 0
         self.distributed = dist.is_initialized() and dist.get_world_size() > 1 if distributed is None else distributed
-        self.comm_stream = torch.cuda.Stream() if self.distributed and dev0.type == "cuda" else None
+        # gradient all-reduce policy (SCAN_DP_POLICY / dp_policy; the same on every rank -- it fixes the collective sequence):
+        #   "overlap": every bucket as soon as it is final, beside the rest of the backward (six ranges per step)
+        #   "coarse":  two -- FCOS head + discriminators (114 MB) once the middle head's backward starts, the rest at the end
+        #   "tail":    ONE all-reduce of the whole arena after the backward, in front of the optimizer
+        # Default from profiles/r06_dp_emulation.txt (tools/dp_emulate.py: a stand-in kernel with RCCL's footprint on the comm
+        # stream beside the MFMA kernels, policy x workgroups, ms/step).
+        self.dp_policy = (dp_policy or os.environ.get("SCAN_DP_POLICY", DEFAULT_DP_POLICY)).lower()
+        if self.dp_policy not in DP_POLICIES:
+            raise ValueError("dp_policy %r: one of %s" % (self.dp_policy, ", ".join(DP_POLICIES)))
+        self.comm_stream = None  # set below, from the side-stream pool: the all-reduce lives INSIDE the four-queue budget
+        self.comm_hook = None  # callable(lo, hi) run on the comm stream behind every all-reduce (tools/dp_emulate.py)
         if hasattr(model["backbone"], "record_grad_marks"):
             model["backbone"].record_grad_marks = bool(self.distributed)
         self._pending = []
@@ -363,6 +377,18 @@ class Trainer:
         # head_out's feature share (97 % of that conv) beside the graph tier's tiny launches, forward and backward
         # (an existing side stream, idle at that point of the step -- the P7 discriminator's)
         self.out_stream = self.dis_streams.get("P7") if on_gpu and os.environ.get("SCAN_OUT_STREAM", "1") != "0" else None
+        if self.distributed and on_gpu:
+            # Data parallel: NO fifth stream (a fifth active hardware queue costs the step 17 %, profiles/r05_hw_queues.txt; a
+            # fifth HIP stream aliases another one's queue and serialises with it).  The collectives take s2: its other role,
+            # the P6 + P7 discriminators, has queued its last backward kernel before the first bucket becomes final (the
+            # discriminator bucket is final when ALL discriminators have back-propagated) and its next forward comes after the
+            # optimizer, which waits for the collectives -- the two roles never interleave.  head_out's feature share, the one
+            # s2 role that would (it runs during the middle head's backward, beside the first buckets' all-reduce), moves to s1.
+            # RCCL launches on the stream it is called on (ProcessGroupNCCL runs async_op=False collectives on the CURRENT
+            # stream), so nothing else appears: null stream + three side streams, as without data parallelism.
+            self.comm_stream = pool[2]
+            if self.out_stream is not None:
+                self.out_stream = pool[1]
         if "middle_head" in model and hasattr(model["middle_head"], "out_stream"):
             model["middle_head"].out_stream = self.out_stream
         # weight gradients of flat-buffer parameters on a stream of their own (ops.WGRAD_STREAM)
@@ -423,8 +449,15 @@ class Trainer:
             self.comm_stream.wait_stream(self.wgrad_stream)
         with torch.cuda.stream(self.comm_stream):
             g = self.grad_arena[lo:hi]
-            g.div_(ws)
-            self._pending.append(dist.all_reduce(g, async_op=True))
+            if dist.get_backend() == "nccl":
+                # RCCL: the mean in the collective itself (no scaling pass), launched synchronously = on THIS stream
+                # (ProcessGroupNCCL: async_op=False collectives run on the current stream, no internal stream, no host wait)
+                dist.all_reduce(g, op=dist.ReduceOp.AVG)
+            else:  # gloo with device tensors (tests/test_gpu_dp.py): staged through the host, completed at _flush_buckets
+                g.div_(ws)
+                self._pending.append(dist.all_reduce(g, async_op=True))
+            if self.comm_hook is not None:
+                self.comm_hook(lo, hi)
 
     # ---- gradient buckets: the ranges of the arena in the order they become final during the backward, the SAME list
     # on every rank and in both schedules (a collective sequence must not depend on a rank's batch shapes)
@@ -434,6 +467,24 @@ class Trainer:
         bucket."""
         if self._bucket_list is not None:
             return self._bucket_list
+        self._bucket_list = self._policy_buckets(self._fine_buckets())
+        return self._bucket_list
+
+    def _policy_buckets(self, fine):
+        """the bucket list of self.dp_policy out of the fine-grained one.  Entries: (name, ranges, after_side_streams,
+        needs) -- needs = the hook names (fine bucket names) that must ALL have fired before the entry is final."""
+        if self.dp_policy == "overlap":
+            return [(n, r, s_, frozenset([n])) for n, r, s_ in fine]
+        total = (min(r[0] for _, rs, _ in fine for r in rs), max(r[1] for _, rs, _ in fine for r in rs))
+        if self.dp_policy == "tail":
+            return [("all", [total], True, frozenset(n for n, _, _ in fine))]
+        heads = [(n, rs) for n, rs, _ in fine if n in ("fcos", "dis")]
+        cut = max(r[1] for _, rs in heads for r in rs)  # the arena is ordered FCOS head | discriminators | middle head | backbone
+        assert min(r[0] for _, rs in heads for r in rs) == total[0]
+        return [("heads", [(total[0], cut)], True, frozenset(n for n, _ in heads)),
+                ("rest", [(cut, total[1])], True, frozenset(n for n, _, _ in fine if n not in ("fcos", "dis")))]
+
+    def _fine_buckets(self):
         ar = self.arena_range
         dis = [k for k in self.groups if k.startswith("dis_")]
         out = [("fcos", [ar["fcos"]], True)]
@@ -457,7 +508,6 @@ class Trainer:
                 out.append(("backbone:rest", restr, False))
             else:
                 out.append(("backbone:rest", [ar["backbone"]], False))
-        self._bucket_list = out
         return out
 
     def _begin_buckets(self):
@@ -472,8 +522,8 @@ class Trainer:
             return
         self._ready.add(name)
         bl = self._buckets()
-        while self._issued < len(bl) and bl[self._issued][0] in self._ready:
-            _, rngs, side = bl[self._issued]
+        while self._issued < len(bl) and bl[self._issued][3] <= self._ready:
+            _, rngs, side, _ = bl[self._issued]
             for lo, hi in rngs:
                 self._allreduce_range(lo, hi, side)
             self._issued += 1
@@ -485,7 +535,7 @@ class Trainer:
         bl = self._buckets()
         self.issued_before_flush = self._issued  # buckets the backward's own hooks fired (tests: all of them in the paired step)
         while self._issued < len(bl):
-            _, rngs, side = bl[self._issued]
+            _, rngs, side, _ = bl[self._issued]
             for lo, hi in rngs:
                 self._allreduce_range(lo, hi, side)
             self._issued += 1

@@ -28,8 +28,16 @@ try:
     if _os.environ.get("SCAN_OPS_BACKEND", "") == "python":
         raise ImportError("SCAN_OPS_BACKEND=python")
     from ..ext.scan_ops import _ops
+    from .._lib import lib as _lib_handle
+    # a module left over from an earlier build must not run against a newer library: both report the ABI they were built for
+    if int(_ops.scan_abi_version()) != int(_lib_handle().scan_abi_version()):
+        raise ImportError("scan_ops._ops was built for ABI %d, libscan_hip.so is ABI %d: rebuild (__graft_entry__.build())"
+                          % (_ops.scan_abi_version(), _lib_handle().scan_abi_version()))
     OPS_BACKEND = "compiled"
-except ImportError:
+except ImportError as _e:
+    if "ABI" in str(_e):
+        import warnings as _warnings
+        _warnings.warn(str(_e) + " -- scan_amd.layers uses its ctypes bindings")
     _ops = None
     OPS_BACKEND = "python"
 
@@ -176,6 +184,11 @@ class GroupNorm(nn.GroupNorm):
         self.fuse_relu = relu
 
     def forward(self, x):
+        # the kernels are built for the one GroupNorm the SCAN modules use: 32 groups, affine, whole float4 channel groups
+        if self.num_groups != 32 or not self.affine or self.num_channels % 32 != 0 or x.shape[1] != self.num_channels:
+            raise RuntimeError("scan_amd.layers.GroupNorm: only GroupNorm(32, C) with affine=True and C %% 32 == 0 is built "
+                               "(got num_groups=%d, num_channels=%d, affine=%s, input channels=%d)"
+                               % (self.num_groups, self.num_channels, self.affine, x.shape[1]))
         if _ops is not None:
             return _ops.group_norm_relu(x, self.weight, self.bias, self.eps, self.fuse_relu)
         rows, shape, c = _to_rows(x)

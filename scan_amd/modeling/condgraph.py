@@ -179,13 +179,21 @@ def sample_target_nodes(feats, maps, shape, eps=3, thr=0.05):
 
 
 _shift_cache = {}
+_SHIFT_CACHE_MAX = 64  # ragged batches: every padded size adds two entries; oldest first out
+
+
+def _shift_put(key, value):
+    if len(_shift_cache) >= _SHIFT_CACHE_MAX:
+        _shift_cache.pop(next(iter(_shift_cache)))
+    _shift_cache[key] = value
+    return value
 
 
 def _level_bounds(shape_src, device):
     """row offsets of levels 1 .. L-1 of the source-only pyramid (bucketize boundaries: row -> level)"""
     key = ("b", tuple(shape_src.sizes), shape_src.n_images, str(device))
     if key not in _shift_cache:
-        _shift_cache[key] = torch.tensor(list(shape_src.row_off[1:shape_src.n_levels]), dtype=torch.int64, device=device)
+        return _shift_put(key, torch.tensor(list(shape_src.row_off[1:shape_src.n_levels]), dtype=torch.int64, device=device))
     return _shift_cache[key]
 
 
@@ -193,8 +201,8 @@ def _level_shift(shape_src, shape, device):
     """per level: (row offset in the joint pyramid) - (row offset in the source-only pyramid)"""
     key = ("s", tuple(shape.sizes), shape_src.n_images, shape.n_images, str(device))
     if key not in _shift_cache:
-        _shift_cache[key] = torch.tensor([shape.row_off[l] - shape_src.row_off[l] for l in range(shape.n_levels)],
-                                         dtype=torch.int64, device=device)
+        return _shift_put(key, torch.tensor([shape.row_off[l] - shape_src.row_off[l] for l in range(shape.n_levels)],
+                                            dtype=torch.int64, device=device))
     return _shift_cache[key]
 
 

@@ -429,6 +429,15 @@ class FCOSPostProcessor:
         with torch.cuda.stream(self._select_stream):
             pend = self._select(shape, box_cls, box_regression, centerness, image_sizes)
         pend.inputs = (box_cls, box_regression, centerness)  # read on the side stream: not to be reused by main before finish()
+        # ... and should the pending object be dropped without finish() (an exception unwinding the dataset loop), the caching
+        # allocator must still know who touched what: the head outputs (allocated on main) were read on the selection stream,
+        # the selection's results (allocated there) are read on main and the NMS streams
+        for t in pend.inputs:
+            t.record_stream(self._select_stream)
+        for t in (pend.ok, pend.det, pend.val, pend.lab):
+            t.record_stream(main)
+            for s_ in (self._nms_streams or ops.borrow_side_streams(2)):
+                t.record_stream(s_)
         return pend
 
     def _select(self, shape, box_cls, box_regression, centerness, image_sizes):

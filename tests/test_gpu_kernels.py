@@ -732,10 +732,12 @@ def test_wgrad_full_size_elementwise(device, case, mode, monkeypatch):
     w0 = (torch.randn((cout, cin, 3, 3), device=device, generator=g) / (cin * 9) ** 0.5).contiguous(memory_format=torch.channels_last)
     b0 = torch.randn((cout,), device=device, generator=g)
 
-    def grads(conv_mode, v6=1, tile=2):
+    def grads(conv_mode, v6=1, tile=None):
         monkeypatch.setattr(ops, "CONV_MODE", conv_mode)
         old = _lib.query("scan_tune", b"wgrad_v6", v6)
-        old_tile = _lib.query("scan_tune", b"wgrad_tile", tile)
+        dflt = _lib.query("scan_tune_default", b"wgrad_tile")
+        assert dflt == 0, "the shipped default is the 64 x 32 tile (no temporary accumulator), round 6"
+        old_tile = _lib.query("scan_tune", b"wgrad_tile", dflt if tile is None else tile)
         try:
             xx = x.clone().requires_grad_(True)
             w = w0.clone().requires_grad_(True)
@@ -781,19 +783,19 @@ def test_wgrad_full_size_elementwise(device, case, mode, monkeypatch):
     e, e32 = sampled_err(dw), sampled_err(dw32)
     print("wgrad error vs fp64 (max, rms)", case, mode, e, "fp32-MFMA", e32)
     if mode == "bf16x6":
-        # no further from fp64 than the exact fp32-MFMA kernel: the six piece products of a 32-pixel step are summed in a
-        # temporary and added to the running accumulator once (csrc/conv_wgrad.hip: TCHAIN), so a split-K slab's 8,192-pixel
-        # chain rounds once per step at the accumulator's magnitude.  Measured 0.2-0.5x the fp32-MFMA kernel's rms
-        # (tools/wgrad_err.py); without the temporary it was 1.0-2.1x
-        assert e[0] <= 5e-6 and e[1] <= 1.1 * e32[1] and e[0] <= 1.5 * e32[0], (e, e32)
-        # scan_tune wgrad_tile = 0 (the 64 x 32 consumer tile) has no temporary: the six products go straight into the running
-        # accumulator -- correct to the same element bar against the fp32-MFMA kernel, but up to ~2x its distance from fp64
-        # (include/scan_hip.h says so; this is the variant the shipped default is NOT)
-        _, _, dw_t0, _ = grads(mode, tile=0)
-        assert float((dw_t0 - dw32).abs().max()) <= 1e-5 * scale
-        e_t0 = sampled_err(dw_t0)
-        print("   wgrad_tile = 0 (no temporary accumulator):", e_t0)
-        assert e_t0[1] <= 3.0 * e32[1] and e_t0[1] >= e[1], (e_t0, e, e32)
+        # The shipped default (round 6: scan_tune wgrad_tile = 0, the 64 x 32 consumer tile) adds the six piece products
+        # straight into the running accumulator: correct to the element bar above against the fp32-MFMA kernel and within
+        # 1.0-2.1x (bar 3x) of ITS distance from fp64 -- i.e. an fp32 weight gradient in another summation order, which is all
+        # the contract asks for (the whole golden suite is green on it; profiles/r06_wgrad_tile_ab.txt: 4-5 % faster).
+        assert e[0] <= 1e-5 and e[1] <= 3.0 * e32[1], (e, e32)
+        # wgrad_tile = 1 keeps round 4's temporary accumulator (csrc/conv_wgrad.hip: TCHAIN -- the six products of a 32-pixel
+        # step summed from zero and added once, so a split-K slab's 8,192-pixel chain rounds once per step at the
+        # accumulator's magnitude): no further from fp64 than the exact fp32-MFMA kernel, measured 0.2-0.5x its rms
+        _, _, dw_t1, _ = grads(mode, tile=1)
+        assert float((dw_t1 - dw32).abs().max()) <= 1e-5 * scale
+        e_t1 = sampled_err(dw_t1)
+        print("   wgrad_tile = 1 (temporary accumulator):", e_t1)
+        assert e_t1[0] <= 5e-6 and e_t1[1] <= 1.1 * e32[1] and e_t1[0] <= 1.5 * e32[0] and e_t1[1] <= e[1], (e_t1, e, e32)
     else:
         assert e[0] <= 1e-4, e
     # adjoint identities (bias removed from y), fp64 accumulation on the device
@@ -1219,6 +1221,56 @@ def test_nchw_drop_in_modules(device):
     lr = F.conv2d(f, kp.view(9, 256, 1, 1))
     np.testing.assert_allclose(lg.cpu().numpy(), lr.numpy(), rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(pb.cpu().numpy(), lr.softmax(1).numpy(), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("backend", ["compiled", "python"])
+def test_nchw_modules_followed_by_inplace_relu(device, backend):
+    """the reference follows its convolutions with nn.ReLU(inplace=True) (backbone/mmdetection/vgg.py:29,
+    modeling/make_layers.py:74,117) and GroupNorm with an in-place ReLU in the towers written with make_conv3x3: the drop-in
+    modules' outputs must be tensors an in-place op may modify on BOTH operator backends (the C++ nodes return row matrices,
+    the NCHW view is taken outside apply()).  Outputs and gradients against torch.nn on the CPU; GroupNorm(16, C) and
+    affine=False are refused instead of silently normalised over 32 groups."""
+    import importlib
+    import scan_amd.layers as L
+    old = os.environ.get("SCAN_OPS_BACKEND")
+    try:
+        if backend == "python":
+            os.environ["SCAN_OPS_BACKEND"] = "python"
+        else:
+            os.environ.pop("SCAN_OPS_BACKEND", None)
+        L = importlib.reload(L)
+        assert L.OPS_BACKEND == backend
+        torch.manual_seed(3)
+
+        def block(conv, gn):
+            return nn.Sequential(conv(64, 256, kernel_size=3, stride=1, padding=1), nn.ReLU(inplace=True),
+                                 conv(256, 256, kernel_size=1), gn(32, 256), nn.ReLU(inplace=True),
+                                 conv(256, 5, kernel_size=3, stride=1, padding=1), nn.ReLU(inplace=True))
+
+        ref, mine = block(nn.Conv2d, nn.GroupNorm), block(L.Conv2d, L.GroupNorm).to(device)
+        mine.load_state_dict(ref.state_dict())
+        x = torch.randn(2, 64, 12, 20)
+        xr = x.clone().requires_grad_(True)
+        xm = x.to(device).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        yr, ym = ref(xr), mine(xm)
+        np.testing.assert_allclose(ym.detach().cpu().numpy(), yr.detach().numpy(), rtol=1e-4, atol=1e-4)
+        gy = torch.randn_like(yr)
+        yr.backward(gy)
+        ym.backward(gy.to(device))
+        np.testing.assert_allclose(xm.grad.cpu().numpy(), xr.grad.numpy(), rtol=1e-3, atol=2e-4 * float(xr.grad.abs().max()))
+        for (n, pr), (_, pm) in zip(ref.named_parameters(), mine.named_parameters()):
+            np.testing.assert_allclose(pm.grad.cpu().numpy(), pr.grad.numpy(), rtol=1e-3,
+                                       atol=2e-4 * float(pr.grad.abs().max()), err_msg=n)
+        with pytest.raises(RuntimeError):
+            L.GroupNorm(16, 256).to(device)(xm.new_zeros(1, 256, 4, 4))
+        with pytest.raises(RuntimeError):
+            L.GroupNorm(32, 256, affine=False).to(device)(xm.new_zeros(1, 256, 4, 4))
+    finally:
+        if old is None:
+            os.environ.pop("SCAN_OPS_BACKEND", None)
+        else:
+            os.environ["SCAN_OPS_BACKEND"] = old
+        importlib.reload(L)
 
 
 def test_compiled_ops_cpp_autograd_equals_python_path_and_torch(device):

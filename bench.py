@@ -44,6 +44,7 @@ PEAK_BF16X6_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 3.0
 HEADLINE_MODE = "bf16x6"
 XGMI_LINK_GBS = 153.0  # per link and direction; 7 links per GPU (MI355X_MICROARCH.md)
+RCCL_MAX_NCHANNELS = 16  # launcher default for N > 1, see launch_ranks
 
 
 def csrc_sha1():
@@ -250,6 +251,9 @@ def launch_ranks(a):
                          % (a.gpus, n_vis))
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    # RCCL's CU footprint beside the one-workgroup-per-CU MFMA kernels: one workgroup per channel stays resident for the whole
+    # collective.  Default from the emulation (tools/dp_emulate.py, profiles/r06_dp_emulation.txt); an explicit setting wins.
+    env.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_MAX_NCHANNELS))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.call(cmd, env=env)
@@ -332,8 +336,14 @@ def main():
         raise SystemExit("bench.py: rank %d has no GPU (%d visible)" % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # each rank on the CPUs local to ITS GPU, disjoint from its neighbours' (scan_amd/comm.py: sysfs kfd topology -> NUMA node ->
+    # cpulist; SCAN_RANK_BINDING=0 switches it off).  A single rank keeps the whole affinity mask: the CPU baseline needs it.
+    from scan_amd import comm as _comm
+    binding = _comm.bind_rank(local_rank, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None
     if world > 1 or launched:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:  # started by the driver's own torch.distributed.run: the launcher's default applies here too
+            os.environ.setdefault("NCCL_MAX_NCHANNELS", str(RCCL_MAX_NCHANNELS))
         dist.init_process_group("nccl", device_id=dev)
 
     from scan_amd import _lib, comm, engine, ops, synth
@@ -582,7 +592,7 @@ def main():
     # gradient buckets of the data-parallel step: bytes and a per-link-bound ring model of their all-reduce over xGMI
     def bucket_plan(n):
         out = []
-        for name, rngs, _ in trainer._buckets():
+        for name, rngs, *_ in trainer._buckets():
             nbytes = 4 * sum(hi - lo for lo, hi in rngs)
             ring = 2.0 * (n - 1) / n * nbytes / (XGMI_LINK_GBS * 1e9) if n > 1 else 0.0
             out.append({"bucket": name, "bytes": nbytes, "allreduces": len(rngs),
@@ -591,6 +601,7 @@ def main():
 
     n_model = world if world > 1 else 8
     buckets = bucket_plan(n_model)
+    trainer_policy = trainer.dp_policy
     rank_ms = None
     if world > 1:  # per-rank step time of the timed region (before the MAX): a straggler shows as max >> min
         t = torch.tensor([dt_local / a.steps * 1e3], device=dev, dtype=torch.float64)
@@ -686,6 +697,8 @@ def main():
                        "ranks_in_process_group": dist.get_world_size() if dist.is_initialized() else 1,
                        "collective_backend": dist.get_backend() if dist.is_initialized() else None,
                        "losses_finite": finite, "rank_ms_per_step": rank_ms,
+                       "dp_policy": trainer_policy, "rank0_cpu_binding": binding,
+                       "rccl_env": {k: os.environ[k] for k in ("NCCL_MAX_NCHANNELS", "NCCL_MIN_NCHANNELS") if k in os.environ},
                        "gradient_buckets": buckets, "gradient_buckets_modelled_for_ranks": n_model},
             "roofline": roof, "roofline_pointwise": pointwise, "cpu_baseline": cpu,
             "strict_fp32": strict, "bf16x3_two_piece": fast, "three_phase_schedule": three_phase, "inference": infer,

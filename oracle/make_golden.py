@@ -800,6 +800,83 @@ def gen_datasets():
         os.path.getsize(os.path.join(GOLD, "datasets.npz")), os.path.getsize(os.path.join(GOLD, "datasets.json")), len(res)))
 
 
+def gen_voc_ap():
+    """AP50 of the in-loop validation cross-checked against reference-held code.  The reference's COCO evaluation delegates its
+    arithmetic to pycocotools (absent), but the reference DOES hold a pure-numpy evaluator that runs here:
+    data/datasets/evaluation/voc/voc_eval.py:48-200 (eval_detection_voc -> calc_detection_voc_prec_rec, calc_detection_voc_ap).
+    On a detection set where the VOC and COCO matching rules coincide its per-class AP at IoU 0.5 pins scan_amd/coco_eval.py's
+    AP50 (tests/test_datasets_eval.py::test_ap50_against_reference_voc_evaluator).  The set is built so that they do:
+
+      * the ground truth of one class in one image is pairwise DISJOINT -> a detection reaches IoU >= 0.5 with at most one
+        truth, so "argmax IoU over all truth, false positive if taken" (VOC, voc_eval.py:107-127) and "best IoU over the
+        not-yet-matched truth" (COCO) choose the same match; no difficult / crowd truth; <= 100 detections per image;
+      * scores are distinct (VOC sorts with argsort()[::-1], COCO with a stable sort: ties would order differently);
+      * boxes are integers and each evaluator gets the set in ITS OWN pixel convention for the same geometric boxes
+        [x, x + w) x [y, y + h): COCO json xywh = (x, y, w, h) -> IoU on w x h (maskApi bbIou); the VOC code adds 1 to x2 / y2
+        and boxlist_iou adds TO_REMOVE = 1 once more (voc_eval.py:110-117, structures/boxlist_ops.py:49-82), so it is handed
+        xyxy = (x, y, x + w - 2, y + h - 2) and measures the same w x h;
+      * what differs by construction is the integration of the precision-recall curve: VOC's exact area (use_07_metric=False)
+        vs COCO's 101-point sampling -> the fixture also stores the reference's prec / rec arrays, from which the test forms the
+        101-point sample exactly.
+    AP at the other nine IoU thresholds, area ranges and crowd handling stay parity-unpinned (no reference-held code)."""
+    import importlib.util
+    rh.setup()
+    from fcos_core.structures.bounding_box import BoxList
+    spec = importlib.util.spec_from_file_location(
+        "ref_voc_eval", os.path.join(rh.REF, "fcos_core", "data", "datasets", "evaluation", "voc", "voc_eval.py"))
+    ve = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ve)
+    rs = np.random.RandomState(2026)
+    W, H, CELL, n_cls, n_img = 400, 240, 40, 4, 12
+    images, score_pool = [], list(rs.permutation(4000))
+    for i in range(n_img):
+        gt, dt = [], []
+        for c in range(1, n_cls + 1):
+            cells = [(cx, cy) for cx in range(W // CELL) for cy in range(H // CELL)]
+            rs.shuffle(cells)
+            n_gt = int(rs.randint(0, 9)) if not (i == 3 and c == 2) else 0  # one (image, class) without truth but with detections
+            for (cx, cy) in cells[:n_gt]:
+                w, h = int(rs.randint(10, CELL - 3)), int(rs.randint(10, CELL - 3))
+                x, y = cx * CELL + int(rs.randint(0, CELL - w - 1)), cy * CELL + int(rs.randint(0, CELL - h - 1))
+                gt.append((c, x, y, w, h))
+                for rep in range(int(rs.choice([0, 1, 1, 1, 2, 3]))):  # missed / found / found twice or three times
+                    j = rs.randint(-7, 8, 4) if rs.rand() < 0.7 else rs.randint(-2, 3, 4)
+                    dx, dy, dw, dh = x + int(j[0]), y + int(j[1]), max(4, w + int(j[2])), max(4, h + int(j[3]))
+                    dt.append((c, max(0, dx), max(0, dy), dw, dh, score_pool.pop() / 4000.0 + 1e-4))
+            for (cx, cy) in cells[n_gt:n_gt + int(rs.randint(0, 5))]:  # detections where nothing is
+                w, h = int(rs.randint(6, CELL)), int(rs.randint(6, CELL))
+                dt.append((c, cx * CELL + int(rs.randint(0, 8)), cy * CELL + int(rs.randint(0, 8)), w, h,
+                           score_pool.pop() / 4000.0 + 1e-4))
+        images.append({"id": 101 + i, "width": W, "height": H, "gt": gt, "dt": dt})
+    assert max(len(im["dt"]) for im in images) <= 100
+
+    def boxlist(rows, with_scores):
+        # geometric [x, x + w) x [y, y + h) in the VOC code's convention (see the docstring)
+        b = torch.tensor([[x, y, x + w - 2, y + h - 2] for (_, x, y, w, h, *_) in rows], dtype=torch.float32).reshape(-1, 4)
+        bl = BoxList(b, (W, H), mode="xyxy")
+        bl.add_field("labels", torch.tensor([r[0] for r in rows], dtype=torch.int64))
+        if with_scores:
+            bl.add_field("scores", torch.tensor([r[5] for r in rows], dtype=torch.float64))
+        else:
+            bl.add_field("difficult", torch.zeros(len(rows), dtype=torch.uint8))
+        return bl
+
+    gts = [boxlist(im["gt"], False) for im in images]
+    dts = [boxlist(im["dt"], True) for im in images]
+    res = ve.eval_detection_voc(dts, gts, iou_thresh=0.5, use_07_metric=False)
+    prec, rec = ve.calc_detection_voc_prec_rec(gts, dts, iou_thresh=0.5)
+    out = {"size": [W, H], "images": images, "n_classes": n_cls,
+           "voc_ap": [None if np.isnan(a) else float(a) for a in res["ap"]], "voc_map": float(res["map"]),
+           "voc_prec": [None if p is None else [float(v) for v in p] for p in prec],
+           "voc_rec": [None if r is None else [float(v) for v in r] for r in rec],
+           "iou_convention": "geometric boxes [x, x+w) x [y, y+h); COCO: xywh; VOC code: xyxy = (x, y, x+w-2, y+h-2)"}
+    json.dump(out, open(os.path.join(GOLD, "voc_ap50.json"), "w"))
+    print("voc_ap50.json: %d images, %d truth, %d detections, reference VOC AP per class %s, mAP %.4f, %d bytes" % (
+        n_img, sum(len(im["gt"]) for im in images), sum(len(im["dt"]) for im in images),
+        [None if a is None else round(a, 4) for a in out["voc_ap"]], out["voc_map"],
+        os.path.getsize(os.path.join(GOLD, "voc_ap50.json"))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--check", action="store_true")
@@ -862,6 +939,8 @@ def main():
         gen_pipeline()
     if "datasets" in todo:
         gen_datasets()
+    if "voc_ap" in todo:
+        gen_voc_ap()
     if "cfg" in todo:
         gen_cfg()
     if "ckpt" in todo:

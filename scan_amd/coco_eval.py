@@ -15,8 +15,13 @@ PythonAPI/pycocotools/cocoeval.py: _prepare, computeIoU, evaluateImg, accumulate
   * precision is made monotone from the right and sampled at 101 recall thresholds with searchsorted(side="left")
   * stats = AP, AP50, AP75, APs, APm, APl, AR@1, AR@10, AR@100, ARs, ARm, ARl; -1 where nothing is defined
 
-PARITY UNPINNED against pycocotools itself (absent); tests/test_datasets_eval.py anchors it on known-answer cases
-computed by hand and on an independent brute-force AP in the tests.
+Parity: pycocotools itself is absent, so AP@[.5:.95], AP75, the area ranges, AR and crowd handling are PARITY-UNPINNED
+(known-answer cases worked out by hand and an independent single-threshold AP in tests/test_datasets_eval.py).  AP50 -- the
+one number the training loop consumes (VAL_TYPE AP50 gates forward_target, trainer.py:350,465-479) -- IS cross-checked against
+reference-held code: on a set where the VOC and COCO matching rules coincide, the true / false-positive sequence at IoU 0.5
+reproduces the precision / recall arrays of the reference's numpy evaluator (data/datasets/evaluation/voc/voc_eval.py:48-200)
+element by element, and AP50 equals the 101-point sample of that curve (test_ap50_against_reference_voc_evaluator,
+tests/golden/voc_ap50.json written by oracle/make_golden.py gen_voc_ap).
 """
 import json
 import tempfile

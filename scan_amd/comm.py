@@ -106,3 +106,84 @@ def gather_detections(results, image_ids, device=None):
             sel = p[:, 0] == float(iid)
             merged[int(iid)] = (p[sel, 1:5].contiguous(), p[sel, 5].contiguous(), p[sel, 6].to(torch.int64))
     return merged
+
+
+# ----------------------------------------------------------------------------- rank placement on the host
+# One process per GPU: each rank's Python thread enqueues ~850 launches per step and must not share cores with its seven
+# neighbours or sit on the other socket's memory.  torch.distributed.run places nothing; the reference leaves it to the user
+# (tools/train_net_da.py:421-515 starts under torch.distributed.launch with no binding).  The GPU -> NUMA node -> CPU list map
+# is read from sysfs (kfd topology node -> drm render minor -> PCI device's numa_node / local_cpulist); nothing here opens the GPU.
+def _parse_cpulist(text):
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out.extend(range(int(a), int(b or a) + 1))
+    return out
+
+
+def gpu_numa_map(sysfs_root="/sys"):
+    """[{gpu, render_minor, numa_node, cpus}] for every kfd GPU node, in kfd order (= HIP device order without
+    HIP_VISIBLE_DEVICES); [] when sysfs has no kfd topology."""
+    import os
+    base = os.path.join(sysfs_root, "class", "kfd", "kfd", "topology", "nodes")
+    try:
+        nodes = sorted(os.listdir(base), key=lambda n: int(n))
+    except (OSError, ValueError):
+        return []
+    out = []
+    for node in nodes:
+        try:
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(l.split(None, 1) for l in f.read().splitlines() if " " in l)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0")) <= 0:
+            continue  # a CPU node
+        minor = int(props.get("drm_render_minor", "-1"))
+        dev = os.path.join(sysfs_root, "class", "drm", "renderD%d" % minor, "device")
+        numa, cpus = -1, []
+        try:
+            with open(os.path.join(dev, "numa_node")) as f:
+                numa = int(f.read().strip())
+            with open(os.path.join(dev, "local_cpulist")) as f:
+                cpus = _parse_cpulist(f.read())
+        except (OSError, ValueError):
+            pass
+        out.append({"gpu": len(out), "render_minor": minor, "numa_node": numa, "cpus": cpus})
+    return out
+
+
+def rank_cpu_set(local_rank, local_world, sysfs_root="/sys", allowed=None):
+    """The CPUs rank ``local_rank`` of ``local_world`` should run on: the CPUs local to its GPU (restricted to ``allowed``, the
+    process's current affinity mask), split evenly among the ranks whose GPUs share that NUMA node, in rank order.  None when
+    the topology is unknown or the share would be empty (then nothing is bound)."""
+    gpus = gpu_numa_map(sysfs_root)
+    if local_rank >= len(gpus) or not gpus[local_rank]["cpus"]:
+        return None
+    me = gpus[local_rank]
+    cpus = [c for c in me["cpus"] if allowed is None or c in allowed]
+    peers = [g["gpu"] for g in gpus[:local_world] if g["numa_node"] == me["numa_node"] and g["cpus"] == me["cpus"]]
+    if not cpus or me["gpu"] not in peers:
+        return None
+    k, n = peers.index(me["gpu"]), len(peers)
+    share = cpus[k * len(cpus) // n:(k + 1) * len(cpus) // n]
+    return {"numa_node": me["numa_node"], "cpus": share} if share else None
+
+
+def bind_rank(local_rank, local_world, sysfs_root="/sys"):
+    """sched_setaffinity of this process to rank_cpu_set(...) (memory then follows by first touch).  SCAN_RANK_BINDING=0
+    switches it off.  Returns what was applied (for the bench line) or None."""
+    import os
+    if os.environ.get("SCAN_RANK_BINDING", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None
+    try:
+        allowed = os.sched_getaffinity(0)
+        sel = rank_cpu_set(local_rank, local_world, sysfs_root, allowed)
+        if sel is None:
+            return None
+        os.sched_setaffinity(0, sel["cpus"])
+        return {"numa_node": sel["numa_node"], "n_cpus": len(sel["cpus"]), "first_cpu": sel["cpus"][0], "last_cpu": sel["cpus"][-1]}
+    except OSError:
+        return None

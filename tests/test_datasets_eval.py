@@ -250,3 +250,60 @@ def test_validation_writes_results_and_gate(tmp_path):
     assert not gate.update(results)  # not a new best
     low = coco_eval.TargetGate(initial_ap50=60)
     assert not low.update(results) and not low.forward_target  # below the initial bar: no switch, no checkpoint
+
+
+def test_ap50_against_reference_voc_evaluator(gold_dir):
+    """AP50 cross-checked against REFERENCE-HELD code: tests/golden/voc_ap50.json holds a synthetic detection set and what the
+    reference's pure-numpy VOC evaluator (data/datasets/evaluation/voc/voc_eval.py:48-200, use_07_metric=False) makes of it
+    (oracle/make_golden.py gen_voc_ap: per-class AP, and the precision / recall arrays behind it).  The set is built so that the
+    VOC and COCO matching rules coincide (truth of a class disjoint within an image, no difficult / crowd truth, distinct
+    scores, <= 100 detections per image, integer boxes handed to each evaluator in its own pixel convention for the same
+    geometric boxes -- see gen_voc_ap's docstring).  Then
+      (1) the true / false-positive sequence COCOeval derives at IoU 0.5 must reproduce the reference's precision / recall
+          arrays element by element (matching, score order and counting pinned exactly), so that
+      (2) its AP50 = the 101-point sample of the reference's own precision-recall curve (formed here from the stored arrays,
+          1e-12), and
+      (3) lies within the interpolation error of the reference's exact-area AP (<= 1 / 101 + the recall granularity).
+    AP at the other IoU thresholds, the area ranges and crowd handling remain parity-unpinned (no reference-held code)."""
+    g = json.load(open(os.path.join(gold_dir, "voc_ap50.json")))
+    W, H = g["size"]
+    cats = list(range(1, g["n_classes"] + 1))
+    js = _coco_json([(im["id"], W, H) for im in g["images"]],
+                    [(im["id"], c, (x, y, w, h), 0) for im in g["images"] for (c, x, y, w, h) in im["gt"]], cats)
+    dets = [{"image_id": im["id"], "category_id": c, "bbox": [x, y, w, h], "score": s}
+            for im in g["images"] for (c, x, y, w, h, s) in im["dt"]]
+    gt = datasets.CocoIndex(js)
+    ev = coco_eval.COCOeval(gt, gt.loadRes(dets), "bbox")
+    ev.evaluate()
+    ev.accumulate()
+    stats = ev.summarize()
+    p = ev.params
+    t50 = int(np.where(np.isclose(p.iouThrs, 0.5))[0][0])
+    a_all, m100, I = p.areaRngLbl.index("all"), p.maxDets.index(100), len(p.imgIds)
+    aps = []
+    for k, c in enumerate(p.catIds):
+        ref_prec, ref_rec = g["voc_prec"][c], g["voc_rec"][c]
+        assert ref_prec is not None and ref_rec is not None
+        # (1) COCOeval's per-image matches at IoU 0.5, in global score order
+        E = [e for e in (ev.evalImgs[k * len(p.areaRng) * I + a_all * I + i] for i in range(I)) if e is not None]
+        sc = np.concatenate([e["dtScores"] for e in E])
+        order = np.argsort(-sc, kind="mergesort")
+        tp = np.concatenate([e["dtMatches"][t50] for e in E])[order] > 0
+        assert not np.concatenate([e["dtIgnore"][t50] for e in E]).any()
+        ctp, cfp = np.cumsum(tp), np.cumsum(~tp)
+        n_pos = sum(1 for im in g["images"] for r in im["gt"] if r[0] == c)
+        np.testing.assert_allclose(ctp / (ctp + cfp), np.asarray(ref_prec), rtol=0, atol=1e-15)
+        np.testing.assert_allclose(ctp / n_pos, np.asarray(ref_rec), rtol=0, atol=1e-15)
+        # (2) the 101-point sample of the reference's curve
+        env = np.maximum.accumulate(np.asarray(ref_prec)[::-1])[::-1]
+        idx = np.searchsorted(np.asarray(ref_rec), p.recThrs, side="left")
+        sampled = float(np.mean([env[j] if j < len(env) else 0.0 for j in idx]))
+        mine = float(np.mean(ev.eval["precision"][t50, :, k, a_all, m100]))
+        assert mine == pytest.approx(sampled, abs=1e-12), (c, mine, sampled)
+        # (3) the reference's own AP (exact area under the monotone curve)
+        assert abs(mine - g["voc_ap"][c]) <= 1.0 / 101 + 1.0 / n_pos, (c, mine, g["voc_ap"][c])
+        aps.append(mine)
+    assert stats[1] == pytest.approx(float(np.mean(aps)), abs=1e-12)
+    assert abs(stats[1] - g["voc_map"]) <= 0.012, (stats[1], g["voc_map"])
+    print("AP50 per class: COCOeval %s | reference VOC evaluator %s" % ([round(a, 4) for a in aps],
+                                                                       [round(g["voc_ap"][c], 4) for c in cats]))

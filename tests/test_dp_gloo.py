@@ -130,6 +130,71 @@ def test_gradient_buckets_keep_one_collective_order():
     assert red0["a_loss"] == 1.5 and red0["consistency_loss_gt"] == 0.25
 
 
+def _policy_worker(rank, world, port, q):
+    """Trainer.dp_policy "coarse" and "tail" on host tensors: the hooks fire with the fine-grained names (rank 1 scrambled, one
+    missing), the collective sequence is the policy's and the arena the rank average."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from scan_amd import engine
+    model = engine.build_model(9, device="cpu")
+    out = {}
+    for pol in ("coarse", "tail", "overlap"):
+        trainer = engine.Trainer(model, distributed=True, dp_policy=pol)
+        fine = [b[0] for b in trainer._fine_buckets()]
+        n = trainer.grad_arena.numel()
+        trainer.grad_arena.copy_(torch.arange(n, dtype=torch.float32) % 97 + 100.0 * rank)
+        trainer._begin_buckets()
+        order = fine if rank == 0 else [fine[3], fine[1], fine[0], fine[4], fine[2]]
+        by_hooks = []
+        for nm in order:
+            trainer._bucket_ready(nm)
+            by_hooks.append(len(trainer.collective_log))
+        trainer._flush_buckets()
+        dis_end = max(trainer.arena_range[k][1] for k in trainer.groups if k.startswith("dis_"))
+        out[pol] = ([b[0] for b in trainer._buckets()], list(trainer.collective_log), by_hooks, dis_end, n,
+                    trainer.grad_arena[:2048].clone().numpy(), trainer.grad_arena.double().sum().item())
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_policies():
+    """overlap / coarse / tail (engine.Trainer.dp_policy, SCAN_DP_POLICY): same reduced arena, different collective sequences,
+    identical on both ranks whatever order the hooks fire in."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_policy_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for pol in ("coarse", "tail", "overlap"):
+        names0, log0, hooks0, dis_end, n, head0, sum0 = res[0][pol]
+        names1, log1, hooks1, _, _, head1, sum1 = res[1][pol]
+        assert names0 == names1 and log0 == log1, (pol, log0, log1)
+        expect = torch.arange(n, dtype=torch.float32) % 97 + 50.0
+        assert torch.equal(torch.from_numpy(head0), expect[:2048]) and torch.equal(torch.from_numpy(head1), expect[:2048])
+        assert sum0 == sum1 and abs(sum0 - expect.double().sum().item()) < 1e-3 * n
+        if pol == "coarse":
+            assert names0 == ["heads", "rest"] and log0 == [(0, dis_end), (dis_end, n)]
+            # rank 0 (backward order fcos, dis, ..., backbone:rest): the heads range goes out with the second hook, the rest with
+            # the last one (the conv3_1 node's hook = the end of the backward)
+            assert hooks0 == [0, 1, 1, 1, 1, 2]
+            # rank 1 (c4, dis, fcos, c3, middle head; backbone:rest never reported): 'dis' alone is not enough, 'fcos' completes
+            # the heads; the rest waits for the flush
+            assert hooks1 == [0, 0, 1, 1, 1]
+        elif pol == "tail":
+            # one range; rank 0 issues it from the last hook of the backward, rank 1 (a hook missing) at the flush
+            assert names0 == ["all"] and log0 == [(0, n)] and hooks0 == [0, 0, 0, 0, 0, 1] and hooks1[-1] == 0
+        else:
+            assert len(log0) >= 7
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # Eight ranks (BASELINE.json configs[2] / [4]: one process per GPU of an 8-GPU node).  No 8-GPU box is available to the
 # build, so everything of the N = 8 path that does not need a GPU runs here on gloo: the launcher, the global batch split,

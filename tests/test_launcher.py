@@ -124,3 +124,40 @@ def test_bench_symbols_and_peaks():
     assert bench.HEADLINE_MODE == "bf16x6"
     from scan_amd import ops
     assert ops.CONV_MODE == bench.HEADLINE_MODE  # the shipped default is what the headline is measured in
+
+
+def _fake_sysfs(root, gpus):
+    """gpus: [(render_minor, numa_node, cpulist)]; plus one CPU node (simd_count 0) in front, like a real host"""
+    nodes = os.path.join(root, "class", "kfd", "kfd", "topology", "nodes")
+    os.makedirs(os.path.join(nodes, "0"))
+    open(os.path.join(nodes, "0", "properties"), "w").write("cpu_cores_count 64\nsimd_count 0\ndrm_render_minor 0\n")
+    for i, (minor, numa, cpus) in enumerate(gpus, 1):
+        os.makedirs(os.path.join(nodes, str(i)))
+        open(os.path.join(nodes, str(i), "properties"), "w").write("cpu_cores_count 0\nsimd_count 1024\ndrm_render_minor %d\n" % minor)
+        dev = os.path.join(root, "class", "drm", "renderD%d" % minor, "device")
+        os.makedirs(dev)
+        open(os.path.join(dev, "numa_node"), "w").write("%d\n" % numa)
+        open(os.path.join(dev, "local_cpulist"), "w").write(cpus + "\n")
+
+
+def test_rank_cpu_placement_from_sysfs(tmp_path):
+    """8 GPUs on two sockets (4 + 4), SMT siblings listed as a second range: every rank gets a disjoint share of ITS socket's
+    CPUs; an affinity mask narrower than the socket is respected; unknown topology binds nothing."""
+    from scan_amd import comm
+    root = str(tmp_path)
+    _fake_sysfs(root, [(128 + i, 0 if i < 4 else 1, "0-15,32-47" if i < 4 else "16-31,48-63") for i in range(8)])
+    m = comm.gpu_numa_map(root)
+    assert [g["numa_node"] for g in m] == [0, 0, 0, 0, 1, 1, 1, 1] and m[5]["render_minor"] == 133
+    sets = [comm.rank_cpu_set(r, 8, root) for r in range(8)]
+    assert all(s is not None and len(s["cpus"]) == 8 for s in sets)
+    assert sets[0]["cpus"] == list(range(0, 8)) and sets[3]["cpus"] == list(range(40, 48))
+    assert sets[4]["numa_node"] == 1 and sets[4]["cpus"] == list(range(16, 24))
+    flat = [c for s in sets for c in s["cpus"]]
+    assert len(flat) == len(set(flat)) == 64
+    # two ranks only: each takes half of socket 0
+    assert comm.rank_cpu_set(1, 2, root)["cpus"] == list(range(32, 48))
+    # a cpuset of 8 CPUs (this container): shares are cut from what the process may use
+    assert comm.rank_cpu_set(1, 4, root, allowed=set(range(8)))["cpus"] == [2, 3]
+    assert comm.rank_cpu_set(5, 8, root, allowed=set(range(8))) is None  # none of socket 1's CPUs allowed: nothing bound
+    assert comm.rank_cpu_set(0, 1, str(tmp_path / "missing")) is None and comm.gpu_numa_map(str(tmp_path / "missing")) == []
+    assert comm.rank_cpu_set(9, 8, root) is None

@@ -298,6 +298,11 @@ def main():
                     help="run although SCAN_HIP_LIB selects another build than scan_amd/libscan_hip.so (timing experiments, "
                          "csrc/Makefile exp_*: WRONG results by construction); the line is then marked as not a measurement "
                          "of the product")
+    ap.add_argument("--surface", choices=("layers", "none"), default="layers",
+                    help="companion leg `extra.drop_in`: the same DA iteration through scan_amd.surface -- NCHW tensors, one module "
+                         "call per level, scan_amd.layers on the C++ autograd operators, i.e. the call shape of the reference's module "
+                         "files (rpn/fcos/fcos.py:66-114, condgraph.py:86-119) -- ms/step, launches/step and a per-operator table "
+                         "beside the engine's (tools/surface_bench.py)")
     ap.add_argument("--serial-streams", action="store_true",
                     help="run everything on one stream (no side-stream overlap): what the per-kernel roofline "
                          "figures and the rocprof summaries under profiles/ are taken with")
@@ -438,7 +443,7 @@ def main():
     finite = all(bool(torch.isfinite(v)) for v in losses.values())
 
     # ---- companion legs (N = 1, headline model only): same frames, same trainer, outside the timed region
-    strict = fast = three_phase = infer = dp1 = None
+    strict = fast = three_phase = infer = dp1 = drop_in = None
 
     def note(msg):  # progress on stderr: the JSON line is the only thing on stdout
         if rank == 0:
@@ -578,9 +583,11 @@ def main():
                 dtd = (time.time() - t0d) / a.steps
                 dp1 = {"ms_per_step": round(dtd * 1e3, 2), "pairs_per_s": round(B / dtd, 4), "steps": a.steps,
                        "collective_backend": dist.get_backend(), "ranks_in_process_group": dist.get_world_size(),
-                       "gradient_allreduces_per_step": len(tr_dp.collective_log),
+                       "gradient_allreduces_per_step": len(tr_dp.collective_log), "dp_policy": tr_dp.dp_policy,
+                       "streams": "comm = side stream s2 (no fifth stream), head_out share on s1",
                        "note": "same step through engine.Trainer(distributed=True) on a one-rank RCCL group"}
                 ops.WGRAD_STREAM = trainer.wgrad_stream
+                model["middle_head"].out_stream = trainer.out_stream
                 note("one-rank RCCL leg %.1f ms" % dp1["ms_per_step"])
                 del tr_dp
             except Exception as e:  # a broken collective path must not take the headline down with it
@@ -588,6 +595,21 @@ def main():
             finally:
                 if dist.is_initialized():
                     dist.destroy_process_group()
+
+        # (e) the drop-in operator surface: what a reference-shaped NCHW, per-level module graph gets from the same kernels
+        if a.surface == "layers":
+            note("drop-in surface leg (scan_amd.surface on scan_amd.layers)")
+            try:
+                from tools import surface_bench
+                ops.WGRAD_STREAM = trainer.wgrad_stream
+                model["middle_head"].out_stream = trainer.out_stream
+                drop_in = surface_bench.measure(trainer, imgs_s, tg, imgs_t, steps=max(3, a.steps // 4))
+                drop_in["engine_ms_per_step"] = round(dt / a.steps * 1e3, 2)
+                drop_in["ratio_to_engine"] = round(drop_in["ms_per_step"] / (dt / a.steps * 1e3), 3)
+                note("drop-in surface %.1f ms/step, %d launches (engine %d)" % (drop_in["ms_per_step"], drop_in["launches_per_step"],
+                                                                              drop_in["engine_launches_per_step"]))
+            except Exception as e:  # a companion leg never costs the run its line
+                drop_in = {"error": repr(e)}
 
     # gradient buckets of the data-parallel step: bytes and a per-link-bound ring model of their all-reduce over xGMI
     def bucket_plan(n):
@@ -702,7 +724,7 @@ def main():
                        "gradient_buckets": buckets, "gradient_buckets_modelled_for_ranks": n_model},
             "roofline": roof, "roofline_pointwise": pointwise, "cpu_baseline": cpu,
             "strict_fp32": strict, "bf16x3_two_piece": fast, "three_phase_schedule": three_phase, "inference": infer,
-            "dp1_nccl": dp1,
+            "dp1_nccl": dp1, "extra": {"drop_in": drop_in},
         }
         # RCCL prints a version banner through C stdio, which is still buffered here when stdout is a pipe: push it
         # out first so the JSON line is the LAST line on stdout

@@ -128,6 +128,13 @@ at::Tensor conv_rows_forward(const at::Tensor& xr, const at::Tensor& wp, const a
           "scan_conv2d_forward");
     return y;
   }
+  if (g.k == 3 && g.stride == 1 && g.cs == 4 && g.cout <= 64 && !gn_sums.defined()) {
+    // the first layer (3 input channels, mmdetection/vgg.py conv1_1): the dedicated K = taps x 4 kernel, like scan_amd.ops
+    check(scan_conv_smallcin_bf16x6(xr.data_ptr<float>(), (int32_t)g.n, (int32_t)g.h, (int32_t)g.w, wp.data_ptr<float>(), opt_ptr(bias),
+                                    y.data_ptr<float>(), (int32_t)g.cout, (int32_t)g.ns, 3, 1, relu ? 1 : 0, st),
+          "scan_conv_smallcin_bf16x6");
+    return y;
+  }
   const Planes pl = split3(wp, 0, g.cs);
   if (g.k == 3) {
     if (gn_sums.defined())

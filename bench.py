@@ -44,7 +44,7 @@ PEAK_BF16X6_TFLOPS = PEAK_BF16_TFLOPS / 6.0
 PEAK_BF16X3_TFLOPS = PEAK_BF16_TFLOPS / 3.0
 HEADLINE_MODE = "bf16x6"
 XGMI_LINK_GBS = 153.0  # per link and direction; 7 links per GPU (MI355X_MICROARCH.md)
-RCCL_MAX_NCHANNELS = 16  # launcher default for N > 1, see launch_ranks
+RCCL_MAX_NCHANNELS = 32  # launcher default for N > 1 (profiles/r06_dp_emulation.txt: 16-64 resident workgroups cost the step the same, 8 more), see launch_ranks
 
 
 def csrc_sha1():

@@ -23,6 +23,8 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <torch/extension.h>
 
+#include <map>
+#include <utility>
 #include <vector>
 
 #include "../../include/scan_hip.h"
@@ -80,8 +82,52 @@ struct Planes {
   at::Tensor p[3];
   int64_t csw;
 };
+
+// ---- weight planes across calls.  A reference-shaped module graph calls the SAME conv once per pyramid level (rpn/fcos/fcos.py:
+// 66-114 shares its towers over five levels), and every call would split the same fp32 weight into the same three bf16 planes
+// again (forward + data gradient: 2 launches x 5 levels per layer).  The planes are kept per (storage address, shape, mode) and
+// reused while the weight is provably unchanged: same at::Tensor version counter (every in-place update through torch bumps
+// it -- torch.optim.SGD, load_state_dict, .data.copy_), same epoch (invalidate_weight_cache(): updates that bypass torch, like the
+// engine's fused SGD on raw pointers, call it through scan_amd.ops.invalidate_weight_planes), same stream.
+struct PlaneEntry {
+  at::Tensor keep;  // the packed weight itself: while the entry lives its storage cannot be handed to another tensor
+  uint32_t version;
+  int64_t epoch;
+  void* stream;
+  int64_t o, t, cs;
+  Planes pl;
+};
+int64_t g_plane_epoch = 0;
+std::map<std::pair<const void*, int>, PlaneEntry>& plane_cache() {
+  static std::map<std::pair<const void*, int>, PlaneEntry> c;
+  return c;
+}
+void invalidate_weight_cache() {
+  ++g_plane_epoch;
+  plane_cache().clear();
+}
 // three bf16 planes of packed weights wp [O][T][Cs]; mode 0: forward [O][T][csw]; mode 1: data gradient [Cs][T][csw]
-Planes split3(const at::Tensor& wp, int mode, int64_t cs_src) {
+Planes split3_uncached(const at::Tensor& wp, int mode, int64_t cs_src);
+Planes split3(const at::Tensor& wp, int mode, int64_t cs_src, const at::Tensor& owner = at::Tensor()) {
+  // owner: defined when wp is a VIEW of the weight tensor (pack_weight of a channels_last weight with C % 4 == 0: shares its storage
+  // and its version counter) -- only then does the cache apply; a packed COPY is a fresh temporary every call
+  if (!owner.defined() || owner.data_ptr() != wp.data_ptr()) return split3_uncached(wp, mode, cs_src);
+  const auto key = std::make_pair((const void*)wp.data_ptr(), mode);
+  void* st = cur_stream(wp);
+  auto& cache = plane_cache();
+  auto it = cache.find(key);
+  if (it != cache.end()) {
+    const PlaneEntry& e = it->second;
+    if (e.version == owner._version() && e.epoch == g_plane_epoch && e.stream == st && e.o == wp.size(0) && e.t == wp.size(1) &&
+        e.cs == wp.size(2))
+      return e.pl;
+  }
+  if (cache.size() > 512) cache.clear();
+  PlaneEntry e{wp, owner._version(), g_plane_epoch, st, wp.size(0), wp.size(1), wp.size(2), split3_uncached(wp, mode, cs_src)};
+  cache[key] = e;
+  return e.pl;
+}
+Planes split3_uncached(const at::Tensor& wp, int mode, int64_t cs_src) {
   const int64_t o = wp.size(0), t = wp.size(1), cs = wp.size(2);
   const int64_t rnd = t == 9 ? 32 : 8;  // 3x3: whole 32-channel K chunks (LDS-DMA weight tiles); 1x1: 8-element granule
   Planes pl;
@@ -118,7 +164,7 @@ ConvGeom geom(const at::Tensor& x, const at::Tensor& weight, int64_t stride, con
 // ---- forward / backward of a conv on row matrices (shared by Conv2dFn and ConvGnReluFn) -------------------------------
 // y rows [Mo, Ns]; gn_sums (defined): the epilogue accumulates the GroupNorm sums of the output there (3x3 / stride 1 only)
 at::Tensor conv_rows_forward(const at::Tensor& xr, const at::Tensor& wp, const at::Tensor& bias, const ConvGeom& g, bool relu,
-                             at::Tensor gn_sums) {
+                             at::Tensor gn_sums, const at::Tensor& owner = at::Tensor()) {
   const scan_pyramid_t xd = one_level(g.n, g.h, g.w), yd = one_level(g.n, g.ho, g.wo);
   at::Tensor y = g.ns != g.cout ? at::zeros({yd.row_off[1], g.ns}, xr.options()) : at::empty({yd.row_off[1], g.ns}, xr.options());
   void* st = cur_stream(xr);
@@ -135,7 +181,7 @@ at::Tensor conv_rows_forward(const at::Tensor& xr, const at::Tensor& wp, const a
           "scan_conv_smallcin_bf16x6");
     return y;
   }
-  const Planes pl = split3(wp, 0, g.cs);
+  const Planes pl = split3(wp, 0, g.cs, owner);
   if (g.k == 3) {
     if (gn_sums.defined())
       check(scan_conv3x3_gn_bf16x6(xr.data_ptr<float>(), &xd, (int32_t)g.cs, pl.p[0].data_ptr(), pl.p[1].data_ptr(), pl.p[2].data_ptr(),
@@ -158,7 +204,7 @@ at::Tensor conv_rows_forward(const at::Tensor& xr, const at::Tensor& wp, const a
 
 // dyr rows [Mo, Ns] (the ReLU, if any, already backed out).  Returns {dx rows [Mi, Cs] or undefined, dw packed, db or undefined}
 std::vector<at::Tensor> conv_rows_backward(const at::Tensor& xr, const at::Tensor& wp, const at::Tensor& dyr, const ConvGeom& g,
-                                           bool need_dx, bool need_dw, bool need_db) {
+                                           bool need_dx, bool need_dw, bool need_db, const at::Tensor& owner = at::Tensor()) {
   const scan_pyramid_t xd = one_level(g.n, g.h, g.w), yd = one_level(g.n, g.ho, g.wo);
   void* st = cur_stream(xr);
   const int64_t T = g.k * g.k;
@@ -173,7 +219,7 @@ std::vector<at::Tensor> conv_rows_backward(const at::Tensor& xr, const at::Tenso
                               (int32_t)g.cs, 3, 2, nullptr, st),
             "scan_conv2d_dgrad");
     } else {
-      const Planes pl = split3(wp, 1, g.ns);  // flipped + transposed planes: the data gradient is the forward kernel on dY
+      const Planes pl = split3(wp, 1, g.ns, owner);  // flipped + transposed planes: the data gradient is the forward kernel on dY
       if (g.k == 3)
         check(scan_conv3x3_bf16x6(dyr.data_ptr<float>(), &yd, (int32_t)g.ns, pl.p[0].data_ptr(), pl.p[1].data_ptr(), pl.p[2].data_ptr(),
                                   (int32_t)pl.csw, nullptr, nullptr, dx.data_ptr<float>(), (int32_t)g.cs, (int32_t)g.cs, 0, st),
@@ -232,8 +278,10 @@ struct Conv2dFn : public torch::autograd::Function<Conv2dFn> {
     c10::hip::HIPGuardMasqueradingAsCUDA guard(xr.device());
     at::Tensor wp = pack_weight(weight);
     at::Tensor bc = bias.defined() ? bias.contiguous() : bias;
-    at::Tensor y = conv_rows_forward(xr, wp, bc, g, relu, at::Tensor());
+    const bool wp_view = wp.data_ptr() == weight.data_ptr();
+    at::Tensor y = conv_rows_forward(xr, wp, bc, g, relu, at::Tensor(), wp_view ? wp : at::Tensor());
     ctx->save_for_backward({xr, wp, relu ? y : at::Tensor()});
+    ctx->saved_data["wp_view"] = wp_view;
     ctx->saved_data["geom"] = gv;
     ctx->saved_data["relu"] = relu;
     ctx->saved_data["has_bias"] = bias.defined();
@@ -253,7 +301,7 @@ struct Conv2dFn : public torch::autograd::Function<Conv2dFn> {
     }
     const bool has_bias = ctx->saved_data["has_bias"].toBool();
     auto r = conv_rows_backward(xr, wp, dyr, g, ctx->needs_input_grad(0), ctx->needs_input_grad(1),
-                                has_bias && ctx->needs_input_grad(2));
+                                has_bias && ctx->needs_input_grad(2), ctx->saved_data["wp_view"].toBool() ? wp : at::Tensor());
     at::Tensor dw = (r[1].defined() && ctx->needs_input_grad(1)) ? unpack_wgrad(r[1], g.cin, g.k) : at::Tensor();
     return {r[0], dw, r[2], at::Tensor(), at::Tensor()};
   }
@@ -320,7 +368,9 @@ struct ConvGnReluFn : public torch::autograd::Function<ConvGnReluFn> {
     at::Tensor cb = bias.defined() ? bias.contiguous() : bias;
     const scan_pyramid_t d = one_level(g.n, g.h, g.w);
     at::Tensor sums = at::empty({g.n * kGroups * 2}, xr.options().dtype(at::kDouble));  // cleared by the conv launch
-    at::Tensor c = conv_rows_forward(xr, wp, cb, g, false, sums);
+    const bool wp_view = wp.data_ptr() == weight.data_ptr();
+    at::Tensor c = conv_rows_forward(xr, wp, cb, g, false, sums, wp_view ? wp : at::Tensor());
+    ctx->saved_data["wp_view"] = wp_view;
     at::Tensor stats = at::empty({g.n * kGroups * 2}, xr.options()), y = at::empty_like(c);
     check(scan_groupnorm_relu_forward_from_sums(c.data_ptr<float>(), &d, 256, kGroups, reinterpret_cast<float*>(sums.data_ptr()),
                                                 (float)eps, gc.data_ptr<float>(), bc.data_ptr<float>(), relu ? 1 : 0, y.data_ptr<float>(),
@@ -340,7 +390,8 @@ struct ConvGnReluFn : public torch::autograd::Function<ConvGnReluFn> {
     at::Tensor dgamma, dbeta;
     at::Tensor dc = gn_rows_backward(s[2], s[3], s[4], s[5], grads[0].contiguous(), d, ctx->saved_data["relu"].toBool(), dgamma, dbeta);
     const bool has_bias = ctx->saved_data["has_bias"].toBool();
-    auto r = conv_rows_backward(s[0], s[1], dc, g, ctx->needs_input_grad(0), ctx->needs_input_grad(1), has_bias && ctx->needs_input_grad(2));
+    auto r = conv_rows_backward(s[0], s[1], dc, g, ctx->needs_input_grad(0), ctx->needs_input_grad(1), has_bias && ctx->needs_input_grad(2),
+                                ctx->saved_data["wp_view"].toBool() ? s[1] : at::Tensor());
     at::Tensor dw = (r[1].defined() && ctx->needs_input_grad(1)) ? unpack_wgrad(r[1], g.cin, g.k) : at::Tensor();
     return {r[0], dw, r[2], dgamma, dbeta, at::Tensor(), at::Tensor(), at::Tensor()};
   }
@@ -429,4 +480,7 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("dynamic_conv_softmax", &dynamic_conv_softmax, "F.conv2d(x, kernel_par[K, C, 1, 1]) + softmax(dim = 1) -> (logits, probs)",
         py::arg("features"), py::arg("kernel_par"));
   m.def("scan_abi_version", []() { return scan_abi_version(); });
+  m.def("invalidate_weight_cache", &invalidate_weight_cache,
+        "drop the cached bf16 weight planes: call after updating parameters through anything but torch's own in-place ops");
+  m.def("weight_cache_size", []() { return (int64_t)plane_cache().size(); });
 }

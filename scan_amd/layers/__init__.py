@@ -34,6 +34,7 @@ try:
         raise ImportError("scan_ops._ops was built for ABI %d, libscan_hip.so is ABI %d: rebuild (__graft_entry__.build())"
                           % (_ops.scan_abi_version(), _lib_handle().scan_abi_version()))
     OPS_BACKEND = "compiled"
+    ops._EXT_INVALIDATE = _ops.invalidate_weight_cache  # ops.invalidate_weight_planes() then drops the C++ side's planes too
 except ImportError as _e:
     if "ABI" in str(_e):
         import warnings as _warnings

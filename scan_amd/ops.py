@@ -362,6 +362,11 @@ def invalidate_weight_planes():
     _active_plan = None
     _zero_pool["active"] = False
     _split_cache.clear()
+    if _EXT_INVALIDATE is not None:  # the compiled operators' own plane cache (scan_ops_ext.cpp), when that module is loaded
+        _EXT_INVALIDATE()
+
+
+_EXT_INVALIDATE = None  # set by scan_amd.layers when scan_ops._ops is imported
 
 
 # GroupNorm sums produced by a conv epilogue, handed to the groupnorm_relu call that consumes that conv's output
@@ -1197,18 +1202,21 @@ def softmax_focal_loss_mean(logits, labels, gamma=2.0):
 class _GradReverse(torch.autograd.Function):
     """reference discriminator/layer.py:6-24: forward x.clone(), backward -lambda * g.  The forward here is a view of
     x -- same values, and nothing downstream writes into it in place -- which saves a read + write of every feature
-    and act map handed to the five discriminators (375 MB per iteration at the bench size)."""
+    and act map handed to the five discriminators (375 MB per iteration at the bench size).  Any dense layout is taken as
+    it is (row matrices; channels_last NCHW tensors on the drop-in surface): the backward is element-wise on the storage."""
 
     @staticmethod
     def forward(ctx, x, lam):
-        _chk(x)
+        if not x.is_cuda:
+            raise RuntimeError("scan_amd ops run only on the GPU (HIP) -- got a %s tensor; no CPU fallback" % x.device)
         ctx.lam = lam
         return x.view_as(x)
 
     @staticmethod
     def backward(ctx, g):
-        g = g.contiguous()
-        d = torch.empty_like(g)
+        if not (g.is_contiguous() or (g.dim() == 4 and g.is_contiguous(memory_format=torch.channels_last))):
+            g = g.contiguous()
+        d = torch.empty_like(g)  # preserve_format: the same dense strides as g
         call("scan_scale", _ptr(g), -ctx.lam, _ptr(d), g.numel(), _stream())
         return d, None
 

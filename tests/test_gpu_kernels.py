@@ -1273,6 +1273,53 @@ def test_nchw_modules_followed_by_inplace_relu(device, backend):
         importlib.reload(L)
 
 
+def test_compiled_ops_weight_plane_cache_follows_parameter_updates(device):
+    """scan_ops._ops keeps the three bf16 planes of a weight across calls (a reference-shaped graph calls one conv once per
+    pyramid level).  They must be re-split whenever the parameter changed: an in-place torch update (what torch.optim.SGD and
+    load_state_dict do: the version counter moves), and an update that bypasses torch followed by
+    ops.invalidate_weight_planes() (what the engine's fused SGD does)."""
+    from scan_amd import layers as L
+    from scan_amd import ops
+    if L.OPS_BACKEND != "compiled":
+        pytest.skip("scan_ops._ops not built")
+    torch.manual_seed(2)
+    conv = L.Conv2d(256, 256, 3, 1, 1).to(device)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    x = torch.randn(1, 256, 16, 24, device=device).contiguous(memory_format=torch.channels_last)
+
+    def fresh():  # the Python path splits on every call outside a weight epoch
+        rows, shape, _ = L._to_rows(x)
+        ops.invalidate_weight_planes()
+        return L._to_nchw(ops.conv2d(rows, conv.weight, conv.bias, shape, 3, 1), shape, 256)
+
+    L._ops.invalidate_weight_cache()
+    y1 = conv(x)
+    n1 = L._ops.weight_cache_size()
+    assert n1 >= 1 and torch.equal(y1, fresh())
+    assert torch.equal(conv(x), y1) and L._ops.weight_cache_size() == n1  # second call: served from the cache
+    with torch.no_grad():
+        conv.weight.mul_(1.5)  # torch in-place: version counter moves
+    y2 = conv(x)
+    assert torch.equal(y2, fresh()) and not torch.equal(y2, y1)
+    # an update behind torch's back (raw pointer, like scan_sgd_momentum_multi on the flat buffers) + the invalidation call
+    w = conv.weight.detach()
+    ops.call("scan_scale", ops._ptr(w), 0.5, ops._ptr(w), w.numel(), ops._stream())
+    ops.invalidate_weight_planes()
+    assert L._ops.weight_cache_size() == 0
+    y3 = conv(x)
+    assert torch.equal(y3, fresh()) and not torch.equal(y3, y2)
+    # backward through cached planes: same gradients as the Python path
+    xg = x.clone().requires_grad_(True)
+    conv(xg).square().sum().backward()
+    gx, gw = xg.grad.clone(), conv.weight.grad.clone()
+    conv.weight.grad = None
+    xg2 = x.clone().requires_grad_(True)
+    rows, shape, _ = L._to_rows(xg2)
+    ops.invalidate_weight_planes()
+    L._to_nchw(ops.conv2d(rows, conv.weight, conv.bias, shape, 3, 1), shape, 256).square().sum().backward()
+    assert torch.equal(gx, xg2.grad) and torch.equal(gw, conv.weight.grad)
+
+
 def test_compiled_ops_cpp_autograd_equals_python_path_and_torch(device):
     """scan_amd/ext/scan_ops/_ops (scan_amd/csrc/scan_ops_ext.cpp): conv2d, conv3x3_gn_relu, group_norm_relu and
     dynamic_conv_softmax as torch::autograd::Function nodes in C++ on the C ABI.  Same kernels as the Python autograd path of

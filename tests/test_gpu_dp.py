@@ -208,3 +208,54 @@ def test_two_ranks_mixed_schedules_issue_the_same_collectives(device, tmp_path, 
         # both ranks hold the same averaged gradients: identical parameters whatever schedule produced their shares
         assert torch.equal(a[k], b[k]), (k, (a[k] - b[k]).abs().max().item())
         assert torch.allclose(a[k], ref[k], rtol=1e-4, atol=5e-6), (k, (a[k] - ref[k]).abs().max().item())
+
+
+def _policy_worker(rank, world, port, outdir, policy):
+    """one rank on RCCL: the data-parallel machinery (hooks, buckets, comm stream = side stream s2, ReduceOp.AVG launched on the
+    calling stream) under one dp_policy; the mean over one rank is the identity"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        from scan_amd import engine, ops, synth
+        dev = torch.device("cuda", 0)
+        model = engine.build_model(9, device=dev, attn_dropout=0.0)
+        engine.load_procedural_weights(model)
+        trainer = engine.Trainer(model, distributed=True, dp_policy=policy)
+        assert trainer.comm_stream is ops.borrow_side_streams(3)[2] and trainer.out_stream is ops.borrow_side_streams(3)[1]
+        imgs_s, tg, imgs_t = _batch(0, dev)
+        for _ in range(STEPS):
+            losses = trainer.step(imgs_s, tg, imgs_t)
+        torch.cuda.synchronize()
+        assert all(bool(torch.isfinite(v)) for v in losses.values())
+        out = {k: g.flat_p.detach().cpu().clone() for k, g in trainer.groups.items()}
+        out["collective_log"] = torch.tensor(trainer.collective_log, dtype=torch.int64)
+        out["n_arena"] = torch.tensor([trainer.grad_arena.numel()])
+        torch.save(out, os.path.join(outdir, "policy_%s.pt" % policy))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("policy", ["overlap", "coarse", "tail"])
+def test_one_rank_rccl_every_policy_equals_plain_step(device, tmp_path, policy):
+    """engine.Trainer.dp_policy on a real RCCL process group (one rank: what a 1-GPU box allows): overlap / coarse / tail issue
+    6+ / 2 / 1 all-reduce ranges that cover the arena once, on side stream s2 (no fifth stream), and leave the parameters where
+    the plain single-process step leaves them (run-to-run tolerance of the loss atomics)."""
+    ctx = mp.get_context("spawn")
+    port = 30100 + os.getpid() % 1500 + {"overlap": 0, "coarse": 1, "tail": 2}[policy]
+    p = ctx.Process(target=_policy_worker, args=(0, 1, port, str(tmp_path), policy))
+    p.start()
+    p.join(timeout=900)
+    assert p.exitcode == 0
+    got = torch.load(os.path.join(str(tmp_path), "policy_%s.pt" % policy))
+    log = [tuple(r) for r in got["collective_log"].tolist()]
+    n = int(got["n_arena"][0])
+    assert sum(b - a for a, b in log) == n and min(a for a, _ in log) == 0 and max(b for _, b in log) == n
+    assert {"overlap": len(log) >= 6, "coarse": len(log) == 2, "tail": len(log) == 1}[policy], log
+    ref = _run(0, 1, True)
+    for k, v in ref.items():
+        if k in got:
+            assert torch.allclose(got[k], v, rtol=1e-4, atol=5e-6), (policy, k, (got[k] - v).abs().max().item())

@@ -65,11 +65,12 @@ int scan_abi_version(void);
  *                 convs).  bf16x3: bit-identical; bf16x6: other K-chunk length, i.e. other split-K boundaries.
  *   "wgrad_prio"  1: the producer waves of that kernel run at s_setprio 3; 0 (default): at the consumers' priority.  Same
  *                 results bit for bit.
- *   "wgrad_tile"  consumer wave tile of that kernel: 0 (default) = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c); any other value = the
- *                 default.  bf16x3: same results bit for bit.  bf16x6: 0 adds the six piece products of a 32-pixel step
- *                 straight into the running accumulator (an fp32 sum in another order: 1.0-2.1x the fp32-MFMA kernel's
- *                 distance from fp64; the golden suite is green on it and it is 4-5 % faster), 1 sums them in a temporary
- *                 first (one rounding per step at the accumulator's magnitude, DESIGN.md 3.0: 0.23-0.5x that distance).
+ *   "wgrad_tile"  consumer wave tile of that kernel: 0 = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c), 2 (default, and any other value) = 1
+ *                 for bf16x6, 0 for bf16x3.  bf16x3: same results bit for bit.  bf16x6: 1 sums the six piece products of a
+ *                 32-pixel step in a temporary first (one rounding per step at the accumulator's magnitude, DESIGN.md 3.0:
+ *                 0.23-0.5x the fp32-MFMA kernel's distance from fp64); 0 adds them straight into the running accumulator (an
+ *                 fp32 sum in another order, 1.0-2.1x that distance; the golden suite is green on it, 4-5 % faster on random
+ *                 operands, no faster in the training step: profiles/r06_wgrad_tile_ab.txt).
  *   "wgrad_wgs"   768 (default): workgroups a weight-gradient launch aims at (tiles x split-K slabs); 512 / 640 / 896 / 1024
  *                 / 1280 / 1536 are 2...25 % slower on the 256- and 512-channel layers (bf16x3).
  *   "gconv_mfma"  0 (default): the grouped class-branch conv runs on fp32 FMAs; 1: tap products and data gradient on the

@@ -875,15 +875,16 @@ __global__ W6_BOUNDS void conv_wgrad_v6_kernel(
   __syncthreads();  // pairs with the producers' bias-reduction barrier
 }
 
-// scan_tune "wgrad_tile": consumer wave tile of the producer / consumer kernel: 0 (default) = 64 (o) x 32 (c), every piece product
-// accumulated straight into the running fp32 accumulator; 1 = 32 (o) x 64 (c) with a temporary accumulator per 32-pixel step
-// (three pieces only: the six products of a step are summed from zero and added once -- 0.23-0.5x the fp32-MFMA kernel's distance
-// from an fp64 weight gradient instead of 1.0-2.1x, tests/test_gpu_kernels.py::test_wgrad_full_size_elementwise measures both).
-// Round 6: the WHOLE golden suite (strict fp32 bars, every digest of step_cfg2, both trajectories; 273 tests) is green on tile 0
-// (gpurun, SCAN_TUNE=wgrad_tile=0), i.e. the temporary buys accuracy the contract does not ask for, at 4-5 % of the kernel:
-// conv3_x 2576 -> 2442 us, conv4_x 2473 -> 2379, conv5_x 640 -> 608, towers 1080 -> 942 (profiles/r06_wgrad_tile_ab.txt).  Tile 0
-// is the default; 1 stays as the knob.  Two pieces: same results bit for bit on either tile.  Any other value = the default.
-int g_scan_wgrad_tile = 0;
+// scan_tune "wgrad_tile": consumer wave tile of the producer / consumer kernel: 0 = 64 (o) x 32 (c), 1 = 32 (o) x 64 (c),
+// 2 (default; any other value too) = by piece count: three pieces 32 x 64 with a temporary accumulator per 32-pixel step (the six
+// products of a step are summed from zero and added once: 0.23-0.5x the fp32-MFMA kernel's distance from an fp64 weight gradient),
+// two pieces 64 x 32 (within noise of the other; same results bit for bit).  Three pieces on tile 0 add every piece product straight
+// into the running accumulator (1.0-2.1x that distance; tests/test_gpu_kernels.py::test_wgrad_full_size_elementwise measures both).
+// Round 6 tried tile 0 as the default for three pieces: the whole golden suite (273 tests) is green on it and on Gaussian operands it
+// is 4-5 % faster (conv3_x 2576 -> 2442 us, tools/conv_bench.py) -- but in the training step, on post-ReLU activations and sparse
+// gradients, the SAME-BOX A/B shows nothing: 0.5406 / 0.5376 / 0.5396 ms per launch with the temporary against 0.5436 / 0.5396 /
+// 0.5443 without, 92.2 ms per step either way (profiles/r06_wgrad_tile_ab.txt).  No speed for the accuracy: the temporary stays.
+int g_scan_wgrad_tile = 2;  // 2 = by piece count
 // scan_tune "wgrad_v6": 1 (default) = the 3x3 launches take the producer / consumer kernel, 0 = conv_wgrad_v4_kernel
 int g_scan_wgrad_v6 = 1;
 // scan_tune "wgrad_prio": 1 = the producer waves run at s_setprio 3, 0 (default) = at the consumers' priority.  Round 3 ran them
@@ -1007,7 +1008,7 @@ static int wgrad3_launch(const float* x, const scan_pyramid_t* d, int32_t Cs, co
       set_lds(conv_wgrad_v6_kernel<NP, WK6, 3, 2, 4>, sh6);
       done = true;
     }
-    if (g_scan_wgrad_tile == 1)
+    if ((g_scan_wgrad_tile == 0 || g_scan_wgrad_tile == 1) ? g_scan_wgrad_tile == 1 : NP == 3)
       hipLaunchKernelGGL((conv_wgrad_v6_kernel<NP, WK6, 3, 2, 4>), dim3(nt * sp), dim3(W6_THREADS), sh6, st, x, *d, Cs, dy, Cout, Cout_s,
                          ws, bias_slab, ct, nt, ctl, cps, sp, g_scan_wgrad_prio);
     else

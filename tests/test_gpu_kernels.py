@@ -736,7 +736,7 @@ def test_wgrad_full_size_elementwise(device, case, mode, monkeypatch):
         monkeypatch.setattr(ops, "CONV_MODE", conv_mode)
         old = _lib.query("scan_tune", b"wgrad_v6", v6)
         dflt = _lib.query("scan_tune_default", b"wgrad_tile")
-        assert dflt == 0, "the shipped default is the 64 x 32 tile (no temporary accumulator), round 6"
+        assert dflt == 2, "the shipped default is 'by piece count': three pieces take the 32 x 64 tile with the temporary accumulator"
         old_tile = _lib.query("scan_tune", b"wgrad_tile", dflt if tile is None else tile)
         try:
             xx = x.clone().requires_grad_(True)
@@ -783,19 +783,20 @@ def test_wgrad_full_size_elementwise(device, case, mode, monkeypatch):
     e, e32 = sampled_err(dw), sampled_err(dw32)
     print("wgrad error vs fp64 (max, rms)", case, mode, e, "fp32-MFMA", e32)
     if mode == "bf16x6":
-        # The shipped default (round 6: scan_tune wgrad_tile = 0, the 64 x 32 consumer tile) adds the six piece products
-        # straight into the running accumulator: correct to the element bar above against the fp32-MFMA kernel and within
-        # 1.0-2.1x (bar 3x) of ITS distance from fp64 -- i.e. an fp32 weight gradient in another summation order, which is all
-        # the contract asks for (the whole golden suite is green on it; profiles/r06_wgrad_tile_ab.txt: 4-5 % faster).
-        assert e[0] <= 1e-5 and e[1] <= 3.0 * e32[1], (e, e32)
-        # wgrad_tile = 1 keeps round 4's temporary accumulator (csrc/conv_wgrad.hip: TCHAIN -- the six products of a 32-pixel
-        # step summed from zero and added once, so a split-K slab's 8,192-pixel chain rounds once per step at the
-        # accumulator's magnitude): no further from fp64 than the exact fp32-MFMA kernel, measured 0.2-0.5x its rms
-        _, _, dw_t1, _ = grads(mode, tile=1)
-        assert float((dw_t1 - dw32).abs().max()) <= 1e-5 * scale
-        e_t1 = sampled_err(dw_t1)
-        print("   wgrad_tile = 1 (temporary accumulator):", e_t1)
-        assert e_t1[0] <= 5e-6 and e_t1[1] <= 1.1 * e32[1] and e_t1[0] <= 1.5 * e32[0] and e_t1[1] <= e[1], (e_t1, e, e32)
+        # no further from fp64 than the exact fp32-MFMA kernel: the six piece products of a 32-pixel step are summed in a
+        # temporary and added to the running accumulator once (csrc/conv_wgrad.hip: TCHAIN), so a split-K slab's 8,192-pixel
+        # chain rounds once per step at the accumulator's magnitude.  Measured 0.2-0.5x the fp32-MFMA kernel's rms
+        # (tools/wgrad_err.py); without the temporary it is 1.0-2.1x
+        assert e[0] <= 5e-6 and e[1] <= 1.1 * e32[1] and e[0] <= 1.5 * e32[0], (e, e32)
+        # scan_tune wgrad_tile = 0 (the 64 x 32 consumer tile) has no temporary: the six products go straight into the running
+        # accumulator -- correct to the same element bar against the fp32-MFMA kernel, an fp32 sum in another order (bar: 3x its
+        # distance from fp64).  Round 6 ran the whole golden suite green on it, found it no faster in the training step
+        # (profiles/r06_wgrad_tile_ab.txt) and left it a knob.
+        _, _, dw_t0, _ = grads(mode, tile=0)
+        assert float((dw_t0 - dw32).abs().max()) <= 1e-5 * scale
+        e_t0 = sampled_err(dw_t0)
+        print("   wgrad_tile = 0 (no temporary accumulator):", e_t0)
+        assert e_t0[0] <= 1e-5 and e_t0[1] <= 3.0 * e32[1] and e_t0[1] >= e[1], (e_t0, e, e32)
     else:
         assert e[0] <= 1e-4, e
     # adjoint identities (bias removed from y), fp64 accumulation on the device

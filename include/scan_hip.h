@@ -60,6 +60,9 @@ int scan_abi_version(void);
  *                 results bit for bit.
  *   "conv_glds"   1 (default): the 128- / 256-channel 3x3 instances stage weight tiles by LDS-DMA (buffer_load ... lds) on
  *                 whole tiles; 0: through registers.  Same results bit for bit.
+ *   "conv1x1"     bf16x6 1x1 convs (FPN laterals, ResNet bottlenecks): bit 0 = weight tiles by LDS-DMA, bit 1 = the 256-channel tile
+ *                 when the output channels fill it without costing a round; 3 (default), 0 = rounds 4-5's 128-channel register-staged
+ *                 instance.  Same results bit for bit.
  *   "wgrad_v6"    1 (default): the 3x3 weight-gradient launches take the producer / consumer kernel (12 waves: 8 issue
  *                 MFMAs, 4 stage); 0: the kernel in which all 8 waves stage and multiply in turn (always used by the 1x1
  *                 convs).  bf16x3: bit-identical; bf16x6: other K-chunk length, i.e. other split-K boundaries.

@@ -25,6 +25,7 @@ extern int g_scan_conv_w8;
 extern int g_scan_conv_tpb3;
 extern int g_scan_conv_bn64_th16;
 extern int g_scan_conv_glds;
+extern int g_scan_conv1x1;
 extern int g_scan_wgrad_v6;
 extern int g_scan_wgrad_prio;
 extern int g_scan_wgrad_tile;
@@ -44,7 +45,7 @@ static Knob* knob_table(int* count) {
       {"conv_w8", &g_scan_conv_w8, 0},         {"conv_tpb3", &g_scan_conv_tpb3, 0},     {"conv_bn64_th16", &g_scan_conv_bn64_th16, 0},
       {"conv_glds", &g_scan_conv_glds, 0},     {"wgrad_v6", &g_scan_wgrad_v6, 0},       {"wgrad_prio", &g_scan_wgrad_prio, 0},
       {"wgrad_tile", &g_scan_wgrad_tile, 0},   {"wgrad_wgs", &g_scan_wgrad_wgs, 0},     {"gconv_mfma", &g_scan_gconv_mfma, 0},
-      {"dbscan_bf16x3", &g_scan_dbscan_bf16x3, 0}, {"reduce_blocks", &g_scan_reduce_blocks, 0},
+      {"dbscan_bf16x3", &g_scan_dbscan_bf16x3, 0}, {"reduce_blocks", &g_scan_reduce_blocks, 0}, {"conv1x1", &g_scan_conv1x1, 0},
   };
   static bool init = false;
   if (!init) {  // the values the library was built with: knobs are only ever written through scan_tune below

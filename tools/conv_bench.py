@@ -34,18 +34,35 @@ SHAPES = [
 ]
 
 
+# 1x1 convs of the ResNet-50 body at the K2C bench shape (4 frames of 1024x2048 in the paired step: C2 at 256x512 ... C5 at 32x64)
+# and the FPN laterals; --ksize 1 selects these
+SHAPES_1X1 = [
+    ("layer1 conv1 256->64 @256x512, 4 frames", 4, [(256, 512)], 256, 64),
+    ("layer1 conv3 64->256 @256x512, 4 frames", 4, [(256, 512)], 64, 256),
+    ("layer2 conv1 512->128 @128x256, 4 frames", 4, [(128, 256)], 512, 128),
+    ("layer2 conv3 128->512 @128x256, 4 frames", 4, [(128, 256)], 128, 512),
+    ("layer3 conv1 1024->256 @64x128, 4 frames", 4, [(64, 128)], 1024, 256),
+    ("layer3 conv3 256->1024 @64x128, 4 frames", 4, [(64, 128)], 256, 1024),
+    ("layer4 conv1 2048->512 @32x64, 4 frames", 4, [(32, 64)], 2048, 512),
+    ("layer4 conv3 512->2048 @32x64, 4 frames", 4, [(32, 64)], 512, 2048),
+    ("FPN lateral 512->256 @128x256, 4 frames", 4, [(128, 256)], 512, 256),
+    ("FPN lateral 2048->256 @32x64, 4 frames", 4, [(32, 64)], 2048, 256),
+]
+KS = 3  # --ksize
+
+
 def run(shape_def, reps, dev):
     name, n, sizes, cin, cout = shape_def
     shape = ops.PyramidShape(n, sizes)
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn((shape.rows, ops.pad4(cin)), device=dev, generator=g)
-    w = (torch.randn((cout, cin, 3, 3), device=dev, generator=g) * 0.05).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, KS, KS), device=dev, generator=g) * 0.05).contiguous(memory_format=torch.channels_last)
     b = torch.randn((cout,), device=dev, generator=g)
-    flops = 2.0 * shape.rows * cout * 9 * cin
+    flops = 2.0 * shape.rows * cout * KS * KS * cin
 
     def fwd():
         with torch.no_grad():
-            return ops.conv2d(x, w, b, shape, 3, 1)
+            return ops.conv2d(x, w, b, shape, KS, 1)
 
     fwd()
     torch.cuda.synchronize()
@@ -64,10 +81,10 @@ def run_dgrad(shape_def, reps, dev):
     shape = ops.PyramidShape(n, sizes)
     g = torch.Generator(device=dev).manual_seed(0)
     x = torch.randn((shape.rows, ops.pad4(cin)), device=dev, generator=g).requires_grad_(True)
-    w = (torch.randn((cout, cin, 3, 3), device=dev, generator=g) * 0.05).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn((cout, cin, KS, KS), device=dev, generator=g) * 0.05).contiguous(memory_format=torch.channels_last)
     dy = torch.randn((shape.rows, cout), device=dev, generator=g)
-    flops = 2.0 * shape.rows * cout * 9 * cin
-    y = ops.conv2d(x, w, None, shape, 3, 1)
+    flops = 2.0 * shape.rows * cout * KS * KS * cin
+    y = ops.conv2d(x, w, None, shape, KS, 1)
 
     def go():
         x.grad = None
@@ -130,11 +147,16 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--variants", default="conv_bn256=0,conv_bn256=1")
+    ap.add_argument("--ksize", type=int, choices=(1, 3), default=3, help="1: the ResNet-50 / FPN 1x1 shapes (fwd, dgrad)")
     a = ap.parse_args()
+    global KS
+    KS = a.ksize
+    if KS == 1 and a.op == "wgrad":
+        raise SystemExit("--ksize 1: fwd and dgrad only")
     dev = torch.device("cuda:0")
     ops.CONV_MODE = a.mode
     print("op %s  mode %s" % (a.op, a.mode), flush=True)
-    shapes = [sd for sd in SHAPES if not a.shapes or any(t in sd[0] for t in a.shapes.split(","))]
+    shapes = [sd for sd in (SHAPES if KS == 3 else SHAPES_1X1) if not a.shapes or any(t in sd[0] for t in a.shapes.split(","))]
     variants = [(v, "") for v in a.variants.split(",")]  # each variant: "key=value" or "key=value+key=value"
     for sd in shapes:
         ref = None
@@ -156,7 +178,7 @@ def main():
                 b.append(us)
                 if rnd == 0 and not torch.equal(ref, y):  # different kernels agree to rounding, not bit for bit
                     line += " [%s differs: max %.2e of %.2e]" % (key, (ref - y).abs().max().item(), ref.abs().max().item())
-        flops = 2.0 * ops.PyramidShape(sd[1], sd[2]).rows * sd[4] * 9 * sd[3]
+        flops = 2.0 * ops.PyramidShape(sd[1], sd[2]).rows * sd[4] * KS * KS * sd[3]
         for (key, val), us in best.items():
             line += "  %s: %s us -> %6.1f TF" % (key, "/".join("%.0f" % u for u in us), flops / min(us) * 1e-6)
         print(line, flush=True)

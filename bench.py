@@ -95,6 +95,8 @@ def symbol_of(name):
     if m:
         np_, bn, ks = (3 if m.group(2) == "6" else 2), int(m.group(4)), (3 if m.group(1) == "3x3" else 1)
         th, nt, tail = (8, 256, "") if bn == 64 else (16, 512, "")
+        if np_ == 3 and ks == 1:  # scan_conv1x1_bf16x6_instance: 1128 / 1256 = LDS-DMA weight tiles (scan_tune conv1x1)
+            return "conv_split_kernel<3,%d,%d,%d,1%s>" % (bn % 1000, 8 if bn == 64 else 16, 256 if bn == 64 else 512, ",1,true" if bn > 1000 else "")
         if np_ == 3:  # three pieces: weight tiles by LDS-DMA on every 3x3 instance (scan_conv3x3_bf16x6_instance)
             if bn in (1064, 2064):
                 return "conv_split_kernel<3,64,%d,512,3,1,true>" % (16 if bn == 1064 else 32)

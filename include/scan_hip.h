@@ -108,6 +108,9 @@ int scan_comm_standin(float* buf, int64_t n_floats, double traffic, int32_t wgs,
 /* Output-channel tile (64, 128 or 256) the bf16x3 3x3 kernel uses for a launch on pyramid d with Nout channels;
  * 1128 / 1256 = the 128- / 256-channel tile on 16-wave workgroups, 2256 = the 256-channel tile on the 8-wave LDS-DMA instance. */
 int scan_conv3x3_bf16x3_instance(const scan_pyramid_t* d, int32_t Nout);
+/* the same for a bf16x6 1x1 launch on output pyramid yd with Nout channels and weight-plane row length Csw: 64 / 128 = register-staged
+ * tiles, 1128 / 1256 = the 128- / 256-channel tile with LDS-DMA weight tiles (scan_tune "conv1x1") */
+int scan_conv1x1_bf16x6_instance(const scan_pyramid_t* yd, int32_t Nout, int32_t Csw);
 
 /* ---- SigmoidFocalLoss  (replaces _C.sigmoid_focalloss_forward / _backward,
  *      csrc/SigmoidFocalLoss.h:10-41, csrc/cuda/SigmoidFocalLoss_cuda.cu:20-187) ----

@@ -61,6 +61,7 @@ SIGNATURES = {
     "scan_tune_key": (ctypes.c_char_p, [ctypes.c_int]),
     "scan_mfma_sustained_bf16": (ctypes.c_int, [ctypes.c_double, c_i32, ctypes.POINTER(ctypes.c_double), c_vp]),
     "scan_conv3x3_bf16x3_instance": (ctypes.c_int, [_PD, c_i32]),
+    "scan_conv1x1_bf16x6_instance": (ctypes.c_int, [_PD, c_i32, c_i32]),
     "scan_conv3x3_bf16x6_instance": (ctypes.c_int, [_PD, c_i32]),
     "scan_sigmoid_focal_loss_forward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp, c_vp]),
     "scan_sigmoid_focal_loss_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_f32, c_i64, c_i32, c_f32, c_f32, c_vp, c_vp]),

@@ -729,12 +729,30 @@ int conv3x3_split_launch(int np, const float* x, const scan_pyramid_t* d, int32_
   return 0;
 }
 
+// instance of a three-piece 1x1 launch: 64 / 128 = the register-staged tiles, 1128 / 1256 = the 128- / 256-channel tile with LDS-DMA weights
+static int conv1x1_instance3(const scan_pyramid_t* yd, int32_t Nout, int32_t Csw);
 // scan_tune "conv1x1" (three pieces): bit 0 = the 1x1 instances stage their weight tiles by LDS-DMA (whole K chunks), bit 1 = the
 // 256-channel tile when the channels fill it and it does not cost a round of 256 CUs.  Default 3 (round 6).  Same results bit for bit
 // (tools/conv_bench.py --ksize 1 --variants conv1x1=0,conv1x1=1,conv1x1=3, ResNet-50 body + FPN laterals at the K2C bench shape, us):
 // forward 64 -> 256 @256x512 259 -> 217, 128 -> 512 172 -> 146, 256 -> 1024 120 -> 108, 512 -> 2048 111 -> 95, lateral 512 -> 256 225 -> 181;
 // data gradient 256 -> 64 267 -> 213, 512 -> 128 166 -> 136, 1024 -> 256 111 -> 96, 2048 -> 512 98 -> 84, lateral 259 -> 202; Cout <= 128: +- 2 %.
 int g_scan_conv1x1 = 3;
+static int conv1x1_instance3(const scan_pyramid_t* yd, int32_t Nout, int32_t Csw) {
+  if (Nout <= 64) return 64;
+  if (!((g_scan_conv1x1 & 1) && Csw % 32 == 0)) return 128;
+  if ((g_scan_conv1x1 & 2) && Nout % 256 == 0) {
+    TileTab2 tt;
+    make_tiles_v2(yd, &tt, 16);
+    const int64_t tiles = tt.tile_off[yd->n_levels];
+    const int64_t r256 = (tiles * (Nout / 256) + 255) / 256 * 2, r128 = (tiles * (Nout / 128) + 255) / 256;
+    if (r256 * 97 <= r128 * 100) return 1256;
+  }
+  return 1128;
+}
+extern "C" int scan_conv1x1_bf16x6_instance(const scan_pyramid_t* yd, int32_t Nout, int32_t Csw) {
+  return yd ? conv1x1_instance3(yd, Nout, Csw) : -1;
+}
+
 int conv1x1_split_launch(int np, const float* x, const scan_pyramid_t* xd, int32_t Cs, const void* w0, const void* w1,
                          const void* w2, int32_t Csw, const float* bias, const float* mask, float* y,
                          const scan_pyramid_t* yd, int32_t Nout, int32_t Ns, int32_t relu, int32_t map, void* stream) {
@@ -743,15 +761,8 @@ int conv1x1_split_launch(int np, const float* x, const scan_pyramid_t* xd, int32
   // scan_tune "conv1x1": bit 0 = weight tiles by LDS-DMA (whole K chunks: Csw % 32 == 0), bit 1 = the 256-channel tile when the
   // channels fill it and it does not cost a round of 256 CUs (the 3x3 rule, v2_instance).  1x1 convs are a sliver of the VGG step (FPN
   // laterals) but a fifth of the ResNet-50 body's (BASELINE.json configs[3]: bottleneck conv1 / conv3 / downsample).
-  const bool gl = (g_scan_conv1x1 & 1) && Csw % 32 == 0;
-  bool wide = false;
-  if ((g_scan_conv1x1 & 2) && gl && Nout % 256 == 0) {
-    TileTab2 tt;
-    make_tiles_v2(yd, &tt, 16);
-    const int64_t tiles = tt.tile_off[yd->n_levels];
-    const int64_t r256 = (tiles * (Nout / 256) + 255) / 256 * 2, r128 = (tiles * (Nout / 128) + 255) / 256;
-    wide = r256 * 97 <= r128 * 100;
-  }
+  const int inst = np == 3 ? conv1x1_instance3(yd, Nout, Csw) : (Nout <= 64 ? 64 : 128);
+  const bool wide = inst == 1256, gl = inst >= 1000;
   if (np == 3) {
     if (Nout <= 64)
       launch_v2<3, 64, 8, 256, 1>(a);

@@ -414,7 +414,12 @@ def _conv_split(x, shape, wp, cout, rows_out, cs_src, mode, bias, relu, ns, name
     wptrs = [_ptr(t) for t in planes]
     y = out if out is not None else (x.new_zeros if ns != nout else x.new_empty)((rows_out, ns))
     if kernel_timer.enabled:  # label the record with the template instance the launch takes (64 / 128 / 256 channels)
-        inst = query("scan_conv3x3_%s_instance" % sfx, (dst_shape or shape).ref(), nout) if T == 9 else (128 if nout > 64 else 64)
+        if T == 9:
+            inst = query("scan_conv3x3_%s_instance" % sfx, (dst_shape or shape).ref(), nout)
+        elif npc == 3:
+            inst = query("scan_conv1x1_bf16x6_instance", (dst_shape or shape).ref(), nout, csw)
+        else:
+            inst = 128 if nout > 64 else 64
         ev = kernel_timer.begin("%s_bn%d" % (name, inst), flops)
     else:
         ev = None

@@ -354,6 +354,7 @@ class Trainer:
         if hasattr(model["backbone"], "record_grad_marks"):
             model["backbone"].record_grad_marks = bool(self.distributed)
         self._pending = []
+        self._seeds = {}
         self._bucket_list = None
         self._issued, self._ready = 0, set()
         self.collective_log = []  # (lo, hi) of every gradient all-reduce issued, in order (tests; cleared per step)
@@ -598,6 +599,21 @@ class Trainer:
             main.wait_stream(side)
         return ld
 
+    def _backward_terms(self, terms):
+        """backward of sum_i w_i * t_i without forming the sum: every term is a root of ONE autograd pass seeded with its weight
+        (a cached 0-dim constant).  Same gradients as (sum_i w_i * t_i).backward() -- the seeds are the exact partial
+        derivatives -- and the same node order (the engine orders by creation sequence whatever the roots)."""
+        roots, seeds = [], []
+        for t, w in terms:
+            if t.requires_grad:
+                key = (str(t.device), float(w))
+                sd = self._seeds.get(key)
+                if sd is None:
+                    sd = self._seeds[key] = torch.full((), float(w), device=t.device)
+                roots.append(t)
+                seeds.append(sd)
+        torch.autograd.backward(roots, seeds)
+
     def _join_streams(self):
         """Backward kernels that accumulate straight into the flat gradient buffers run on the stream of their
         forward op and bypass autograd's AccumulateGrad (and with it the engine's end-of-backward stream sync):
@@ -739,6 +755,7 @@ class Trainer:
         # as one node per tensor whose backward scales each level's gradient straight into its rows
         lams = [model["dis_%s_CON" % lvl].grad_reverse.lambda_ for lvl in LEVELS]
         f, a = ops.split_levels_grl(feats, shape, lams), ops.split_levels_grl(maps, shape, lams)
+        adv_names, adv_raw = [], []
         for lvl in DIS_ORDER:
             i = LEVELS.index(lvl)
             side = self.dis_streams.get(lvl)
@@ -746,12 +763,20 @@ class Trainer:
                 side.wait_stream(main)
             with torch.cuda.stream(side if side is not None else main):
                 ls, lt = model["dis_%s_CON" % lvl].forward_pair(f[i], a[i], shape.level(i), B, grl_applied=True)
-                losses["loss_adv_%s_CON_ds" % lvl] = lam * ls
-                losses["loss_adv_%s_CON_dt" % lvl] = lam * lt
+                adv_names += ["loss_adv_%s_CON_ds" % lvl, "loss_adv_%s_CON_dt" % lvl]
+                adv_raw += [ls, lt]
         for side in self.dis_streams.values():
             main.wait_stream(side)
         if fstream is not None:
             main.wait_stream(fstream)
+        # the ten adversarial terms enter the objective as con_dis_lambda * loss (trainer.py:314-333,373-376).  The reported values
+        # are formed in two launches (stack, scale) instead of ten, and the backward is seeded per term (_backward_terms) instead
+        # of walking mul / add nodes of a summed scalar: 26 forward and 11 backward launches of one element each less, same
+        # products bit for bit (lam * loss; d(lam * loss) = lam).
+        terms = [(v, 1.0) for v in losses.values()] + [(v, lam) for v in adv_raw]
+        scaled = torch.stack([v.detach() for v in adv_raw]) * lam
+        for n, v in zip(adv_names, scaled.unbind(0)):
+            losses[n] = v
         if self.distributed:
             # the backward reaches `feats` (and `maps`) only after every consumer -- the five discriminators and the
             # FCOS head -- has back-propagated: their gradient buffers (114 of the 199 MB) are final then and are
@@ -775,7 +800,7 @@ class Trainer:
                 self._hook_ready(rows, "middle_head")
             self._hook_backbone_marks()
         self._mark("mid")
-        sum(losses.values()).backward()
+        self._backward_terms(terms)
         self._join_streams()
         losses["zero_gt"] = feats.new_zeros(())
         self._flush_buckets()
@@ -833,7 +858,7 @@ class Trainer:
         # the same accumulated .grad and walks the shared backbone / middle-head graph once instead of twice.
         ld = self._discriminators(feat_s, maps_s, shape, 1.0, "source", "ds")
         if self.merge_source_backward:
-            (sum(loss_dict.values()) + sum(ld.values())).backward()
+            self._backward_terms([(v, 1.0) for v in loss_dict.values()] + [(v, 1.0) for v in ld.values()])
         else:
             sum(loss_dict.values()).backward(retain_graph=True)
             sum(ld.values()).backward()
@@ -874,7 +899,7 @@ class Trainer:
                     else:
                         pending["n"] -= 1
             self._hook_backbone_marks()
-        sum(v for k, v in ld.items() if k != "zero_gt").backward()
+        self._backward_terms([(v, 1.0) for k, v in ld.items() if k != "zero_gt"])
         self._join_streams()
         out.update(ld)
         self._flush_buckets()

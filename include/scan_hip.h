@@ -167,6 +167,16 @@ int scan_cka_bce_backward_loss(const float* logits, const float* act, int64_t M,
 /* ---- y = alpha * x  (GradientReversalFunction: forward alpha = 1 copy, backward alpha = -lambda;
  *      discriminator/layer.py:6-24) ---- */
 int scan_scale(const float* x, float alpha, float* y, int64_t n, void* stream);
+/* dst[r][c] = src[r][c] for c < ncols, zeros for ncols <= c < ncols + ztail; row pitches ld_src / ld_dst in floats (callers
+ * offset the pointers to the first column).  Replaces the torch-tier spellings of F.pad(act_maps, (0, 3)) in front of head_out's
+ * act-map share (rpn/fcos/condgraph.py:344-362: cat(features, act_maps)) and of cat(x, act_maps[:, 1:]) in front of the class
+ * branches (discriminator/fcos_head_discriminator_con.py:104-118). */
+int scan_copy_cols(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int64_t M, int32_t ncols, int32_t ztail,
+                   void* stream);
+/* GRAPHModule.update_prototype_nx1_rnn with COSINE_UPDATE_ON (rpn/fcos/condgraph.py:586-606) on the paradigm buffer P [K][C][T]
+ * in place: slot = it - 1 if it == T else it; m = cosine_similarity(P[:, :, slot], pb); P[:, :, slot] <- cur * m + pb * (1 - m) for the
+ * classes whose batch mean pb [K][C] is not all zero; it == T shifts the slots down by one first.  C <= 1024. */
+int scan_paradigm_update(float* P, const float* pb, int32_t K, int32_t C, int32_t T, int32_t it, void* stream);
 
 /* ---- semantic-conditioned dynamic 1x1 conv + channel softmax
  *      (replaces GRAPHModule.dynamic_conv + softmax, rpn/fcos/condgraph.py:619-629, 344-346) ----

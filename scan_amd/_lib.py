@@ -74,6 +74,8 @@ SIGNATURES = {
     "scan_cka_bce_forward_loss": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp]),
     "scan_cka_bce_backward_loss": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_f32, c_vp, c_vp, c_vp, c_vp]),
     "scan_scale": (ctypes.c_int, [c_vp, c_f32, c_vp, c_i64, c_vp]),
+    "scan_copy_cols": (ctypes.c_int, [c_vp, c_i32, c_vp, c_i32, c_i64, c_i32, c_i32, c_vp]),
+    "scan_paradigm_update": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "scan_dynconv_softmax_forward": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "scan_dynconv_ws_floats": (c_i64, [c_i64, c_i32, c_i32]),
     "scan_dynconv_softmax_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),

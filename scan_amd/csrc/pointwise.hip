@@ -1040,3 +1040,89 @@ extern "C" int scan_take_images_backward(const float* g, const scan_pyramid_t* d
   SCAN_LAUNCH_CHECK("take_images_backward");
   return 0;
 }
+
+// ---- column block copy between row matrices of different row pitch (round 6): dst[r][dc0 + c] = src[r][sc0 + c] for c < ncols,
+// and zeros in dst columns [dc0 + ncols, dc0 + ncols + ztail).  What the torch tier spelled as F.pad of the [M, 9] act maps to
+// [M, 12] (a fill plus a narrow strided copy, and a strided slice copy back in the backward) and as buf[:, C:C + e] = extra in
+// front of the class branches: one coalesced pass each here.
+__global__ __launch_bounds__(256) void copy_cols_kernel(const float* __restrict__ src, int ld_src, float* __restrict__ dst,
+                                                        int ld_dst, int64_t M, int ncols, int ztail) {
+  const int w = ncols + ztail;
+  const int64_t total = M * (int64_t)w;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = e / w;
+    const int c = (int)(e - r * w);
+    dst[r * ld_dst + c] = c < ncols ? src[r * ld_src + c] : 0.f;
+  }
+}
+
+extern "C" int scan_copy_cols(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int64_t M, int32_t ncols,
+                              int32_t ztail, void* stream) {
+  SCAN_CHECK_ARG(M >= 0 && ncols >= 0 && ztail >= 0 && ld_src >= ncols && ld_dst >= ncols + ztail,
+                 "copy_cols: bad arguments (M=%lld ncols=%d ztail=%d ld_src=%d ld_dst=%d)", (long long)M, ncols, ztail, ld_src, ld_dst);
+  if (M == 0 || ncols + ztail == 0) return 0;
+  SCAN_CHECK_ARG(src && dst, "copy_cols: null pointer");
+  hipLaunchKernelGGL(copy_cols_kernel, dim3(grid_for(M * (int64_t)(ncols + ztail), 256)), dim3(256), 0, as_stream(stream), src,
+                     ld_src, dst, ld_dst, M, ncols, ztail);
+  SCAN_LAUNCH_CHECK("copy_cols");
+  return 0;
+}
+
+// ---- paradigm (prototype) update of the middle head, reference condgraph.py:586-606 with COSINE_UPDATE_ON (round 6: one launch
+// instead of ~25 one-row torch launches on the step's critical small-kernel stretch).  P [K][C][T] (slot t of class k, channel c
+// at (k * C + c) * T + t), pb [K][C] the batch's class means (zero rows: class not seen).  it = the paradigm counter's value:
+//   slot = it - 1 if it == T else it;   cur = P[:, :, slot]
+//   m    = cosine_similarity(cur, pb, dim = 1, eps = 1e-8)      (rows normalised first, like torch: x / max(||x||, eps))
+//   upd  = pb.sum(1) != 0 ? cur * m + pb * (1 - m) : cur
+//   it == T: slots 0 .. T-2 <- slots 1 .. T-1;   P[:, :, slot] = upd
+// One workgroup per class, C <= 1024 channels over 256 threads.
+__global__ __launch_bounds__(256) void paradigm_update_kernel(float* __restrict__ P, const float* __restrict__ pb, int C, int T,
+                                                              int it) {
+  __shared__ float red[4];
+  const int k = blockIdx.x;
+  const int slot = it == T ? it - 1 : it;
+  float cur[4], b[4];
+  float s_cc = 0.f, s_bb = 0.f, s_b = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = threadIdx.x + 256 * j;
+    cur[j] = c < C ? P[((int64_t)k * C + c) * T + slot] : 0.f;
+    b[j] = c < C ? pb[(int64_t)k * C + c] : 0.f;
+    s_cc += cur[j] * cur[j];
+    s_bb += b[j] * b[j];
+    s_b += b[j];
+  }
+  auto bsum = [&](float v) {
+    float r = block_sum_256(v, red);
+    __shared__ float bc;
+    if (threadIdx.x == 0) bc = r;
+    __syncthreads();
+    r = bc;
+    __syncthreads();
+    return r;
+  };
+  const float n_c = fmaxf(sqrtf(bsum(s_cc)), 1e-8f), n_b = fmaxf(sqrtf(bsum(s_bb)), 1e-8f);
+  const bool exist = bsum(s_b) != 0.f;
+  float dotp = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) dotp += (cur[j] / n_c) * (b[j] / n_b);
+  const float m = bsum(dotp);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = threadIdx.x + 256 * j;
+    if (c >= C) continue;
+    float* row = P + ((int64_t)k * C + c) * T;
+    const float upd = exist ? cur[j] * m + b[j] * (1.f - m) : cur[j];
+    if (it == T)
+      for (int t = 0; t + 1 < T; ++t) row[t] = row[t + 1];
+    row[slot] = upd;
+  }
+}
+
+extern "C" int scan_paradigm_update(float* P, const float* pb, int32_t K, int32_t C, int32_t T, int32_t it, void* stream) {
+  SCAN_CHECK_ARG(P && pb && K >= 1 && C >= 1 && C <= 1024 && T >= 1 && it >= 0 && it <= T,
+                 "paradigm_update: bad arguments (K=%d C=%d T=%d it=%d)", K, C, T, it);
+  hipLaunchKernelGGL(paradigm_update_kernel, dim3(K), dim3(256), 0, as_stream(stream), P, pb, C, T, it);
+  SCAN_LAUNCH_CHECK("paradigm_update");
+  return 0;
+}

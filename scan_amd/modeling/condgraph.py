@@ -111,6 +111,7 @@ def sim_matrix(a, b, eps=1e-8):
     return torch.mm(a / torch.clamp(a_n, min=eps), (b / torch.clamp(b_n, min=eps)).transpose(0, 1))
 
 
+FUSED_PARADIGM_UPDATE = True  # False: the torch spelling of update_prototype_nx1_rnn also on the GPU (cross-checks)
 DBSCAN_BACKEND = "device"  # "host": sklearn on the host cores, the reference's own call (kept for cross-checks)
 # MEASUREMENT ONLY (bench.py --ft-positives, SURVEY.md 8d "second series"): a random-init model's act maps are nearly
 # uniform, so EVERY (pixel, class) entry passes the 0.05 threshold and the clustering sees 100 % of the entries -- a
@@ -266,8 +267,14 @@ class GRAPHModule(nn.Module):
         # synchronisation per use (nonzero) in the middle of the forward pass -- the host then cannot enqueue ahead and
         # the GPU idles through the small-kernel tier that follows.  Row-wise arithmetic on ALL classes and a masked
         # select give the same rows: cosine_similarity works row by row, absent classes (pb = 0) keep their old value.
-        exist = pb.sum(-1).bool()[:, None]
         P = self.prototype
+        if P.is_cuda and P.dtype == torch.float32 and P.is_contiguous() and P.shape[1] <= 1024 and FUSED_PARADIGM_UPDATE:
+            # the rest of this function as ONE launch (csrc/pointwise.hip: paradigm_update_kernel) instead of ~25 one-row torch
+            # launches on the critical small-kernel stretch of the step
+            ops.call("scan_paradigm_update", ops._ptr(P), ops._ptr(pb.contiguous().float()), P.shape[0], P.shape[1], P.shape[2],
+                     int(it), ops._stream())
+            return
+        exist = pb.sum(-1).bool()[:, None]
         slot = it - 1 if it == self.prototype_iter else it
         cur = P[:, :, slot]
         m = F.cosine_similarity(cur, pb).unsqueeze(1)
@@ -316,7 +323,7 @@ class GRAPHModule(nn.Module):
             main, main_stream = main
             conv = self.head_out.middle_tower[0]
             C, K = feats.shape[1], maps.shape[1]
-            thin_in = maps if K % 4 == 0 else F.pad(maps, (0, ops.pad4(K) - K))
+            thin_in = ops.pad_cols(maps, ops.pad4(K))  # [M, 9] -> [M, 12], zero tail, one pass
             thin = ops.conv2d(thin_in, conv.weight[:, C:C + K], None, shape, 3, 1)
             if main_stream is not None:
                 torch.cuda.current_stream().wait_stream(main_stream)

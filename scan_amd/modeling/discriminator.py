@@ -110,5 +110,8 @@ class FCOSDiscriminator_con(nn.Module):
         logits, act_maps = self._logits(feature, act_maps, shape, grl_applied)
         (h, w) = shape.sizes[0]
         m = n_src * h * w
+        if self.num_classes > 1 and 0 < m < logits.shape[0]:
+            # both domain losses as one node: its backward writes the two halves of ONE gradient buffer (ops.cka_bce_pair)
+            return ops.cka_bce_pair(logits, act_maps.detach(), m, self.num_classes)
         ls, lt = ops.split_rows2(logits, m)  # one gradient buffer in the backward instead of two zero-filled ones + an add
         return self._loss(ls, act_maps[:m], 1.0), self._loss(lt, act_maps[m:], 0.0)

@@ -954,9 +954,14 @@ class _CatInto(torch.autograd.Function):
         C, e = y.shape[1], extra.shape[1]
         if y.data_ptr() != buf.data_ptr() or y.stride(0) != buf.shape[1] or C + e > buf.shape[1]:
             raise RuntimeError("cat_into: y must be the leading columns of buf")
-        buf[:, C:C + e] = extra
-        if C + e < buf.shape[1]:
-            buf[:, C + e:] = 0
+        if buf.is_cuda and extra.dtype == torch.float32 and extra.stride(1) == 1:
+            # one coalesced pass (scan_copy_cols): the e columns + the zero tail (torch: a strided slice copy + a fill)
+            call("scan_copy_cols", _ptr(extra), extra.stride(0), ctypes.c_void_p(buf.data_ptr() + 4 * C), buf.shape[1],
+                 buf.shape[0], e, buf.shape[1] - C - e, _stream())
+        else:
+            buf[:, C:C + e] = extra
+            if C + e < buf.shape[1]:
+                buf[:, C + e:] = 0
         ctx.cols = (C, e)
         # a fresh tensor object over buf's storage: to autograd the result is not a view of an input
         return torch.empty(0, dtype=buf.dtype, device=buf.device).set_(buf.untyped_storage(), buf.storage_offset(),
@@ -970,6 +975,30 @@ class _CatInto(torch.autograd.Function):
 
 def cat_into(y, extra, buf):
     return _CatInto.apply(y, extra, buf)
+
+
+class _PadCols(torch.autograd.Function):
+    """[M, K] -> [M, cs] with zero columns behind (F.pad(x, (0, cs - K))) in one pass; backward: the first K columns."""
+
+    @staticmethod
+    def forward(ctx, x, cs):
+        _chk(x)
+        M, K = x.shape
+        ctx.k = K
+        y = x.new_empty((M, cs))
+        call("scan_copy_cols", _ptr(x), K, _ptr(y), cs, M, K, cs - K, _stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        d = g.new_empty((g.shape[0], ctx.k))
+        call("scan_copy_cols", _ptr(g), g.shape[1], _ptr(d), ctx.k, g.shape[0], ctx.k, 0, _stream())
+        return d, None
+
+
+def pad_cols(x, cs):
+    return x if x.shape[1] == cs else _PadCols.apply(x, int(cs))
 
 
 # ----------------------------------------------------------------------------- dynamic conv + softmax
@@ -1142,6 +1171,44 @@ class _CkaBce(torch.autograd.Function):
             call("scan_cka_bce_backward_loss", _ptr(logits), _ptr(act), logits.shape[0], cf, target,
                  _ptr(g.reshape(1).contiguous()), _ptr(out), _ptr(d), _stream())
         return d, None, None, None
+
+
+class _CkaBcePair(torch.autograd.Function):
+    """the two domain losses of one level in the paired step -- rows [0, m) against label 1 (source), rows [m, M) against label 0
+    (target), each with its own act-map normaliser (_CkaBce on the two halves) -- with ONE gradient buffer: the two backward
+    launches write their halves of d_logits directly (split_rows2 + two _CkaBce nodes: two buffers + two copies per level)."""
+
+    @staticmethod
+    def forward(ctx, logits, act, m, cf):
+        _chk(logits, act)
+        M = logits.shape[0]
+        assert logits.shape[1] == cf and act.shape[1] == cf + 1 and 0 < m < M
+        outs = []
+        for lo, hi, target in ((0, m, 1.0), (m, M, 0.0)):
+            out = _zeros_f32(2 * cf + 2, logits.device)
+            call("scan_cka_bce_forward_loss", _ptr(logits[lo:hi]), _ptr(act[lo:hi]), hi - lo, cf, target, _ptr(out), _stream())
+            outs.append(out)
+        ctx.save_for_backward(logits, act, outs[0], outs[1])
+        ctx.cfg = (m, cf)
+        return outs[0][2 * cf + 1], outs[1][2 * cf + 1]
+
+    @staticmethod
+    def backward(ctx, gs, gt):
+        logits, act, out_s, out_t = ctx.saved_tensors
+        m, cf = ctx.cfg
+        M = logits.shape[0]
+        d = torch.empty_like(logits)
+        for lo, hi, target, g, out in ((0, m, 1.0, gs, out_s), (m, M, 0.0, gt, out_t)):
+            if g is None:
+                d[lo:hi].zero_()
+            else:
+                call("scan_cka_bce_backward_loss", _ptr(logits[lo:hi]), _ptr(act[lo:hi]), hi - lo, cf, target,
+                     _ptr(g.reshape(1).contiguous()), _ptr(out), _ptr(d[lo:hi]), _stream())
+        return d, None, None, None
+
+
+def cka_bce_pair(logits, act_detached, m, cf):
+    return _CkaBcePair.apply(logits.contiguous(), act_detached.contiguous(), int(m), int(cf))
 
 
 class _SplitRows2(torch.autograd.Function):

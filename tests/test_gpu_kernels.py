@@ -1927,3 +1927,54 @@ def test_take_images_backward_one_pass(device, C, i0, i1):
     x.grad = None
     ref.backward(g)
     assert torch.equal(got, x.grad)
+
+
+def test_round6_glue_kernels_equal_their_torch_spellings(device):
+    """scan_copy_cols (F.pad of the act maps / the class-branch cat), scan_paradigm_update (condgraph.update_prototype_nx1_rnn) and
+    the paired CKA loss node against the torch-tier spellings they replace."""
+    from scan_amd import ops, synth
+    from scan_amd.modeling import condgraph
+    torch.manual_seed(9)
+    # (a) pad_cols forward / backward == F.pad / its slice
+    x = torch.randn(1000, 9, device=device, requires_grad=True)
+    y = ops.pad_cols(x, 12)
+    assert torch.equal(y, F.pad(x.detach(), (0, 3)))
+    g = torch.randn(1000, 12, device=device)
+    y.backward(g)
+    assert torch.equal(x.grad, g[:, :9])
+    # (b) cat_into: the extra columns + zero tail behind a tower output that already sits in the buffer
+    buf = torch.randn(500, 268, device=device)
+    keep = buf[:, :256].clone()
+    yv = buf[:, :256]
+    extra = torch.randn(500, 9, device=device)
+    out = ops.cat_into(yv, extra[:, 1:], buf)
+    assert torch.equal(out[:, :256], keep) and torch.equal(out[:, 256:264], extra[:, 1:]) and float(out[:, 264:].abs().max()) == 0.0
+    # (c) the paradigm update, every counter value incl. the shifting one, with unseen classes (zero rows)
+    mh_a, mh_b = condgraph.GRAPHModule(256, 9).to(device), condgraph.GRAPHModule(256, 9).to(device)
+    sd = synth.middle_head_state_dict(9)
+    mh_a.load_state_dict(sd)
+    mh_b.load_state_dict(sd)
+    for it in range(6):
+        pb = torch.randn(9, 256, device=device)
+        pb[(it + 2) % 9] = 0
+        pb[7] = 0
+        condgraph.FUSED_PARADIGM_UPDATE = True
+        mh_a.update_prototype_nx1_rnn(pb)
+        condgraph.FUSED_PARADIGM_UPDATE = False
+        try:
+            mh_b.update_prototype_nx1_rnn(pb)
+        finally:
+            condgraph.FUSED_PARADIGM_UPDATE = True
+        np.testing.assert_allclose(mh_a.prototype.cpu().numpy(), mh_b.prototype.cpu().numpy(), rtol=2e-6, atol=2e-6, err_msg=str(it))
+    # (d) the paired CKA loss == the two single losses on the halves, values and gradient bit for bit
+    M, m, cf = 3000, 1400, 8
+    logits = torch.randn(M, cf, device=device)
+    act = torch.rand(M, cf + 1, device=device)
+    l1 = logits.clone().requires_grad_(True)
+    ls, lt = ops.cka_bce_pair(l1, act, m, cf)
+    (0.3 * ls + 0.7 * lt).backward()
+    l2 = logits.clone().requires_grad_(True)
+    a, b = ops.split_rows2(l2, m)
+    rs, rt = ops.cka_bce(a, act[:m], 1.0, cf), ops.cka_bce(b, act[m:], 0.0, cf)
+    (0.3 * rs + 0.7 * rt).backward()
+    assert torch.equal(ls, rs) and torch.equal(lt, rt) and torch.equal(l1.grad, l2.grad)

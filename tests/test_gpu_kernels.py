@@ -1958,13 +1958,14 @@ def test_round6_glue_kernels_equal_their_torch_spellings(device):
         pb = torch.randn(9, 256, device=device)
         pb[(it + 2) % 9] = 0
         pb[7] = 0
-        condgraph.FUSED_PARADIGM_UPDATE = True
-        mh_a.update_prototype_nx1_rnn(pb)
-        condgraph.FUSED_PARADIGM_UPDATE = False
+        old = condgraph.FUSED_PARADIGM_UPDATE
         try:
+            condgraph.FUSED_PARADIGM_UPDATE = True
+            mh_a.update_prototype_nx1_rnn(pb)
+            condgraph.FUSED_PARADIGM_UPDATE = False
             mh_b.update_prototype_nx1_rnn(pb)
         finally:
-            condgraph.FUSED_PARADIGM_UPDATE = True
+            condgraph.FUSED_PARADIGM_UPDATE = old
         np.testing.assert_allclose(mh_a.prototype.cpu().numpy(), mh_b.prototype.cpu().numpy(), rtol=2e-6, atol=2e-6, err_msg=str(it))
     # (d) the paired CKA loss == the two single losses on the halves, values and gradient bit for bit
     M, m, cf = 3000, 1400, 8

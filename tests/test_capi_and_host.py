@@ -494,3 +494,29 @@ def test_split_rows2_backward_equals_two_slices():
     assert torch.equal(a, x[:4]) and torch.equal(b, x[4:])
     b.sum().backward()
     assert torch.equal(x.grad, torch.cat([torch.zeros(4, 3), torch.ones(3, 3)]))
+
+
+def test_seeded_multi_root_backward_equals_backward_of_the_weighted_sum():
+    """engine.Trainer._backward_terms (round 6): the loss terms as roots of ONE autograd pass, each seeded with its weight, leave
+    bit-identical gradients to (sum_i w_i * t_i).backward() -- on a graph with shared trunks, repeated weights and a term without
+    a gradient (the zero `consistency_loss_gt` of a rank that sampled no target node)."""
+    import torch
+    from scan_amd import engine
+    trainer = engine.Trainer(engine.build_model(9, device="cpu"))
+    torch.manual_seed(0)
+    w1, w2, w3 = (torch.randn(16, 16, requires_grad=True) for _ in range(3))
+    x = torch.randn(8, 16)
+
+    def terms():
+        h = torch.tanh(x @ w1)                      # shared trunk
+        a, b = (h @ w2).square().mean(), (h @ w3).abs().mean()
+        c = (torch.relu(h @ w2) @ w3).sum() * 1e-3  # touches w2 and w3 again
+        return [(a, 1.0), (b, 0.1), (c, 0.1), (torch.zeros(()), 1.0), (h.mean(), 1.0)]
+
+    sum(w * t for t, w in terms()).backward()
+    ref = [p.grad.clone() for p in (w1, w2, w3)]
+    for p in (w1, w2, w3):
+        p.grad = None
+    trainer._backward_terms(terms())
+    for p, r in zip((w1, w2, w3), ref):
+        assert torch.equal(p.grad, r)

@@ -575,19 +575,42 @@ def main():
                 dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % _free_port(), rank=0, world_size=1,
                                         device_id=dev)
                 tr_dp = engine.Trainer(model, settings=mcfg, distributed=True)
+
+                def use(tr):  # the two trainers share the model: per-trainer stream roles live in model / ops attributes
+                    model["middle_head"].out_stream = tr.out_stream
+                    ops.WGRAD_STREAM = tr.wgrad_stream
+
+                def timed(tr, n, reduce):
+                    use(tr)
+                    for _ in range(2):
+                        ls_ = tr.step(imgs_s, tg, imgs_t)
+                        if reduce:
+                            comm.reduce_loss_dict(ls_)
+                    torch.cuda.synchronize()
+                    t0_ = time.time()
+                    for _ in range(n):
+                        ls_ = tr.step(imgs_s, tg, imgs_t)
+                        if reduce:
+                            comm.reduce_loss_dict(ls_)
+                    torch.cuda.synchronize()
+                    return (time.time() - t0_) / n
+
+                # A B A B in this leg, minutes after the headline region: the difference to the PLAIN step of the same leg is the
+                # figure (the process has warmed up since the headline; box drift is 1-2 % over a run)
+                n_half = max(3, a.steps // 2)
+                t_plain, t_dp = [], []
                 for _ in range(2):
-                    comm.reduce_loss_dict(tr_dp.step(imgs_s, tg, imgs_t))
-                torch.cuda.synchronize()
-                t0d = time.time()
-                for _ in range(a.steps):
-                    comm.reduce_loss_dict(tr_dp.step(imgs_s, tg, imgs_t))
-                torch.cuda.synchronize()
-                dtd = (time.time() - t0d) / a.steps
-                dp1 = {"ms_per_step": round(dtd * 1e3, 2), "pairs_per_s": round(B / dtd, 4), "steps": a.steps,
+                    t_plain.append(timed(trainer, n_half, False))
+                    t_dp.append(timed(tr_dp, n_half, True))
+                dtd, dtp = sum(t_dp) / 2, sum(t_plain) / 2
+                dp1 = {"ms_per_step": round(dtd * 1e3, 2), "pairs_per_s": round(B / dtd, 4), "steps": 2 * n_half,
+                       "plain_ms_same_leg": round(dtp * 1e3, 2), "delta_ms": round((dtd - dtp) * 1e3, 2),
+                       "blocks_ms": {"plain": [round(t * 1e3, 2) for t in t_plain], "dp1": [round(t * 1e3, 2) for t in t_dp]},
                        "collective_backend": dist.get_backend(), "ranks_in_process_group": dist.get_world_size(),
                        "gradient_allreduces_per_step": len(tr_dp.collective_log), "dp_policy": tr_dp.dp_policy,
                        "streams": "comm = side stream s2 (no fifth stream), head_out share on s1",
-                       "note": "same step through engine.Trainer(distributed=True) on a one-rank RCCL group"}
+                       "note": "same step through engine.Trainer(distributed=True) on a one-rank RCCL group, alternating with the plain "
+                               "step in the same leg (A B A B): delta_ms is the data-parallel machinery's cost at one rank"}
                 ops.WGRAD_STREAM = trainer.wgrad_stream
                 model["middle_head"].out_stream = trainer.out_stream
                 note("one-rank RCCL leg %.1f ms" % dp1["ms_per_step"])

@@ -520,3 +520,34 @@ def test_seeded_multi_root_backward_equals_backward_of_the_weighted_sum():
     trainer._backward_terms(terms())
     for p, r in zip((w1, w2, w3), ref):
         assert torch.equal(p.grad, r)
+
+
+def test_surface_adopt_and_flatten_order():
+    """scan_amd.surface (host side, no GPU): adopt() re-classes nn.Conv2d / nn.GroupNorm of every sub-model as the scan_amd.layers
+    drop-ins without touching parameters or state_dict keys, and _flatten() puts per-level NCHW maps into the pyramid's row order
+    (level, image, y, x) -- the order the reference concatenates in before its losses (rpn/fcos/loss.py:191-202) and the engine's
+    PyramidShape uses."""
+    import torch
+    from torch import nn
+    from scan_amd import engine, layers, ops, surface
+    model = engine.build_model(9, device="cpu")
+    keys = {k: list(m.state_dict().keys()) for k, m in model.items()}
+    ptrs = {k: [p.data_ptr() for p in m.parameters()] for k, m in model.items()}
+    surface.adopt(model)
+    for k, m in model.items():
+        assert list(m.state_dict().keys()) == keys[k] and [p.data_ptr() for p in m.parameters()] == ptrs[k]
+        for sub in m.modules():
+            assert type(sub) is not nn.Conv2d and type(sub) is not nn.GroupNorm
+    assert isinstance(model["fcos"].head.cls_tower[0], layers.Conv2d) and isinstance(model["fcos"].head.cls_tower[1], layers.GroupNorm)
+    assert model["fcos"].head.cls_tower[1].fuse_relu is False
+    n, c, sizes = 2, 3, [(4, 6), (2, 3), (1, 2)]
+    shape = ops.PyramidShape(n, sizes)
+    levels = [torch.arange(n * c * h * w, dtype=torch.float32).reshape(n, c, h, w) + 1000 * l for l, (h, w) in enumerate(sizes)]
+    rows = surface._flatten(levels)
+    assert rows.shape == (shape.rows, c)
+    for l, (h, w) in enumerate(sizes):
+        for i in range(n):
+            for y in range(h):
+                for x in range(w):
+                    r = shape.row_off[l] + (i * h + y) * w + x
+                    assert torch.equal(rows[r], levels[l][i, :, y, x])
